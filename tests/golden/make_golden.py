@@ -1,0 +1,387 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE (papamarkou/eeyore
+v0.0.20) in the build container.  Run from the repo root:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference lives at /root/reference and never travels to the GPU box; only the .npz files
+written here (inputs + expected outputs) do.  `kanga` (used only by ChainList.to_kanga,
+eeyore/chains/chain_list.py:126-141) is absent from the image, so an empty stand-in module is
+registered before import -- none of the recorded code paths touch it.
+
+Randomness: the reference draws from the global torch generator (hmc.py:134,148; mala.py:53,66).
+While a sampler runs, torch.randn / torch.rand / torch.normal are wrapped so every draw is
+recorded; torch.normal(loc, scale) is expressed as loc + scale * randn (the transformation the
+C-ABI implements), so a trace is a pure function of the recorded (z, u) streams.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("EEYORE_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+for name in ("kanga", "kanga.chains"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["kanga.chains"].ChainArray = type("ChainArray", (), {"__init__": lambda self, vals: None})
+sys.modules["kanga"].chains = sys.modules["kanga.chains"]
+
+import torch  # noqa: E402
+from torch.distributions import Normal  # noqa: E402
+from torch.utils.data import DataLoader  # noqa: E402
+
+from eeyore.chains import ChainList  # noqa: E402
+from eeyore.constants import loss_functions  # noqa: E402
+from eeyore.datasets import XYDataset  # noqa: E402
+from eeyore.models import mlp  # noqa: E402
+from eeyore.samplers import HMC, MALA, MetropolisHastings, PowerPosteriorSampler  # noqa: E402
+import eeyore.stats as st  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ACT = {None: 0, torch.sigmoid: 1}
+LIK = {"binary_classification": 0, "multiclass_classification": 1}
+
+
+def iris_shaped_synthetic(seed=0, per_class=50):
+    """Iris-shaped synthetic data: 3 classes x 50, 4 features, Gaussian per class.
+    Mirrors eeyore_amd.datasets.synthetic.iris_shaped (kept in sync by tests/test_datasets.py)."""
+    rng = np.random.default_rng(seed)
+    means = np.array([[5.0, 3.4, 1.5, 0.2], [5.9, 2.8, 4.3, 1.3], [6.6, 3.0, 5.6, 2.0]])
+    sds = np.array([[0.35, 0.38, 0.17, 0.10], [0.52, 0.31, 0.47, 0.20], [0.64, 0.32, 0.55, 0.27]])
+    xs, ys = [], []
+    for k in range(3):
+        xs.append(means[k] + sds[k] * rng.standard_normal((per_class, 4)))
+        ys.append(np.full(per_class, k))
+    x = np.concatenate(xs)
+    lab = np.concatenate(ys)
+    y = np.zeros((x.shape[0], 3))
+    y[np.arange(x.shape[0]), lab] = 1.0
+    return x, y
+
+
+def datasets(dtype):
+    xor = XYDataset.from_eeyore("xor", dtype=dtype)
+    iris = XYDataset.from_eeyore("iris", yndmin=1, yonehot=True, dtype=dtype)
+    sx, sy = iris_shaped_synthetic()
+    syn = XYDataset(torch.tensor(sx, dtype=dtype), torch.tensor(sy, dtype=dtype))
+    return {"xor": xor, "iris": iris, "synth": syn}
+
+
+MODELS = {
+    # name: (dims, activations, likelihood, dataset)
+    "mlp221": ([2, 2, 1], [torch.sigmoid, torch.sigmoid], "binary_classification", "xor"),
+    "mlp2321": ([2, 3, 2, 1], [torch.sigmoid] * 3, "binary_classification", "xor"),
+    "mlp433": ([4, 3, 3], [torch.sigmoid, None], "multiclass_classification", "iris"),
+    "mlp4323": ([4, 3, 2, 3], [torch.sigmoid, torch.sigmoid, None], "multiclass_classification", "iris"),
+    "mlp432323_iris": ([4, 32, 32, 3], [torch.sigmoid, torch.sigmoid, None], "multiclass_classification", "iris"),
+    "mlp432323_synth": ([4, 32, 32, 3], [torch.sigmoid, torch.sigmoid, None], "multiclass_classification", "synth"),
+}
+
+
+def make_model(name, dtype, prior_sigma=1.0, temperature=None):
+    dims, acts, lik, _ = MODELS[name]
+    hp = mlp.Hyperparameters(dims=dims, bias=[True] * (len(dims) - 1), activations=acts)
+    m = mlp.MLP(loss=loss_functions[lik], hparams=hp, temperature=temperature, dtype=dtype)
+    P = m.num_params()
+    m.prior = Normal(torch.zeros(P, dtype=dtype), prior_sigma * torch.ones(P, dtype=dtype))
+    return m
+
+
+def spec_arrays(name, data, prior_sigma, P):
+    dims, acts, lik, _ = MODELS[name]
+    return dict(dims=np.array(dims), acts=np.array([ACT[a] for a in acts]), lik=np.array(LIK[lik]),
+                x=data.x.numpy(), y=data.y.numpy(), prior_mu=np.zeros(P), prior_sigma=np.full(P, prior_sigma))
+
+
+class Recorder:
+    """Wraps torch.randn / torch.rand / torch.normal and records every draw."""
+
+    def __enter__(self):
+        self.z, self.u = [], []
+        self._randn, self._rand, self._normal = torch.randn, torch.rand, torch.normal
+
+        def randn(*a, **k):
+            v = self._randn(*a, **k)
+            self.z.append(v.clone().numpy())
+            return v
+
+        def rand(*a, **k):
+            v = self._rand(*a, **k)
+            self.u.append(v.clone().numpy())
+            return v
+
+        def normal(mean, std, *a, **k):
+            z = randn(mean.shape, dtype=mean.dtype)
+            return mean + std * z
+
+        torch.randn, torch.rand, torch.normal = randn, rand, normal
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.rand, torch.normal = self._randn, self._rand, self._normal
+
+
+def tnp(v):
+    return v.detach().clone().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
+# ----------------------------------------------------------------------------- G1: KATs of the reference tests
+def g1_kats():
+    out = {}
+    d = datasets(torch.float64)
+    th221 = torch.tensor([1.1, -2.9, -0.4, 0.8, 4.3, 9.2, 4.44, -3.4, 7.2], dtype=torch.float64)  # tests/test_binary_classif_mlp221_log_lik.py:36
+    th2321 = torch.tensor([1.1, -2.9, -0.4, 0.8, 4.3, 9.2, 4.44, -3.4, 7.2, 1.2, -2.3, 0.4, -5.4, -3.3, 2.8, 2.9, 7.7, -4.4, 2, 6],
+                          dtype=torch.float64)  # tests/test_binary_classif_mlp2321_log_lik.py:19-22
+    th4323 = torch.tensor([
+        0.2213, 0.5852, 0.1458, 0.5139, -0.1946, 0.0489, -0.1281, -0.7307,
+        0.2176, 0.3274, -1.3060, 0.3253, -0.4248, 1.7403, 0.6219, 0.2652,
+        -0.5310, -0.0291, 1.0262, -0.4920, 0.4391, -0.2450, 2.3145, -0.0788,
+        1.1180, -1.2803, -0.4435, 0.5371, -0.2440, -0.3574, 0.4446, -0.3453], dtype=torch.float64)  # tests/test_multiclass_classif_mlp4323_log_lik.py:19-25
+    th433 = torch.tensor([
+        0.7735, 0.8161, 0.3910, 0.9622, 0.3748, 0.8711, 0.3315, 0.5473, 0.8820,
+        0.0294, 0.9686, 0.8313, 0.6693, 0.8791, 0.6271, 0.8636, 0.3814, 0.0319,
+        0.5148, 0.5086, 0.7428, 0.5464, 0.5278, 0.6127, 0.4499, 0.1538, 0.9291], dtype=torch.float64)  # tests/test_multiclass_classif_mlp433_log_lik.py:36-39
+    for name, th, sig in (("mlp221", th221, 1.0), ("mlp221_s100", th221, 100.0), ("mlp2321", th2321, 1.0),
+                          ("mlp4323", th4323, 1.0), ("mlp433", th433, 1.0)):
+        base = name.split("_")[0]
+        m = make_model(base, torch.float64, prior_sigma=sig)
+        data = d[MODELS[base][3]]
+        m.set_params(th.clone())
+        ll = m.log_lik(data.x, data.y)
+        lp = m.log_prior()
+        lt, g = m.upto_grad_log_target(th.clone(), data.x, data.y)
+        rec = spec_arrays(base, data, sig, m.num_params())
+        rec.update(theta=tnp(th), log_lik=tnp(ll), log_prior=tnp(lp), log_target=tnp(lt), grad=tnp(g))
+        for k, v in rec.items():
+            out[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g1_kats.npz"), **out)
+    print("g1", len(out))
+
+
+# ----------------------------------------------------------------------------- G2: upto_grad_log_target at seeded thetas
+def g2_grads():
+    out = {}
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        d = datasets(dtype)
+        for name in MODELS:
+            for sig in (1.0, float(np.sqrt(3.0)), 100.0):
+                for temp in (None, 0.3):
+                    if MODELS[name][0][1] == 32 and sig != float(np.sqrt(3.0)):
+                        continue  # keep the fixture small: one prior for the wide model
+                    if tag == "f32" and (sig != float(np.sqrt(3.0)) or name not in ("mlp432323_iris", "mlp432323_synth", "mlp2321")):
+                        continue
+                    m = make_model(name, dtype, prior_sigma=sig, temperature=temp)
+                    data = d[MODELS[name][3]]
+                    P = m.num_params()
+                    torch.manual_seed(1234)
+                    nth = 8 if P < 100 else 3
+                    thetas = 0.5 * torch.randn(nth, P, dtype=dtype)
+                    vals, grads, liks, priors = [], [], [], []
+                    for i in range(nth):
+                        lt, g = m.upto_grad_log_target(thetas[i].clone(), data.x, data.y)
+                        vals.append(tnp(lt)); grads.append(tnp(g))
+                        liks.append(tnp(m.log_lik(data.x, data.y))); priors.append(tnp(m.log_prior()))
+                    key = f"{tag}/{name}/s{sig:.4g}/t{temp}"
+                    rec = spec_arrays(name, data, sig, P)
+                    rec.update(theta=tnp(thetas), log_target=np.array(vals), grad=np.array(grads),
+                               log_lik=np.array(liks), log_prior=np.array(priors),
+                               temperature=np.array(np.nan if temp is None else temp))
+                    for k, v in rec.items():
+                        out[f"{key}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g2_grads.npz"), **out)
+    print("g2", len(out))
+
+
+# ----------------------------------------------------------------------------- G3: HMC.leapfrog
+def g3_leapfrog():
+    out = {}
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        d = datasets(dtype)
+        for name in MODELS:
+            if tag == "f32" and name not in ("mlp432323_synth", "mlp2321"):
+                continue
+            sig = float(np.sqrt(3.0))
+            m = make_model(name, dtype, prior_sigma=sig)
+            data = d[MODELS[name][3]]
+            P = m.num_params()
+            loader = DataLoader(data, batch_size=len(data), shuffle=False)
+            for (eps, L) in ((0.1, 10), (0.01, 20), (0.05, 1)):
+                if P > 100 and (eps, L) == (0.1, 10):
+                    eps = 0.02  # keep the big model's trajectory finite
+                torch.manual_seed(77)
+                th0 = 0.3 * torch.randn(P, dtype=dtype)
+                p0 = torch.randn(P, dtype=dtype)
+                s = HMC(m, theta0=th0.clone(), dataloader=loader, step=eps, num_steps=L, chain=ChainList())
+                thL, pL, tv, gv = s.leapfrog(th0.clone(), p0.clone(), data.x, data.y)
+                key = f"{tag}/{name}/e{eps}_L{L}"
+                rec = spec_arrays(name, data, sig, P)
+                rec.update(theta0=tnp(th0), p0=tnp(p0), step=np.array(eps), L=np.array(L),
+                           thetaL=tnp(thL), pL=tnp(pL), target=tnp(tv), grad=tnp(gv))
+                for k, v in rec.items():
+                    out[f"{key}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g3_leapfrog.npz"), **out)
+    print("g3", len(out))
+
+
+# ----------------------------------------------------------------------------- G4: HMC.draw traces
+def run_trace(sampler, data, iters, keys_extra=()):
+    """Drive sampler.draw like SerialSampler.run does (serial_sampler.py:35-52, full batch) and record."""
+    rows = {k: [] for k in ("sample", "target_val", "accepted") + tuple(keys_extra)}
+    zs, us = [], []
+    sampler.counter.set_epoch_info(iters, 0)
+    for _ in range(iters):
+        with Recorder() as r:
+            sampler.draw(data.x, data.y, savestate=True)
+        zs.append(r.z[0].reshape(-1))
+        us.append(r.u[0].reshape(-1)[0])
+        cur = sampler.current
+        rows["sample"].append(tnp(cur["sample"]))
+        rows["target_val"].append(tnp(cur["target_val"]))
+        rows["accepted"].append(cur["accepted"])
+        for k in keys_extra:
+            rows[k].append(tnp(cur[k]))
+        sampler.counter.increment_idx()
+    rec = {k: np.array(v) for k, v in rows.items()}
+    rec["z"] = np.array(zs)
+    rec["u"] = np.array(us)
+    return rec
+
+
+def g4_hmc_traces():
+    out = {}
+    d = datasets(torch.float64)
+    th221 = torch.tensor([1.1, -2.9, -0.4, 0.8, 4.3, 9.2, 4.44, -3.4, 7.2], dtype=torch.float64)
+    cases = [
+        # key, model, theta0, prior sigma, eps, L, iters
+        ("cfg1", "mlp221", th221, 100.0, 0.1, 10, 50),          # BASELINE config 1
+        ("cfg1_big_step", "mlp221", th221, 100.0, 1.2, 10, 50),  # enough rejections to test the accept rule
+        ("mlp2321", "mlp2321", None, float(np.sqrt(3.0)), 0.9, 8, 50),
+        ("mlp433", "mlp433", None, float(np.sqrt(3.0)), 0.06, 10, 30),
+        ("mlp432323_synth", "mlp432323_synth", None, float(np.sqrt(3.0)), 0.03, 20, 8),
+    ]
+    for key, name, th0, sig, eps, L, iters in cases:
+        m = make_model(name, torch.float64, prior_sigma=sig)
+        data = d[MODELS[name][3]]
+        P = m.num_params()
+        loader = DataLoader(data, batch_size=len(data), shuffle=False)
+        torch.manual_seed(2024)
+        if th0 is None:
+            th0 = 0.1 * torch.randn(P, dtype=torch.float64)
+        s = HMC(m, theta0=th0.clone(), dataloader=loader, step=eps, num_steps=L, chain=ChainList())
+        init_t, init_g = tnp(s.current["target_val"]), tnp(s.current["grad_val"])
+        rec = run_trace(s, data, iters, keys_extra=("hamiltonian",))
+        rec.update(spec_arrays(name, data, sig, P))
+        rec.update(theta0=tnp(th0), init_target=init_t, init_grad=init_g, step=np.array(eps), L=np.array(L))
+        print("g4", key, "acceptance", rec["accepted"].mean())
+        for k, v in rec.items():
+            out[f"{key}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g4_hmc_traces.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G5: MALA / MH traces
+def g5_mala_mh_traces():
+    out = {}
+    d = datasets(torch.float64)
+    sig = float(np.sqrt(3.0))
+    for key, name, kind, par, iters in (("mala_mlp2321", "mlp2321", "mala", 0.6, 60),
+                                        ("mala_mlp433", "mlp433", "mala", 0.012, 40),
+                                        ("mh_mlp2321", "mlp2321", "mh", 0.45, 60),
+                                        ("mh_mlp433", "mlp433", "mh", 0.05, 40)):
+        m = make_model(name, torch.float64, prior_sigma=sig)
+        data = d[MODELS[name][3]]
+        P = m.num_params()
+        loader = DataLoader(data, batch_size=len(data), shuffle=False)
+        torch.manual_seed(99)
+        th0 = 0.5 * torch.randn(P, dtype=torch.float64)
+        if kind == "mala":
+            s = MALA(m, theta0=th0.clone(), dataloader=loader, step=par, chain=ChainList())
+        else:
+            s = MetropolisHastings(m, theta0=th0.clone(), dataloader=loader, chain=ChainList())
+            s.kernel.set_density_params(th0.clone(), scale=torch.full([P], par, dtype=torch.float64))
+        init_t = tnp(s.current["target_val"])
+        init_g = tnp(s.current["grad_val"]) if kind == "mala" else np.zeros(P)
+        rec = run_trace(s, data, iters)
+        rec.update(spec_arrays(name, data, sig, P))
+        rec.update(theta0=tnp(th0), init_target=init_t, init_grad=init_g, par=np.array(par))
+        print("g5", key, "acceptance", rec["accepted"].mean())
+        for k, v in rec.items():
+            out[f"{key}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g5_mala_mh_traces.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G6: power posteriors
+def g6_power_posterior():
+    out = {}
+    d = datasets(torch.float64)
+    sig = float(np.sqrt(3.0))
+    name = "mlp2321"
+    K = 5
+    m = make_model(name, torch.float64, prior_sigma=sig)
+    data = d["xor"]
+    P = m.num_params()
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    torch.manual_seed(5)
+    th0 = 0.5 * torch.randn(P, dtype=torch.float64)
+    s = PowerPosteriorSampler(m, loader, [["MALA", {"step": 0.1}] for _ in range(K)], theta0=th0.clone(),
+                              between_step=1, b=0.5)
+    out["ladder"] = np.array(s.temperature)
+    out["b"] = np.array(0.5)
+    for i in range(K):
+        out[f"cat_probs/{i}"] = tnp(s.eval_categorical_probs(i))
+    # a few within-chain moves so the chains differ, then record swap log-rates for fixed pairs
+    torch.manual_seed(6)
+    for _ in range(5):
+        s.within_chain_moves(data.x, data.y)
+    pairs, rates, ells, temps, lq = [], [], [], [], []
+    for i in range(K):
+        for j in range(K):
+            if i == j:
+                continue
+            r = s.between_chain_move_log_rate(i, j, s.samplers[i], s.samplers[j], data.x, data.y)
+            s.revert_states(s.samplers[i], s.samplers[j])
+            pairs.append((i, j)); rates.append(tnp(r))
+            lq.append((tnp(s.categorical_log_prob(i, j)), tnp(s.categorical_log_prob(j, i))))
+    # untempered log-targets of each chain's current state
+    mm = make_model(name, torch.float64, prior_sigma=sig)
+    for i in range(K):
+        ells.append(tnp(mm.log_target(s.samplers[i].current["sample"].clone(), data.x, data.y)))
+        temps.append(s.temperature[i])
+    out.update(pairs=np.array(pairs), log_rate=np.array(rates), log_q=np.array(lq), ell=np.array(ells),
+               samples=np.array([tnp(s.samplers[i].current["sample"]) for i in range(K)]))
+    for k, v in spec_arrays(name, data, sig, P).items():
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, "g6_power_posterior.npz"), **out)
+    print("g6", len(out))
+
+
+# ----------------------------------------------------------------------------- G7: chain statistics (next rows)
+def g7_stats():
+    out = {}
+    chains = [np.loadtxt(os.path.join(REF, "examples", "stats", f"chain0{i}.csv"), delimiter=",", skiprows=1)
+              for i in range(1, 5)]
+    x = torch.tensor(np.array(chains), dtype=torch.float64)
+    out["chains"] = x.numpy()
+    rhat, _, W, B, _, _ = st.multi_rhat(x)
+    out["multi_rhat"] = np.array(rhat); out["W"] = tnp(W); out["B"] = tnp(B)
+    out["multi_ess"] = np.array([tnp(st.multi_ess(x[i])) for i in range(4)])
+    out["inse_mc_cov"] = np.array([tnp(st.inse_mc_cov(x[i])) for i in range(4)])
+    out["cov"] = np.array([tnp(st.cov(x[i], rowvar=False)) for i in range(4)])
+    np.savez_compressed(os.path.join(HERE, "g7_stats.npz"), **out)
+    print("g7 rhat", out["multi_rhat"], "ess", out["multi_ess"])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    g1_kats()
+    g2_grads()
+    g3_leapfrog()
+    g4_hmc_traces()
+    g5_mala_mh_traces()
+    g6_power_posterior()
+    g7_stats()
+    # bundled datasets re-exported as data fixtures (inputs only)
+    d = datasets(torch.float64)
+    np.savez_compressed(os.path.join(HERE, "datasets.npz"), xor_x=d["xor"].x.numpy(), xor_y=d["xor"].y.numpy(),
+                        iris_x=d["iris"].x.numpy(), iris_y=d["iris"].y.numpy())

@@ -1,0 +1,129 @@
+"""The numpy oracle against every golden vector captured from the reference (tests/golden/make_golden.py)
+and against the known-answer values of the reference's own tests."""
+import numpy as np
+import pytest
+
+from oracle import mlp_oracle as orc
+from tests.helpers import groups, load, spec_from
+
+KAT = {  # SURVEY.md section 4, computed with the reference
+    "mlp221/log_lik": -16.08587869723768,
+    "mlp221/log_prior": -106.60224679884205,
+    "mlp221_s100/log_target": -65.81269034997256,
+    "mlp2321/log_lik": -7.39132872690876,
+    "mlp4323/log_lik": -187.79398747047628,
+    "mlp433/log_lik": -176.25449918882558,
+}
+KAT_GRAD_221 = [-0.31125019417302047, -0.31040841228821037, 0.0002700236585229453, 0.00015006352409646542,
+                -0.36974887883749585, -0.000346705861808311, -1.909804588374762, -1.9979385440124289,
+                -1.9991671747169164]
+
+
+def test_g1_kats_match_survey_values():
+    z = load("g1_kats.npz")
+    for k, v in KAT.items():
+        assert float(z[k]) == pytest.approx(v, rel=0, abs=1e-12)
+    np.testing.assert_allclose(z["mlp221_s100/grad"], KAT_GRAD_221, rtol=0, atol=1e-13)
+
+
+def test_g1_oracle():
+    for name, rec in groups(load("g1_kats.npz")).items():
+        spec = spec_from(rec)
+        th = rec["theta"]
+        assert orc.log_lik(spec, th, rec["x"], rec["y"]) == pytest.approx(float(rec["log_lik"]), rel=1e-13)
+        assert orc.log_prior(spec, th) == pytest.approx(float(rec["log_prior"]), rel=1e-13)
+        t, g = orc.upto_grad_log_target(spec, th, rec["x"], rec["y"])
+        assert t == pytest.approx(float(rec["log_target"]), rel=1e-13)
+        np.testing.assert_allclose(g, rec["grad"], rtol=1e-11, atol=1e-13)
+
+
+def test_parameter_layout_mlp2321():
+    # tests/test_binary_classif_mlp2321_log_lik.py:50-64 of the reference: W then b per layer
+    spec = orc.Spec([2, 3, 2, 1], [1, 1, 1], 0)
+    assert spec.w_off == [0, 9, 17] and spec.b_off == [6, 15, 19] and spec.P == 20
+
+
+@pytest.mark.parametrize("tag,rtol,atol", [("f64", 1e-10, 1e-12), ("f32", 2e-4, 2e-4)])
+def test_g2_grads(tag, rtol, atol):
+    dt = np.float64 if tag == "f64" else np.float32
+    n = 0
+    for name, rec in groups(load("g2_grads.npz")).items():
+        if not name.startswith(tag):
+            continue
+        spec = spec_from(rec, dt)
+        for i in range(rec["theta"].shape[0]):
+            th = rec["theta"][i].astype(dt)
+            t, g = orc.upto_grad_log_target(spec, th, rec["x"].astype(dt), rec["y"].astype(dt))
+            assert t.dtype == dt and g.dtype == dt
+            np.testing.assert_allclose(t, rec["log_target"][i], rtol=rtol, atol=atol * 10)
+            np.testing.assert_allclose(g, rec["grad"][i], rtol=rtol, atol=atol)
+            if tag == "f64":
+                ll = orc.log_lik(spec, th, rec["x"], rec["y"])
+                lp = orc.log_prior(spec, th)
+                np.testing.assert_allclose(ll, rec["log_lik"][i], rtol=1e-12)
+                np.testing.assert_allclose(lp, rec["log_prior"][i], rtol=1e-12)
+            n += 1
+    assert n > 10
+
+
+def test_g3_leapfrog_f64():
+    n = 0
+    for name, rec in groups(load("g3_leapfrog.npz")).items():
+        if not name.startswith("f64"):
+            continue
+        spec = spec_from(rec)
+        th, p, t, g = orc.leapfrog(spec, rec["theta0"], rec["p0"], rec["x"], rec["y"], float(rec["step"]), int(rec["L"]))
+        np.testing.assert_allclose(th, rec["thetaL"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(p, rec["pL"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(t, rec["target"], rtol=1e-10)
+        np.testing.assert_allclose(g, rec["grad"], rtol=1e-8, atol=1e-10)
+        n += 1
+    assert n == 18
+
+
+def _replay(rec, kind):
+    spec = spec_from(rec)
+    x, y = rec["x"], rec["y"]
+    cur = dict(sample=rec["theta0"].copy(), target_val=rec["init_target"][()], grad_val=rec["init_grad"].copy())
+    iters = rec["z"].shape[0]
+    margins = []
+    for it in range(iters):
+        if kind == "hmc":
+            cur, info = orc.hmc_draw(spec, cur, rec["z"][it], rec["u"][it], x, y, float(rec["step"]), int(rec["L"]))
+            margins.append(abs(float(rec["u"][it]) - float(info["rate"])))
+        elif kind == "mala":
+            cur, info = orc.mala_draw(spec, cur, rec["z"][it], rec["u"][it], x, y, float(rec["par"]))
+            margins.append(abs(np.log(float(rec["u"][it])) - float(info["log_rate"])))
+        else:
+            cur, info = orc.mh_draw(spec, cur, rec["z"][it], rec["u"][it], x, y, float(rec["par"]))
+            margins.append(abs(np.log(float(rec["u"][it])) - float(info["log_rate"])))
+        assert info["accepted"] == int(rec["accepted"][it]), (it, margins[-1])
+        np.testing.assert_allclose(cur["sample"], rec["sample"][it], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(cur["target_val"], rec["target_val"][it], rtol=1e-9)
+    return min(margins)
+
+
+def test_g4_hmc_traces_accept_bit_exact():
+    for name, rec in groups(load("g4_hmc_traces.npz")).items():
+        m = _replay(rec, "hmc")
+        assert m > 1e-9, (name, m)  # no decision sits inside rounding distance of the threshold
+
+
+def test_g5_mala_mh_traces_accept_bit_exact():
+    for name, rec in groups(load("g5_mala_mh_traces.npz")).items():
+        m = _replay(rec, "mala" if name.startswith("mala") else "mh")
+        assert m > 1e-9, (name, m)
+
+
+def test_g6_power_posterior():
+    z = load("g6_power_posterior.npz")
+    K = len(z["ladder"])
+    np.testing.assert_allclose(orc.pt_ladder(K), z["ladder"], rtol=1e-15)
+    for i in range(K):
+        np.testing.assert_allclose(orc.pt_categorical_probs(i, K, float(z["b"])), z[f"cat_probs/{i}"], rtol=1e-12)
+    spec = orc.Spec(z["dims"].tolist(), z["acts"].tolist(), int(z["lik"]), mu=z["prior_mu"], sigma=z["prior_sigma"])
+    ell = np.array([orc.log_target(spec, z["samples"][i], z["x"], z["y"]) for i in range(K)])
+    np.testing.assert_allclose(ell, z["ell"], rtol=1e-12)
+    for (i, j), lr, lq in zip(z["pairs"], z["log_rate"], z["log_q"]):
+        got = orc.pt_swap_log_rate(lq[0], lq[1], ell[i], ell[j], z["ladder"][i], z["ladder"][j])
+        np.testing.assert_allclose(got, lr, rtol=1e-9, atol=1e-10)
