@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog-steps/sec x chains, HMC on MLP(4-32-32-3), Iris-shaped synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one HMC iteration of every chain of the rank (one launch of the fused trajectory kernel: momentum
+draw from the in-kernel Philox stream, L = 20 leapfrog steps, accept, state update), BASELINE.json configs[2]:
+4096 chains per GPU, MLP(4-32-32-3; sigmoid, sigmoid, None), CE-sum, prior N(0, sqrt 3), N = 150 rows, fp32.
+Chains shard over ranks with no collective in the step (weak scaling: 4096 chains per GPU, configs[3] at N = 8);
+when N > 1 the per-parameter R-hat summary is all-reduced over RCCL once at the end of the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DIMS = [4, 32, 32, 3]
+N_ROWS = 150
+L_STEPS = 20
+CHAINS_PER_GPU = 4096
+STEP_SIZE = 0.011
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def flops_per_leapfrog_step(dims, n_rows):
+    """F_step = 2 N (2 sum_l d_l d_{l+1} + sum_{l>=1} d_l d_{l+1}) + 6 P (unpadded, no credit for the
+    reference's redundant first evaluation)."""
+    prods = [dims[i] * dims[i + 1] for i in range(len(dims) - 1)]
+    P = sum((dims[i] + 1) * dims[i + 1] for i in range(len(dims) - 1))
+    return 2 * n_rows * (2 * sum(prods) + sum(prods[1:])) + 6 * P
+
+
+def cpu_baseline(x, y, sigma, budget_s=12.0):
+    """The C oracle (oracle/mlp_oracle.c, a port of the reference's algorithm) timed on this host's cores on a
+    bounded sample of the same workload.  The oracle is the checker, never the product."""
+    from oracle.c_oracle import COracle
+    cores = min(os.cpu_count() or 1, 16)
+    co = COracle(DIMS, [1, 1, 0], 1, x, y, 0.0, sigma, dtype=np.float32, nthreads=cores)
+    rng = np.random.default_rng(0)
+    P = co.P
+
+    def run(C, iters):
+        th = (0.1 * rng.standard_normal((C, P))).astype(np.float32)
+        tv = np.zeros(C, np.float32)
+        g = np.zeros((C, P), np.float32)
+        for c in range(C):
+            tv[c], g[c], _, _ = co.log_target_grad(th[c])
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            co.hmc_draw(th, tv, g, rng.standard_normal((C, P)).astype(np.float32), rng.random(C).astype(np.float32),
+                        STEP_SIZE, L_STEPS)
+        return time.perf_counter() - t0
+
+    C0 = 2 * cores
+    t_probe = run(C0, 1)
+    iters = max(1, int(budget_s / max(t_probe, 1e-3)))
+    iters = min(iters, 50)
+    t = run(C0, iters)
+    return {"value": C0 * iters * L_STEPS / t, "unit": "leapfrog-steps/sec x chains", "cores": cores, "kind": "port",
+            "sample": f"{C0} chains x {iters} HMC iterations (L={L_STEPS}, L+1 gradient evaluations each as "
+                      f"hmc.py:104), f32, C oracle with OpenMP over chains, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-generic", action="store_true", help="time the generic VALU kernel instead of the MFMA one")
+    args = ap.parse_args()
+
+    from eeyore_amd import _lib as L
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.distributed import ChainStats, init_from_env
+    from eeyore_amd.plan import Plan
+
+    rank, world, local = init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    C = args.chains_per_gpu
+    chain_offset = rank * C
+
+    xs, ys = synthetic.iris_shaped_arrays(seed=0)
+    sigma = float(np.sqrt(3.0))
+    plan = Plan(DIMS, [1, 1, 1], [1, 1, 0], 1, torch.float32, dev)
+    plan.set_data(torch.tensor(xs, dtype=torch.float32, device=dev), torch.tensor(ys, dtype=torch.float32, device=dev))
+    plan.set_prior(torch.zeros(plan.P), torch.full((plan.P,), sigma))
+    P = plan.P
+
+    # theta0 = 0.1 N(0,1), seed 0, keyed by the global chain id so results do not depend on the GPU count
+    theta = 0.1 * plan.philox_normal(C, seed=0, it=0, chain_offset=chain_offset)
+    target, grad = plan.log_target_grad(theta)
+    out = dict(accepted=plan.empty(C, dtype=torch.uint8), rate=plan.empty(C), h_cur=plan.empty(C), h_prop=plan.empty(C))
+    stats = ChainStats(C, P, dev)
+    flags = L.EY_FORCE_GENERIC if args.force_generic else 0
+    seed = 2024
+
+    def step(it):
+        plan.hmc_step(theta, target, grad, STEP_SIZE, L_STEPS, seed=seed, it=it, chain_offset=chain_offset, flags=flags,
+                      out=out)
+
+    it = 1
+    for _ in range(args.warmup):
+        step(it); it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    for _ in range(args.steps):
+        step(it); it += 1
+        stats.update(theta, out["accepted"])
+    summ = stats.summary() if args.steps > 1 else None  # RCCL all-reduce of [3, P] partial sums when world > 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # dominant kernel, timed per launch with HIP events on the launch stream (torch's current stream)
+    n_ev = 10
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for a, b in evs:
+        a.record(); step(it); b.record(); it += 1
+    torch.cuda.synchronize()
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    if rank == 0:
+        f_step = flops_per_leapfrog_step(DIMS, N_ROWS)
+        total_chains = C * world
+        value = total_chains * L_STEPS * args.steps / elapsed
+        achieved_tflops = f_step * L_STEPS * C / (kern_ms * 1e-3) / 1e12
+        line = {
+            "metric": "leapfrog-steps/sec x chains, HMC MLP(4-32-32-3)",
+            "value": value,
+            "unit": "leapfrog-steps/sec x chains",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"HMC L={L_STEPS}, {C} chains/GPU ({total_chains} total), MLP(4-32-32-3) sigmoid-sigmoid-"
+                            f"linear, CE-sum, prior N(0,sqrt3), Iris-shaped synthetic N={N_ROWS} (BASELINE configs[2]"
+                            f"{'; configs[3] sharding' if world > 1 else ''})",
+                "chains_per_gpu": C, "num_steps": L_STEPS, "step_size": STEP_SIZE, "rng": "in-kernel Philox4x32-10",
+                "kernel": "generic" if args.force_generic else plan.kernel,
+                "gradient_evaluations_per_iteration": L_STEPS,
+                "acceptance": None if summ is None else round(summ["acceptance"], 4),
+                "max_rhat": None if summ is None else round(float(summ["rhat"].max().item()), 4),
+            },
+            "roofline": {
+                "bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "kernel_ms": kern_ms, "flops_per_leapfrog_step_per_chain": f_step,
+            },
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(xs, ys, sigma)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

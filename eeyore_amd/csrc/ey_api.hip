@@ -1,0 +1,349 @@
+// C-ABI entry points (include/eeyore_amd.h): argument validation, plan management, dispatch to the kernel
+// families.  No torch types cross this boundary.
+#include <math.h>
+
+#include <vector>
+
+#include "ey_common.h"
+
+static thread_local std::string g_err;
+void ey_set_error(const std::string& msg) { g_err = msg; }
+
+extern "C" {
+
+int ey_version(void) { return EY_VERSION; }
+const char* ey_last_error(void) { return g_err.c_str(); }
+
+int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias, const int* act, int likelihood,
+                   int dtype, int device_id) {
+  if (!out || !dims || !act) EY_FAIL(EY_ERR_INVALID, "ey_plan_create: null argument");
+  // Hyperparameters: len(dims) >= 3 and len(dims) == len(activations)+1 (eeyore/models/mlp.py:15-19).  A
+  // single layer (logistic regression, eeyore/models/logistic_regression.py) is accepted as the K=1 case.
+  if (n_layers < 1 || n_layers > EY_MAX_LAYERS) EY_FAIL(EY_ERR_INVALID, "ey_plan_create: n_layers must be in 1..8");
+  if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_plan_create: dtype must be EY_F32 or EY_F64");
+  if (likelihood != EY_LIK_BCE_SUM && likelihood != EY_LIK_CE_SUM)
+    EY_FAIL(EY_ERR_INVALID, "ey_plan_create: unknown likelihood");
+  for (int l = 0; l <= n_layers; ++l)
+    if (dims[l] < 1) EY_FAIL(EY_ERR_INVALID, "ey_plan_create: dims must be positive");
+  for (int l = 0; l < n_layers; ++l)
+    if (act[l] < EY_ACT_NONE || act[l] > EY_ACT_RELU) EY_FAIL(EY_ERR_INVALID, "ey_plan_create: unknown activation");
+  int ndev = 0;
+  EY_HIP(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) EY_FAIL(EY_ERR_INVALID, "ey_plan_create: no such device");
+  ey_plan* pl = new ey_plan();
+  EyModel& m = pl->m;
+  m.nl = n_layers;
+  int P = 0, hr = 0, dmax = 0;
+  for (int l = 0; l <= n_layers; ++l) {
+    m.dims[l] = dims[l];
+    m.hoff[l] = hr;
+    hr += dims[l];
+    if (dims[l] > dmax) dmax = dims[l];
+  }
+  for (int l = 0; l < n_layers; ++l) {
+    m.bias[l] = bias ? (bias[l] != 0) : 1;
+    m.act[l] = act[l];
+    m.woff[l] = P;
+    P += dims[l + 1] * dims[l];
+    m.boff[l] = m.bias[l] ? P : -1;
+    if (m.bias[l]) P += dims[l + 1];
+  }
+  m.hrows = hr;
+  m.dmax = dmax;
+  m.lik = likelihood;
+  m.P = P;
+  m.N = 0;
+  m.x = m.y = m.mu = m.inv_var = nullptr;
+  m.labels = nullptr;
+  m.prior_const = 0.0;
+  pl->dtype = dtype;
+  pl->device = device_id;
+  pl->has_data = pl->has_prior = false;
+  pl->d_x = pl->d_y = pl->d_mu = pl->d_inv_var = nullptr;
+  pl->d_labels = nullptr;
+  pl->d_xpack = nullptr;
+  hipDeviceProp_t prop;
+  EY_HIP(hipGetDeviceProperties(&prop, device_id));
+  pl->n_cu = prop.multiProcessorCount;
+  pl->mfma32_ok = ey_mfma32_supports(pl);
+  *out = pl;
+  return EY_OK;
+}
+
+int ey_plan_destroy(ey_plan* pl) {
+  if (!pl) return EY_OK;
+  (void)hipSetDevice(pl->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(pl->d_x);
+  (void)hipFree(pl->d_y);
+  (void)hipFree(pl->d_mu);
+  (void)hipFree(pl->d_inv_var);
+  (void)hipFree(pl->d_labels);
+  (void)hipFree(pl->d_xpack);
+  delete pl;
+  return EY_OK;
+}
+
+int ey_plan_num_params(const ey_plan* pl, int64_t* P) {
+  if (!pl || !P) EY_FAIL(EY_ERR_INVALID, "ey_plan_num_params: null argument");
+  *P = pl->m.P;
+  return EY_OK;
+}
+
+const char* ey_plan_kernel(const ey_plan* pl) { return (pl && pl->mfma32_ok) ? "mfma32" : "generic"; }
+
+static size_t esize(const ey_plan* pl) { return pl->dtype == EY_F32 ? 4 : 8; }
+
+int ey_plan_set_data(ey_plan* pl, const void* x, const void* y, int64_t N, void* stream) {
+  if (!pl || !x || !y) EY_FAIL(EY_ERR_INVALID, "ey_plan_set_data: null argument");
+  if (N < 1 || N > (1 << 24)) EY_FAIL(EY_ERR_INVALID, "ey_plan_set_data: N out of range");
+  hipStream_t s = (hipStream_t)stream;
+  EY_HIP(hipSetDevice(pl->device));
+  EyModel& m = pl->m;
+  const size_t es = esize(pl);
+  const int d0 = m.dims[0], dK = m.dims[m.nl];
+  EY_HIP(hipStreamSynchronize(s));
+  (void)hipFree(pl->d_x); (void)hipFree(pl->d_y); (void)hipFree(pl->d_labels);
+  pl->d_x = pl->d_y = nullptr; pl->d_labels = nullptr;
+  EY_HIP(hipMalloc(&pl->d_x, es * N * d0));
+  EY_HIP(hipMalloc(&pl->d_y, es * N * dK));
+  EY_HIP(hipMalloc((void**)&pl->d_labels, sizeof(int) * N));
+  EY_HIP(hipMemcpyAsync(pl->d_x, x, es * N * d0, hipMemcpyDeviceToDevice, s));
+  EY_HIP(hipMemcpyAsync(pl->d_y, y, es * N * dK, hipMemcpyDeviceToDevice, s));
+  // labels = argmax(y, 1), first maximal index (eeyore/constants/constants.py:17)
+  std::vector<unsigned char> hy(es * N * dK);
+  EY_HIP(hipMemcpyAsync(hy.data(), y, hy.size(), hipMemcpyDeviceToHost, s));
+  EY_HIP(hipStreamSynchronize(s));
+  std::vector<int> lab(N);
+  for (int64_t n = 0; n < N; ++n) {
+    int best = 0;
+    double bv = 0;
+    for (int j = 0; j < dK; ++j) {
+      const double v = es == 4 ? (double)((const float*)hy.data())[n * dK + j] : ((const double*)hy.data())[n * dK + j];
+      if (j == 0 || v > bv) { bv = v; best = j; }
+    }
+    lab[n] = best;
+  }
+  EY_HIP(hipMemcpy(pl->d_labels, lab.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+  m.N = (int)N;
+  m.x = pl->d_x;
+  m.y = pl->d_y;
+  m.labels = pl->d_labels;
+  pl->has_data = true;
+  if (pl->mfma32_ok) {
+    int rc = ey_mfma32_set_data(pl, s);
+    if (rc) return rc;
+  }
+  return EY_OK;
+}
+
+int ey_plan_set_prior(ey_plan* pl, const void* mu, const void* sigma, void* stream) {
+  if (!pl || !mu || !sigma) EY_FAIL(EY_ERR_INVALID, "ey_plan_set_prior: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  EY_HIP(hipSetDevice(pl->device));
+  EyModel& m = pl->m;
+  const size_t es = esize(pl);
+  const int P = m.P;
+  EY_HIP(hipStreamSynchronize(s));
+  if (!pl->d_mu) EY_HIP(hipMalloc(&pl->d_mu, es * P));
+  if (!pl->d_inv_var) EY_HIP(hipMalloc(&pl->d_inv_var, es * P));
+  std::vector<unsigned char> hs(es * P);
+  EY_HIP(hipMemcpyAsync(pl->d_mu, mu, es * P, hipMemcpyDeviceToDevice, s));
+  EY_HIP(hipMemcpyAsync(hs.data(), sigma, es * P, hipMemcpyDeviceToHost, s));
+  EY_HIP(hipStreamSynchronize(s));
+  // Normal.log_prob = -(v-mu)^2/(2 sigma^2) - log(sigma) - log(sqrt(2 pi)); the theta-independent part is
+  // summed once here (in double), the quadratic part is evaluated per call with 1/sigma^2.
+  double c = 0.0;
+  std::vector<unsigned char> hiv(es * P);
+  for (int i = 0; i < P; ++i) {
+    const double sg = es == 4 ? (double)((const float*)hs.data())[i] : ((const double*)hs.data())[i];
+    if (!(sg > 0.0)) EY_FAIL(EY_ERR_INVALID, "ey_plan_set_prior: sigma must be positive");
+    c += -log(sg) - 0.91893853320467274178;
+    if (es == 4) ((float*)hiv.data())[i] = 1.0f / ((float)sg * (float)sg);
+    else ((double*)hiv.data())[i] = 1.0 / (sg * sg);
+  }
+  EY_HIP(hipMemcpy(pl->d_inv_var, hiv.data(), es * P, hipMemcpyHostToDevice));
+  m.mu = pl->d_mu;
+  m.inv_var = pl->d_inv_var;
+  m.prior_const = c;
+  pl->has_prior = true;
+  return EY_OK;
+}
+
+static int check_ready(const ey_plan* pl, int64_t C, const char* who) {
+  if (!pl) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": null plan");
+  if (!pl->has_data) EY_FAIL(EY_ERR_STATE, std::string(who) + ": ey_plan_set_data has not been called");
+  if (!pl->has_prior) EY_FAIL(EY_ERR_STATE, std::string(who) + ": ey_plan_set_prior has not been called");
+  if (C < 0 || C > 0x7fffffffLL) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": chain count out of range");
+  return EY_OK;
+}
+
+int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* log_lik, void* log_prior,
+                  void* stream) {
+  if (!pl) EY_FAIL(EY_ERR_INVALID, "ey_log_target: null plan");
+  // log_prior alone (bayesian_model.py:46-50) needs no data: with no rows attached the likelihood sum is empty
+  if (!log_lik && !pl->has_data && pl->has_prior) {
+    if (!theta) EY_FAIL(EY_ERR_INVALID, "ey_log_target: null theta");
+    if (C <= 0) return EY_OK;
+    EY_HIP(hipSetDevice(pl->device));
+    return ey_generic_log_target(pl, theta, temp, C, nullptr, log_prior, nullptr, nullptr, (hipStream_t)stream);
+  }
+  int rc = check_ready(pl, C, "ey_log_target");
+  if (rc) return rc;
+  if (!theta) EY_FAIL(EY_ERR_INVALID, "ey_log_target: null theta");
+  if (C == 0) return EY_OK;
+  EY_HIP(hipSetDevice(pl->device));
+  return ey_generic_log_target(pl, theta, temp, C, log_lik, log_prior, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int ey_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,
+                       void* stream) {
+  int rc = check_ready(pl, C, "ey_log_target_grad");
+  if (rc) return rc;
+  if (!theta || !target || !grad) EY_FAIL(EY_ERR_INVALID, "ey_log_target_grad: null argument");
+  if (C == 0) return EY_OK;
+  EY_HIP(hipSetDevice(pl->device));
+  return ey_generic_log_target(pl, theta, temp, C, nullptr, nullptr, target, grad, (hipStream_t)stream);
+}
+
+int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                uint64_t chain_offset, uint32_t flags, void* accepted, void* accept_rate, void* H_cur, void* H_prop,
+                void* stream) {
+  int rc = check_ready(pl, C, "ey_hmc_step");
+  if (rc) return rc;
+  if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: null argument");
+  if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: num_steps must be >= 1");
+  if (C == 0) return EY_OK;
+  EY_HIP(hipSetDevice(pl->device));
+  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+    return ey_mfma32_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+                         accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
+  return ey_generic_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+                        accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
+}
+
+int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                    int64_t C, void* target, void* grad, void* stream) {
+  int rc = check_ready(pl, C, "ey_hmc_leapfrog");
+  if (rc) return rc;
+  if (!theta || !p || !target || !grad) EY_FAIL(EY_ERR_INVALID, "ey_hmc_leapfrog: null argument");
+  if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_leapfrog: num_steps must be >= 1");
+  if (C == 0) return EY_OK;
+  EY_HIP(hipSetDevice(pl->device));
+  return ey_generic_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
+}
+
+int ey_mala_step(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                 const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                 uint64_t chain_offset, uint32_t flags, void* accepted, void* log_rate, void* stream) {
+  (void)flags;
+  int rc = check_ready(pl, C, "ey_mala_step");
+  if (rc) return rc;
+  if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: null argument");
+  if (!(step > 0.0) && !step_vec) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: step must be positive");
+  if (C == 0) return EY_OK;
+  EY_HIP(hipSetDevice(pl->device));
+  return ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
+                         log_rate, (hipStream_t)stream);
+}
+
+int ey_mh_step(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
+               const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
+               void* accepted, void* log_rate, void* stream) {
+  (void)flags;
+  int rc = check_ready(pl, C, "ey_mh_step");
+  if (rc) return rc;
+  if (!theta || !target || !scale || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mh_step: null argument");
+  if (C == 0) return EY_OK;
+  EY_HIP(hipSetDevice(pl->device));
+  return ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
+                       (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ----------------------------------------------------------------------------------------------- small kernels
+template <typename T>
+__global__ void k_pt_swap(const T* ell_i, const T* ell_j, const T* t_i, const T* t_j, const T* dlogq, const T* u,
+                          int64_t C, unsigned char* swap, T* log_rate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  // power_posterior_sampler.py:135-141 with T_k = t_k * ell:  dlogq + (t_i - t_j) * (ell_j - ell_i)
+  T lr = (t_i[c] - t_j[c]) * (ell_j[c] - ell_i[c]);
+  if (dlogq) lr += dlogq[c];
+  const T lu = sizeof(T) == 4 ? (T)logf((float)u[c]) : (T)log((double)u[c]);
+  swap[c] = lu < lr ? 1 : 0;  // :160
+  if (log_rate) log_rate[c] = lr;
+}
+
+template <typename T>
+__global__ void k_philox_normal(T* out, int64_t C, int64_t P, uint64_t seed, uint64_t iter, uint64_t chain_offset) {
+  const int64_t c = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const EyRng r = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
+  out[c * P + i] = ey_rng_normal<T>(r, (uint32_t)i);
+}
+
+template <typename T>
+__global__ void k_philox_uniform(T* out, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const EyRng r = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
+  out[c] = ey_rng_uniform<T>(r);
+}
+
+extern "C" {
+
+int ey_pt_swap_decide(const void* ell_i, const void* ell_j, const void* t_i, const void* t_j, const void* dlogq,
+                      const void* u, int64_t C, int dtype, void* swap, void* log_rate, void* stream) {
+  if (!ell_i || !ell_j || !t_i || !t_j || !u || !swap) EY_FAIL(EY_ERR_INVALID, "ey_pt_swap_decide: null argument");
+  if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_pt_swap_decide: bad dtype");
+  if (C <= 0) return EY_OK;
+  const unsigned nb = (unsigned)((C + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EY_F32)
+    hipLaunchKernelGGL(k_pt_swap<float>, dim3(nb), dim3(256), 0, s, (const float*)ell_i, (const float*)ell_j,
+                       (const float*)t_i, (const float*)t_j, (const float*)dlogq, (const float*)u, C,
+                       (unsigned char*)swap, (float*)log_rate);
+  else
+    hipLaunchKernelGGL(k_pt_swap<double>, dim3(nb), dim3(256), 0, s, (const double*)ell_i, (const double*)ell_j,
+                       (const double*)t_i, (const double*)t_j, (const double*)dlogq, (const double*)u, C,
+                       (unsigned char*)swap, (double*)log_rate);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+int ey_philox_normal(void* out, int64_t C, int64_t P, uint64_t seed, uint64_t iter, uint64_t chain_offset, int dtype,
+                     void* stream) {
+  if (!out) EY_FAIL(EY_ERR_INVALID, "ey_philox_normal: null argument");
+  if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_philox_normal: bad dtype");
+  if (C <= 0 || P <= 0) return EY_OK;
+  if (C > 65535) EY_FAIL(EY_ERR_INVALID, "ey_philox_normal: at most 65535 chains per call");
+  const dim3 grid((unsigned)((P + 255) / 256), (unsigned)C);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EY_F32)
+    hipLaunchKernelGGL(k_philox_normal<float>, grid, dim3(256), 0, s, (float*)out, C, P, seed, iter, chain_offset);
+  else
+    hipLaunchKernelGGL(k_philox_normal<double>, grid, dim3(256), 0, s, (double*)out, C, P, seed, iter, chain_offset);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, int dtype,
+                      void* stream) {
+  if (!out) EY_FAIL(EY_ERR_INVALID, "ey_philox_uniform: null argument");
+  if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_philox_uniform: bad dtype");
+  if (C <= 0) return EY_OK;
+  const unsigned nb = (unsigned)((C + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EY_F32)
+    hipLaunchKernelGGL(k_philox_uniform<float>, dim3(nb), dim3(256), 0, s, (float*)out, C, seed, iter, chain_offset);
+  else
+    hipLaunchKernelGGL(k_philox_uniform<double>, dim3(nb), dim3(256), 0, s, (double*)out, C, seed, iter, chain_offset);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+// Shared host/device definitions for the eeyore_amd HIP library (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/eeyore_amd.h"
+
+#define EY_MAX_LAYERS 8
+#define EY_VERSION 100  // 0.1.0
+
+// ----------------------------------------------------------------------------------------------- errors
+void ey_set_error(const std::string& msg);
+#define EY_FAIL(code, msg) \
+  do {                     \
+    ey_set_error(msg);     \
+    return (code);         \
+  } while (0)
+#define EY_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      ey_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                            \
+      return EY_ERR_HIP;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------------- plan
+// Device-visible model description, passed to kernels by value.
+struct EyModel {
+  int nl;                        // number of layers K
+  int dims[EY_MAX_LAYERS + 1];   // d_0..d_K
+  int bias[EY_MAX_LAYERS];
+  int act[EY_MAX_LAYERS];
+  int woff[EY_MAX_LAYERS];       // offset of W_l in theta
+  int boff[EY_MAX_LAYERS];       // offset of b_l in theta, -1 if none
+  int hoff[EY_MAX_LAYERS + 1];   // first activation row of layer l in the per-tile activation store
+  int hrows;                     // sum of d_l
+  int dmax;                      // max d_l
+  int lik;
+  int P;
+  int N;
+  const void* x;        // [N, d0]
+  const void* y;        // [N, dK]
+  const int* labels;    // [N] argmax(y,1) (CE)
+  const void* mu;       // [P]
+  const void* inv_var;  // [P] 1/sigma^2
+  double prior_const;   // sum_i (-log sigma_i - 0.5 log 2pi)
+};
+
+struct ey_plan {
+  EyModel m;
+  int dtype;
+  int device;
+  bool has_data, has_prior;
+  void *d_x, *d_y, *d_mu, *d_inv_var;
+  int* d_labels;
+  // mfma32 path (4-32-32-3-like models, f32): padded/packed data image
+  bool mfma32_ok;
+  void* d_xpack;
+  int n_cu;
+};
+
+// generic kernels (ey_generic.hip)
+int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+                          void* target, void* grad, hipStream_t s);
+int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                   hipStream_t s);
+int ey_generic_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                        int64_t C, void* target, void* grad, hipStream_t s);
+int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                    const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                    uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s);
+int ey_generic_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
+                  const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
+                  void* log_rate, hipStream_t s);
+
+// mfma32 kernels (ey_mfma32.hip)
+bool ey_mfma32_supports(const ey_plan* pl);
+int ey_mfma32_set_data(ey_plan* pl, hipStream_t s);
+int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                  const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                  uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                  hipStream_t s);
+int ey_mfma32_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,
+                              hipStream_t s);
+
+// ----------------------------------------------------------------------------------------------- Philox4x32-10
+// Counter-based generator (Salmon et al. 2011).  One call per (element, chain, iteration, stream): the value a
+// lane needs never depends on which lane asks, so every kernel layout reproduces the same stream.
+#define EY_STREAM_NORMAL 0u
+#define EY_STREAM_UNIFORM 1u
+
+struct EyRng {
+  uint32_t k0, k1;  // key = seed
+  uint32_t c1, c2, c3;  // chain, iter_lo, (iter_hi << 8) | stream
+};
+
+__host__ __device__ inline void ey_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1, uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += W0;
+    k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__host__ __device__ inline EyRng ey_rng_make(uint64_t seed, uint64_t chain, uint64_t iter, uint32_t stream) {
+  EyRng r;
+  r.k0 = (uint32_t)seed;
+  r.k1 = (uint32_t)(seed >> 32);
+  r.c1 = (uint32_t)chain;
+  r.c2 = (uint32_t)iter;
+  r.c3 = ((uint32_t)(iter >> 32) << 8) | (stream & 0xffu) | ((uint32_t)(chain >> 32) << 20);
+  return r;
+}
+
+// N(0,1) for element idx.  Box-Muller on two 24-bit (f32) / 32+21-bit (f64) uniforms.  Contraction is off so
+// the fused kernels and ey_philox_normal produce bit-identical values.
+template <typename T>
+__device__ inline T ey_rng_normal(const EyRng& r, uint32_t idx);
+
+template <>
+__device__ inline float ey_rng_normal<float>(const EyRng& r, uint32_t idx) {
+#pragma clang fp contract(off)
+  uint32_t o[4];
+  ey_philox4x32_10(idx, r.c1, r.c2, r.c3, r.k0, r.k1, o);
+  const float u1 = ((float)(o[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
+  const float u2 = (float)(o[1] >> 8) * 5.9604644775390625e-08f;           // [0,1)
+  const float rad = sqrtf(-2.0f * logf(u1));
+  return rad * cospif(2.0f * u2);
+}
+
+template <>
+__device__ inline double ey_rng_normal<double>(const EyRng& r, uint32_t idx) {
+#pragma clang fp contract(off)
+  uint32_t o[4];
+  ey_philox4x32_10(idx, r.c1, r.c2, r.c3, r.k0, r.k1, o);
+  const double u1 = ((double)(((uint64_t)o[0] << 21) | (o[2] >> 11)) + 0.5) * 1.1102230246251565e-16;  // 2^-53
+  const double u2 = (double)(((uint64_t)o[1] << 21) | (o[3] >> 11)) * 1.1102230246251565e-16;
+  const double rad = sqrt(-2.0 * log(u1));
+  return rad * cospi(2.0 * u2);
+}
+
+template <typename T>
+__device__ inline T ey_rng_uniform(const EyRng& r);
+
+template <>
+__device__ inline float ey_rng_uniform<float>(const EyRng& r) {
+  uint32_t o[4];
+  ey_philox4x32_10(0u, r.c1, r.c2, r.c3, r.k0, r.k1, o);
+  return (float)(o[0] >> 8) * 5.9604644775390625e-08f;
+}
+template <>
+__device__ inline double ey_rng_uniform<double>(const EyRng& r) {
+  uint32_t o[4];
+  ey_philox4x32_10(0u, r.c1, r.c2, r.c3, r.k0, r.k1, o);
+  return (double)(((uint64_t)o[0] << 21) | (o[1] >> 11)) * 1.1102230246251565e-16;
+}

@@ -1,0 +1,552 @@
+// Generic chain-batched kernels: any MLP (dims/bias/activations/likelihood of the plan), f32 and f64.
+// One wavefront (64 lanes) per chain; theta, momentum and gradient live in LDS for the whole step.
+//
+// Reference path restated (paths relative to papamarkou/eeyore):
+//   MLP.forward                eeyore/models/mlp.py:45-50
+//   BCE-sum / CE-sum           eeyore/constants/constants.py:15-18, eeyore/stats/loss.py:1-11
+//   log_lik/log_prior/target   eeyore/models/bayesian_model.py:30-56
+//   gradient (autograd there)  eeyore/models/log_target_model.py:15-23
+//   HMC leapfrog / draw        eeyore/samplers/hmc.py:100-156
+//   MALA draw                  eeyore/samplers/mala.py:46-82
+//   MH draw                    eeyore/samplers/metropolis_hastings.py:41-73
+//
+// Data rows are processed in tiles of 64 (lane <-> row).  Forward is row-parallel (weights broadcast from
+// LDS); the weight gradient is parameter-parallel (lane <-> parameter, contraction over the tile's rows);
+// the input gradient is row-parallel again.  Tile columns use a stride of 65 elements so that the
+// parameter-parallel reads (different rows j, same column n) hit different LDS banks.
+#include "ey_common.h"
+
+#define TS 65
+#define WAVE 64
+
+template <typename T>
+struct Num;
+template <>
+struct Num<float> {
+  static __device__ float exp(float v) { return expf(v); }
+  static __device__ float log(float v) { return logf(v); }
+  static __device__ float tanh(float v) { return tanhf(v); }
+  static __device__ float sqrt(float v) { return sqrtf(v); }
+};
+template <>
+struct Num<double> {
+  static __device__ double exp(double v) { return ::exp(v); }
+  static __device__ double log(double v) { return ::log(v); }
+  static __device__ double tanh(double v) { return ::tanh(v); }
+  static __device__ double sqrt(double v) { return ::sqrt(v); }
+};
+
+template <typename T>
+__device__ inline T act_fn(int code, T g) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return T(1) / (T(1) + Num<T>::exp(-g));
+    case EY_ACT_TANH: return Num<T>::tanh(g);
+    case EY_ACT_RELU: return g > T(0) ? g : T(0);
+    default: return g;
+  }
+}
+template <typename T>
+__device__ inline T dact_fn(int code, T h) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return h * (T(1) - h);
+    case EY_ACT_TANH: return T(1) - h * h;
+    case EY_ACT_RELU: return h > T(0) ? T(1) : T(0);
+    default: return T(1);
+  }
+}
+
+template <typename T>
+__device__ inline T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// LDS carve for one chain
+template <typename T>
+struct Lds {
+  T* th;   // [P] position
+  T* gr;   // [P] gradient at th
+  T* a;    // [P] momentum (HMC) / proposal (MALA, MH)
+  T* b;    // [P] gradient at the proposal (MALA)
+  T* act;  // [hrows * TS] activations of the current row tile, all layers
+  T* dl;   // [2 * dmax * TS] delta ping-pong
+};
+
+template <typename T>
+__device__ inline Lds<T> carve(const EyModel& m, unsigned char* smem, int nvec) {
+  Lds<T> l;
+  T* p = reinterpret_cast<T*>(smem);
+  const int Ppad = (m.P + 3) & ~3;
+  l.th = p; p += Ppad;
+  l.gr = p; p += Ppad;
+  l.a = p; if (nvec > 2) p += Ppad;
+  l.b = p; if (nvec > 3) p += Ppad;
+  l.act = p; p += m.hrows * TS;
+  l.dl = p;
+  return l;
+}
+
+static size_t lds_bytes(const EyModel& m, int nvec, size_t esz) {
+  const size_t Ppad = (m.P + 3) & ~3;
+  return esz * (nvec * Ppad + (size_t)m.hrows * TS + 2 * (size_t)m.dmax * TS);
+}
+
+// log-target (and gradient when GRAD) of the position in `th`; result broadcast to every lane.
+// gr receives the gradient of the (tempered) log-target.  lik/prior are the tempered parts.
+template <typename T, bool GRAD>
+__device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, bool has_temp, T temp, T* lik_out,
+                         T* prior_out) {
+  const int lane = threadIdx.x;
+  const T* x = static_cast<const T*>(m.x);
+  const T* y = static_cast<const T*>(m.y);
+  const int nl = m.nl;
+  const int dK = m.dims[nl];
+  if (GRAD) {
+    for (int i = lane; i < m.P; i += WAVE) gr[i] = T(0);
+  }
+  T lik = T(0);
+  for (int n0 = 0; n0 < m.N; n0 += WAVE) {
+    const int rows = min(WAVE, m.N - n0);
+    const int n = n0 + lane;
+    const bool valid = lane < rows;
+    __syncthreads();  // previous tile's parameter-parallel reads are done; th/gr initialisation visible
+    for (int i = 0; i < m.dims[0]; ++i) l.act[(m.hoff[0] + i) * TS + lane] = valid ? x[(size_t)n * m.dims[0] + i] : T(0);
+    // ---- forward, row-parallel (mlp.py:45-50)
+    for (int k = 0; k < nl; ++k) {
+      const int din = m.dims[k], dout = m.dims[k + 1];
+      const T* W = th + m.woff[k];
+      const T* hin = l.act + m.hoff[k] * TS + lane;
+      T* hout = l.act + m.hoff[k + 1] * TS + lane;
+      for (int j = 0; j < dout; ++j) {
+        T g = T(0);
+        for (int i = 0; i < din; ++i) g += hin[i * TS] * W[j * din + i];
+        if (m.boff[k] >= 0) g += th[m.boff[k] + j];
+        hout[j * TS] = act_fn<T>(m.act[k], g);
+      }
+    }
+    // ---- likelihood and output delta
+    const T* out = l.act + m.hoff[nl] * TS + lane;
+    T* dcur = l.dl;
+    T* dnext = l.dl + m.dmax * TS;
+    if (m.lik == EY_LIK_BCE_SUM) {
+      for (int j = 0; j < dK; ++j) {
+        const T o = out[j * TS];
+        const T yy = valid ? y[(size_t)n * dK + j] : T(0);
+        // naive logs exactly as eeyore/stats/loss.py:2 (NaN once a sigmoid saturates)
+        const T term = Num<T>::log(o) * yy + Num<T>::log(T(1) - o) * (T(1) - yy);
+        if (valid) lik += term;
+        if (GRAD) {
+          const T d = (yy / o - (T(1) - yy) / (T(1) - o)) * dact_fn<T>(m.act[nl - 1], o);
+          dcur[j * TS + lane] = valid ? d : T(0);
+        }
+      }
+    } else {
+      const int lab = valid ? m.labels[n] : 0;
+      T mx = out[0];
+      for (int j = 1; j < dK; ++j) mx = fmax(mx, out[j * TS]);
+      T ssum = T(0);
+      for (int j = 0; j < dK; ++j) ssum += Num<T>::exp(out[j * TS] - mx);
+      if (valid) lik += out[lab * TS] - (mx + Num<T>::log(ssum));
+      if (GRAD) {
+        for (int j = 0; j < dK; ++j) {
+          const T o = out[j * TS];
+          const T d = ((j == lab ? T(1) : T(0)) - Num<T>::exp(o - mx) / ssum) * dact_fn<T>(m.act[nl - 1], o);
+          dcur[j * TS + lane] = valid ? d : T(0);
+        }
+      }
+    }
+    if (GRAD) {
+      // ---- backward
+      for (int k = nl - 1; k >= 0; --k) {
+        const int din = m.dims[k], dout = m.dims[k + 1];
+        __syncthreads();  // delta_k of every row visible
+        // dW_k[j][i] += sum_n delta[j][n] * h_{k}[i][n]   (parameter-parallel)
+        const T* hin_t = l.act + m.hoff[k] * TS;
+        for (int idx = lane; idx < dout * din; idx += WAVE) {
+          const int j = idx / din, i = idx - j * din;
+          const T* dj = dcur + j * TS;
+          const T* hi = hin_t + i * TS;
+          T acc = T(0);
+          for (int r = 0; r < rows; ++r) acc += dj[r] * hi[r];
+          gr[m.woff[k] + idx] += acc;
+        }
+        if (m.boff[k] >= 0) {
+          for (int j = lane; j < dout; j += WAVE) {
+            const T* dj = dcur + j * TS;
+            T acc = T(0);
+            for (int r = 0; r < rows; ++r) acc += dj[r];
+            gr[m.boff[k] + j] += acc;
+          }
+        }
+        if (k > 0) {
+          // delta_{k-1}[i][n] = (sum_j delta_k[j][n] W_k[j][i]) * act'(h_k[i][n])   (row-parallel)
+          const T* W = th + m.woff[k];
+          for (int i = 0; i < din; ++i) {
+            T a = T(0);
+            for (int j = 0; j < dout; ++j) a += dcur[j * TS + lane] * W[j * din + i];
+            dnext[i * TS + lane] = a * dact_fn<T>(m.act[k - 1], hin_t[i * TS + lane]);
+          }
+          T* t = dcur; dcur = dnext; dnext = t;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  lik = wave_sum(lik);
+  // ---- prior (bayesian_model.py:46-50), elementwise Normal(mu, sigma)
+  const T* mu = static_cast<const T*>(m.mu);
+  const T* iv = static_cast<const T*>(m.inv_var);
+  T q = T(0);
+  for (int i = lane; i < m.P; i += WAVE) {
+    const T d = th[i] - mu[i];
+    q += d * d * iv[i];
+    if (GRAD) {
+      T g = gr[i] - d * iv[i];
+      if (has_temp) g *= temp;
+      gr[i] = g;
+    }
+  }
+  q = wave_sum(q);
+  T prior = T(m.prior_const) - T(0.5) * q;
+  if (has_temp) { lik *= temp; prior *= temp; }
+  if (lik_out) *lik_out = lik;
+  if (prior_out) *prior_out = prior;
+  __syncthreads();
+  return lik + prior;
+}
+
+// ----------------------------------------------------------------------------------------------- kernels
+template <typename T, bool GRAD>
+__global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, const T* temp, T* lik_o, T* prior_o,
+                                                     T* target_o, T* grad_o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Lds<T> l = carve<T>(m, smem, 2);
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < m.P; i += WAVE) l.th[i] = theta[c * m.P + i];
+  const bool ht = temp != nullptr;
+  const T tc = ht ? temp[c] : T(1);
+  T lik, prior;
+  const T t = eval_target<T, GRAD>(m, l, l.th, l.gr, ht, tc, &lik, &prior);
+  if (lane == 0) {
+    if (lik_o) lik_o[c] = lik;
+    if (prior_o) prior_o[c] = prior;
+    if (target_o) target_o[c] = t;
+  }
+  if (GRAD) {
+    for (int i = lane; i < m.P; i += WAVE) grad_o[c * m.P + i] = l.gr[i];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T* grad, const T* p0, const T* u_in,
+                                              T step, const T* step_vec, int L, const T* temp, uint64_t seed,
+                                              uint64_t iter, uint64_t chain_offset, int recompute,
+                                              unsigned char* accepted, T* rate_o, T* hcur_o, T* hprop_o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Lds<T> l = carve<T>(m, smem, 3);
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int P = m.P;
+  const bool ht = temp != nullptr;
+  const T tc = ht ? temp[c] : T(1);
+  const T eps = step_vec ? step_vec[c] : step;
+  T* p = l.a;
+  // momentum ~ N(0, I)  (hmc.py:134)
+  const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
+  T kin = T(0);
+  for (int i = lane; i < P; i += WAVE) {
+    l.th[i] = theta[c * P + i];
+    l.gr[i] = grad[c * P + i];
+    const T pi = p0 ? p0[c * P + i] : ey_rng_normal<T>(rn, (uint32_t)i);
+    p[i] = pi;
+    kin += pi * pi;
+  }
+  kin = wave_sum(kin);
+  const T t_cur = target[c];
+  const T h_cur = -t_cur + T(0.5) * kin;  // hmc.py:91-98,137
+  __syncthreads();
+  T t = t_cur;
+  if (recompute) t = eval_target<T, true>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);  // hmc.py:104
+  // leapfrog (hmc.py:100-124); grad_potential = -grad
+  for (int i = lane; i < P; i += WAVE) p[i] = p[i] + T(0.5) * eps * l.gr[i];
+  for (int k = 1; k <= L; ++k) {
+    for (int i = lane; i < P; i += WAVE) l.th[i] = l.th[i] + eps * p[i];
+    t = eval_target<T, true>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+    const T w = (k < L) ? eps : T(0.5) * eps;
+    for (int i = lane; i < P; i += WAVE) p[i] = p[i] + w * l.gr[i];
+  }
+  kin = T(0);
+  for (int i = lane; i < P; i += WAVE) kin += p[i] * p[i];  // p -> -p leaves it unchanged (hmc.py:122)
+  kin = wave_sum(kin);
+  const T h_prop = -t + T(0.5) * kin;
+  T rate = Num<T>::exp(h_cur - h_prop);  // hmc.py:143-146
+  if (rate > T(1)) rate = T(1);
+  const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
+  const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
+  const bool acc = u < rate;  // strict <; NaN rate => reject (hmc.py:148)
+  if (acc) {
+    for (int i = lane; i < P; i += WAVE) {
+      theta[c * P + i] = l.th[i];
+      grad[c * P + i] = l.gr[i];
+    }
+  }
+  if (lane == 0) {
+    if (acc) target[c] = t;
+    accepted[c] = acc ? 1 : 0;
+    if (rate_o) rate_o[c] = rate;
+    if (hcur_o) hcur_o[c] = h_cur;
+    if (hprop_o) hprop_o[c] = h_prop;
+  }
+}
+
+// HMC.leapfrog as a standalone operator (hmc.py:100-124): L+1 evaluations, momentum negated.
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, T step, const T* step_vec, int L,
+                                                   const T* temp, T* target, T* grad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Lds<T> l = carve<T>(m, smem, 3);
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int P = m.P;
+  const bool ht = temp != nullptr;
+  const T tc = ht ? temp[c] : T(1);
+  const T eps = step_vec ? step_vec[c] : step;
+  T* p = l.a;
+  for (int i = lane; i < P; i += WAVE) {
+    l.th[i] = theta[c * P + i];
+    p[i] = pio[c * P + i];
+  }
+  __syncthreads();
+  T t = eval_target<T, true>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+  for (int i = lane; i < P; i += WAVE) p[i] = p[i] + T(0.5) * eps * l.gr[i];
+  for (int k = 1; k <= L; ++k) {
+    for (int i = lane; i < P; i += WAVE) l.th[i] = l.th[i] + eps * p[i];
+    t = eval_target<T, true>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+    const T w = (k < L) ? eps : T(0.5) * eps;
+    for (int i = lane; i < P; i += WAVE) p[i] = p[i] + w * l.gr[i];
+  }
+  for (int i = lane; i < P; i += WAVE) {
+    theta[c * P + i] = l.th[i];
+    pio[c * P + i] = -p[i];
+    grad[c * P + i] = l.gr[i];
+  }
+  if (lane == 0) target[c] = t;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T* grad, const T* z_in, const T* u_in,
+                                               T step, T sqrt_step, const T* step_vec, const T* temp, uint64_t seed,
+                                               uint64_t iter, uint64_t chain_offset, unsigned char* accepted,
+                                               T* log_rate_o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Lds<T> l = carve<T>(m, smem, 4);
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int P = m.P;
+  const bool ht = temp != nullptr;
+  const T tc = ht ? temp[c] : T(1);
+  const T eps = step_vec ? step_vec[c] : step;
+  const T sc = step_vec ? Num<T>::sqrt(eps) : sqrt_step;  // scale = sqrt(step) (mala.py:39)
+  const T inv2v = T(1) / (T(2) * sc * sc);
+  T* prop = l.a;
+  T* gp = l.b;
+  const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
+  T qf = T(0);
+  for (int i = lane; i < P; i += WAVE) {
+    const T th = theta[c * P + i], g = grad[c * P + i];
+    l.th[i] = th;
+    l.gr[i] = g;
+    const T zi = z_in ? z_in[c * P + i] : ey_rng_normal<T>(rn, (uint32_t)i);
+    const T loc = th + T(0.5) * eps * g;  // kernel_mean (mala.py:35-36)
+    const T pr = loc + sc * zi;           // Normal(loc, scale).sample()
+    prop[i] = pr;
+    const T d = pr - loc;
+    qf += d * d;
+  }
+  __syncthreads();
+  const T tv = eval_target<T, true>(m, l, prop, gp, ht, tc, nullptr, nullptr);
+  T qb = T(0);
+  for (int i = lane; i < P; i += WAVE) {
+    const T loc2 = prop[i] + T(0.5) * eps * gp[i];
+    const T d = l.th[i] - loc2;
+    qb += d * d;
+  }
+  qf = wave_sum(qf);
+  qb = wave_sum(qb);
+  // log q terms share -P log(scale) - P/2 log(2 pi): they cancel in log_rate (mala.py:58-64)
+  const T log_rate = (tv - target[c]) + qf * inv2v - qb * inv2v;
+  const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
+  const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
+  const bool acc = Num<T>::log(u) < log_rate;  // mala.py:66
+  if (acc) {
+    for (int i = lane; i < P; i += WAVE) {
+      theta[c * P + i] = prop[i];
+      grad[c * P + i] = gp[i];
+    }
+  }
+  if (lane == 0) {
+    if (acc) target[c] = tv;
+    accepted[c] = acc ? 1 : 0;
+    if (log_rate_o) log_rate_o[c] = log_rate;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, const T* z_in, const T* u_in,
+                                             const T* scale, const T* temp, uint64_t seed, uint64_t iter,
+                                             uint64_t chain_offset, unsigned char* accepted, T* log_rate_o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Lds<T> l = carve<T>(m, smem, 2);
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int P = m.P;
+  const bool ht = temp != nullptr;
+  const T tc = ht ? temp[c] : T(1);
+  const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
+  for (int i = lane; i < P; i += WAVE) {
+    const T zi = z_in ? z_in[c * P + i] : ey_rng_normal<T>(rn, (uint32_t)i);
+    l.th[i] = theta[c * P + i] + scale[i] * zi;  // NormalKernel(theta, scale).sample()
+  }
+  __syncthreads();
+  const T tv = eval_target<T, false>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+  const T log_rate = tv - target[c];  // symmetric kernel (metropolis_hastings.py:50)
+  const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
+  const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
+  const bool acc = Num<T>::log(u) < log_rate;  // :56
+  if (acc) {
+    for (int i = lane; i < P; i += WAVE) theta[c * P + i] = l.th[i];
+  }
+  if (lane == 0) {
+    if (acc) target[c] = tv;
+    accepted[c] = acc ? 1 : 0;
+    if (log_rate_o) log_rate_o[c] = log_rate;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- host launchers
+template <typename K>
+static int prep(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) EY_FAIL(EY_ERR_UNSUPPORTED, "generic kernel: model does not fit the 160 KiB LDS of a CU");
+  if (bytes > 48 * 1024)
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes));
+  return EY_OK;
+}
+
+template <typename T>
+static int launch_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+                             void* target, void* grad, hipStream_t s) {
+  const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
+  int rc;
+  if (grad) {
+    if ((rc = prep(k_log_target<T, true>, bytes))) return rc;
+    hipLaunchKernelGGL((k_log_target<T, true>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
+                       (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)grad);
+  } else {
+    if ((rc = prep(k_log_target<T, false>, bytes))) return rc;
+    hipLaunchKernelGGL((k_log_target<T, false>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
+                       (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)nullptr);
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+                          void* target, void* grad, hipStream_t s) {
+  return pl->dtype == EY_F32 ? launch_log_target<float>(pl, theta, temp, C, lik, prior, target, grad, s)
+                             : launch_log_target<double>(pl, theta, temp, C, lik, prior, target, grad, s);
+}
+
+template <typename T>
+static int launch_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                      const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                      uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                      hipStream_t s) {
+  const size_t bytes = lds_bytes(pl->m, 3, sizeof(T));
+  int rc;
+  if ((rc = prep(k_hmc<T>, bytes))) return rc;
+  hipLaunchKernelGGL((k_hmc<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
+                     (const T*)p0, (const T*)u, (T)step, (const T*)step_vec, L, (const T*)temp, seed, iter,
+                     chain_offset, (int)((flags & EY_RECOMPUTE_INITIAL_GRAD) != 0), (unsigned char*)accepted, (T*)rate,
+                     (T*)hcur, (T*)hprop);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                   hipStream_t s) {
+  return pl->dtype == EY_F32
+             ? launch_hmc<float>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset,
+                                 flags, accepted, rate, hcur, hprop, s)
+             : launch_hmc<double>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset,
+                                  flags, accepted, rate, hcur, hprop, s);
+}
+
+template <typename T>
+static int launch_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                           int64_t C, void* target, void* grad, hipStream_t s) {
+  const size_t bytes = lds_bytes(pl->m, 3, sizeof(T));
+  int rc;
+  if ((rc = prep(k_leapfrog<T>, bytes))) return rc;
+  hipLaunchKernelGGL((k_leapfrog<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)p, (T)step,
+                     (const T*)step_vec, L, (const T*)temp, (T*)target, (T*)grad);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+int ey_generic_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                        int64_t C, void* target, void* grad, hipStream_t s) {
+  return pl->dtype == EY_F32 ? launch_leapfrog<float>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s)
+                             : launch_leapfrog<double>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
+}
+
+template <typename T>
+static int launch_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                       const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                       uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
+  const size_t bytes = lds_bytes(pl->m, 4, sizeof(T));
+  int rc;
+  if ((rc = prep(k_mala<T>, bytes))) return rc;
+  // scale = np.sqrt(step) on the python float, then cast to the model dtype (mala.py:39)
+  hipLaunchKernelGGL((k_mala<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
+                     (const T*)z, (const T*)u, (T)step, (T)sqrt(step), (const T*)step_vec, (const T*)temp, seed, iter,
+                     chain_offset, (unsigned char*)accepted, (T*)log_rate);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                    const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                    uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
+  return pl->dtype == EY_F32 ? launch_mala<float>(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter,
+                                                  chain_offset, accepted, log_rate, s)
+                             : launch_mala<double>(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter,
+                                                   chain_offset, accepted, log_rate, s);
+}
+
+template <typename T>
+static int launch_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
+                     const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
+                     void* log_rate, hipStream_t s) {
+  const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
+  int rc;
+  if ((rc = prep(k_mh<T>, bytes))) return rc;
+  hipLaunchKernelGGL((k_mh<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (const T*)z,
+                     (const T*)u, (const T*)scale, (const T*)temp, seed, iter, chain_offset, (unsigned char*)accepted,
+                     (T*)log_rate);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+int ey_generic_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
+                  const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
+                  void* log_rate, hipStream_t s) {
+  return pl->dtype == EY_F32
+             ? launch_mh<float>(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s)
+             : launch_mh<double>(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
+                                 s);
+}

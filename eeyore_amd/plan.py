@@ -1,0 +1,191 @@
+"""Plan: the Python handle of a C-ABI ``ey_plan`` (include/eeyore_amd.h) operating on torch device tensors.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic of the hot path happens in the HIP library.
+A plan fixes the model (dims/bias/activations/likelihood/dtype); data and prior are attached to it.
+"""
+import ctypes as ct
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.EY_F32, torch.float64: L.EY_F64}
+
+
+def _stream(device):
+    return ct.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Plan:
+    def __init__(self, dims, bias, acts, likelihood, dtype, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(
+                f"eeyore_amd: the hot path runs on an MI355X through the HIP library; device '{device}' is not a ROCm "
+                "device and there is no CPU fallback")
+        if dtype not in _DT:
+            raise ValueError(f"unsupported dtype {dtype}")
+        self.dtype = dtype
+        self.dims = [int(d) for d in dims]
+        n = len(self.dims) - 1
+        self.handle = ct.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        L.check(L.lib().ey_plan_create(ct.byref(self.handle), n, (ct.c_int * (n + 1))(*self.dims),
+                                       (ct.c_int * n)(*[int(b) for b in bias]), (ct.c_int * n)(*[int(a) for a in acts]),
+                                       int(likelihood), _DT[dtype], idx), "ey_plan_create")
+        P = ct.c_int64()
+        L.check(L.lib().ey_plan_num_params(self.handle, ct.byref(P)), "ey_plan_num_params")
+        self.P = P.value
+        self._data_key = None
+        self._prior_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                L.lib().ey_plan_destroy(self.handle)
+                self.handle = ct.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def kernel(self):
+        return L.lib().ey_plan_kernel(self.handle).decode()
+
+    # ------------------------------------------------------------------ data / prior
+    def _prep(self, t, shape=None):
+        t = torch.as_tensor(t)
+        t = t.to(device=self.device, dtype=self.dtype).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def set_data(self, x, y):
+        key = (x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), x._version, y._version, x.dtype, x.device)
+        if key == self._data_key:
+            return
+        xd = self._prep(x)
+        yd = self._prep(y)
+        if xd.dim() != 2 or xd.shape[1] != self.dims[0]:
+            raise ValueError(f"x must be [N, {self.dims[0]}], got {tuple(xd.shape)}")
+        yd = yd.reshape(xd.shape[0], -1)
+        if yd.shape[1] != self.dims[-1]:
+            raise ValueError(f"y must be [N, {self.dims[-1]}], got {tuple(yd.shape)}")
+        L.check(L.lib().ey_plan_set_data(self.handle, L.ptr(xd), L.ptr(yd), xd.shape[0], _stream(self.device)),
+                "ey_plan_set_data")
+        self._data_key = key
+        self.N = xd.shape[0]
+
+    def set_prior(self, mu, sigma):
+        mu = self._prep(torch.broadcast_to(torch.as_tensor(mu), (self.P,)), (self.P,))
+        sigma = self._prep(torch.broadcast_to(torch.as_tensor(sigma), (self.P,)), (self.P,))
+        L.check(L.lib().ey_plan_set_prior(self.handle, L.ptr(mu), L.ptr(sigma), _stream(self.device)),
+                "ey_plan_set_prior")
+
+    # ------------------------------------------------------------------ helpers
+    def _theta(self, theta):
+        if theta.device != self.device or theta.dtype != self.dtype or not theta.is_contiguous():
+            raise ValueError("theta must be a contiguous tensor of the plan's dtype on the plan's device")
+        if theta.dim() != 2 or theta.shape[1] != self.P:
+            raise ValueError(f"theta must be [C, {self.P}]")
+        return theta.shape[0]
+
+    def _opt(self, t, C):
+        if t is None:
+            return None
+        t = torch.as_tensor(t, dtype=self.dtype, device=self.device)
+        if t.dim() == 0:
+            t = t.expand(C)
+        return t.contiguous()
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    # ------------------------------------------------------------------ compute
+    def log_target(self, theta, temp=None, prior_only=False):
+        C = self._theta(theta)
+        lik, prior = (None if prior_only else self.empty(C)), self.empty(C)
+        temp = self._opt(temp, C)
+        L.check(L.lib().ey_log_target(self.handle, L.ptr(theta), L.ptr(temp), C, L.ptr(lik), L.ptr(prior),
+                                      _stream(self.device)), "ey_log_target")
+        return lik, prior
+
+    def log_target_grad(self, theta, temp=None):
+        C = self._theta(theta)
+        target, grad = self.empty(C), self.empty(C, self.P)
+        temp = self._opt(temp, C)
+        L.check(L.lib().ey_log_target_grad(self.handle, L.ptr(theta), L.ptr(temp), C, L.ptr(target), L.ptr(grad),
+                                           _stream(self.device)), "ey_log_target_grad")
+        return target, grad
+
+    def hmc_step(self, theta, target, grad, step, num_steps, p0=None, u=None, step_vec=None, temp=None, seed=0, it=0,
+                 chain_offset=0, flags=0, out=None):
+        C = self._theta(theta)
+        if out is None:
+            out = dict(accepted=self.empty(C, dtype=torch.uint8), rate=self.empty(C), h_cur=self.empty(C),
+                       h_prop=self.empty(C))
+        temp, step_vec, u = self._opt(temp, C), self._opt(step_vec, C), self._opt(u, C)
+        L.check(L.lib().ey_hmc_step(self.handle, L.ptr(theta), L.ptr(target), L.ptr(grad), L.ptr(p0), L.ptr(u),
+                                    float(step), L.ptr(step_vec), int(num_steps), L.ptr(temp), C, int(seed), int(it),
+                                    int(chain_offset), int(flags), L.ptr(out["accepted"]), L.ptr(out["rate"]),
+                                    L.ptr(out["h_cur"]), L.ptr(out["h_prop"]), _stream(self.device)), "ey_hmc_step")
+        return out
+
+    def leapfrog(self, theta, p, step, num_steps, step_vec=None, temp=None):
+        """HMC.leapfrog (hmc.py:100-124) in place on theta [C,P], p [C,P]; returns (target [C], grad [C,P])."""
+        C = self._theta(theta)
+        self._theta(p)
+        target, grad = self.empty(C), self.empty(C, self.P)
+        temp, step_vec = self._opt(temp, C), self._opt(step_vec, C)
+        L.check(L.lib().ey_hmc_leapfrog(self.handle, L.ptr(theta), L.ptr(p), float(step), L.ptr(step_vec),
+                                        int(num_steps), L.ptr(temp), C, L.ptr(target), L.ptr(grad),
+                                        _stream(self.device)), "ey_hmc_leapfrog")
+        return target, grad
+
+    def mala_step(self, theta, target, grad, step, z=None, u=None, step_vec=None, temp=None, seed=0, it=0,
+                  chain_offset=0, flags=0, out=None):
+        C = self._theta(theta)
+        if out is None:
+            out = dict(accepted=self.empty(C, dtype=torch.uint8), log_rate=self.empty(C))
+        temp, step_vec, u = self._opt(temp, C), self._opt(step_vec, C), self._opt(u, C)
+        L.check(L.lib().ey_mala_step(self.handle, L.ptr(theta), L.ptr(target), L.ptr(grad), L.ptr(z), L.ptr(u),
+                                     float(step), L.ptr(step_vec), L.ptr(temp), C, int(seed), int(it),
+                                     int(chain_offset), int(flags), L.ptr(out["accepted"]), L.ptr(out["log_rate"]),
+                                     _stream(self.device)), "ey_mala_step")
+        return out
+
+    def mh_step(self, theta, target, scale, z=None, u=None, temp=None, seed=0, it=0, chain_offset=0, flags=0, out=None):
+        C = self._theta(theta)
+        if out is None:
+            out = dict(accepted=self.empty(C, dtype=torch.uint8), log_rate=self.empty(C))
+        scale = self._prep(torch.broadcast_to(torch.as_tensor(scale, dtype=self.dtype, device=self.device), (self.P,)))
+        temp, u = self._opt(temp, C), self._opt(u, C)
+        L.check(L.lib().ey_mh_step(self.handle, L.ptr(theta), L.ptr(target), L.ptr(z), L.ptr(u), L.ptr(scale),
+                                   L.ptr(temp), C, int(seed), int(it), int(chain_offset), int(flags),
+                                   L.ptr(out["accepted"]), L.ptr(out["log_rate"]), _stream(self.device)), "ey_mh_step")
+        return out
+
+    def philox_normal(self, C, seed, it, chain_offset=0):
+        out = self.empty(C, self.P)
+        L.check(L.lib().ey_philox_normal(L.ptr(out), C, self.P, int(seed), int(it), int(chain_offset), _DT[self.dtype],
+                                         _stream(self.device)), "ey_philox_normal")
+        return out
+
+    def philox_uniform(self, C, seed, it, chain_offset=0):
+        out = self.empty(C)
+        L.check(L.lib().ey_philox_uniform(L.ptr(out), C, int(seed), int(it), int(chain_offset), _DT[self.dtype],
+                                          _stream(self.device)), "ey_philox_uniform")
+        return out
+
+
+def pt_swap_decide(ell_i, ell_j, t_i, t_j, u, dlogq=None):
+    """PowerPosteriorSampler.between_chain_move decision (power_posterior_sampler.py:135-163) for C pairs."""
+    C = ell_i.shape[0]
+    dt = ell_i.dtype
+    dev = ell_i.device
+    args = [a.to(device=dev, dtype=dt).contiguous() if a is not None else None for a in (ell_i, ell_j, t_i, t_j, dlogq, u)]
+    swap = torch.empty(C, dtype=torch.uint8, device=dev)
+    log_rate = torch.empty(C, dtype=dt, device=dev)
+    L.check(L.lib().ey_pt_swap_decide(*[L.ptr(a) for a in args], C, _DT[dt], L.ptr(swap), L.ptr(log_rate), _stream(dev)),
+            "ey_pt_swap_decide")
+    return swap, log_rate

@@ -1,0 +1,131 @@
+/* eeyore_amd C ABI -- the drop-in boundary for the chain-batched MCMC hot path on MI355X (gfx950).
+ *
+ * The reference (papamarkou/eeyore v0.0.20) is pure Python and has no FFI: its boundary is the duck-typed
+ * protocol between a sampler and a model.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - every `const void*` / `void*` data argument is a DEVICE pointer (torch.Tensor.data_ptr()) of the plan's
+ *    dtype unless stated otherwise; the caller owns every buffer, the library never returns memory;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); compute entry points are
+ *    asynchronous on it; ey_plan_create / ey_plan_set_data / ey_plan_set_prior / ey_plan_destroy synchronise;
+ *  - return value 0 = EY_OK, negative = ey_status; ey_last_error() gives a thread-local message;
+ *  - parameters are flat `theta[C, P]`, chain-major, each row in nn.Module.parameters() order: per layer
+ *    W_l [d_{l+1} x d_l] row-major then b_l (eeyore/models/model.py:38-55, eeyore/models/mlp.py:37-43);
+ *  - C = 1 is the reference's single-chain case.
+ *  - a plan is not thread-safe; distinct plans on distinct streams/devices are independent.
+ */
+#ifndef EEYORE_AMD_H
+#define EEYORE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ey_plan ey_plan;
+
+enum ey_status {
+  EY_OK = 0,
+  EY_ERR_INVALID = -1,      /* bad argument (ValueError in the reference, eeyore/models/mlp.py:15-19) */
+  EY_ERR_UNSUPPORTED = -2,  /* model/shape outside what the kernels cover */
+  EY_ERR_HIP = -3,          /* HIP runtime error (RuntimeError in the reference's benchmark(), serial_sampler.py:112) */
+  EY_ERR_STATE = -4         /* data or prior not set */
+};
+
+/* activation codes: eeyore/models/mlp.py:9-13,45-50 (`None` or torch.sigmoid in every reference test/example) */
+enum ey_act { EY_ACT_NONE = 0, EY_ACT_SIGMOID = 1, EY_ACT_TANH = 2, EY_ACT_RELU = 3 };
+
+/* likelihood codes: eeyore/constants/constants.py:15-18 */
+enum ey_lik {
+  EY_LIK_BCE_SUM = 0, /* 'binary_classification': naive BCE(sum) on probabilities, eeyore/stats/loss.py:1-11 */
+  EY_LIK_CE_SUM = 1   /* 'multiclass_classification': CrossEntropyLoss(sum)(logits, argmax(y,1)) */
+};
+
+enum ey_dtype { EY_F32 = 0, EY_F64 = 1 }; /* model.dtype, eeyore/models/model.py:7-10 */
+
+enum ey_flags {
+  EY_RECOMPUTE_INITIAL_GRAD = 1, /* HMC: re-evaluate the gradient at the start of the trajectory exactly as
+                                    hmc.py:104 does (L+1 evaluations) instead of using the cached `grad` (L) */
+  EY_FORCE_GENERIC = 2           /* route to the generic VALU kernels even when an MFMA kernel covers the plan */
+};
+
+int ey_version(void);
+const char* ey_last_error(void);
+
+/* Replaces mlp.Hyperparameters + MLP.__init__/set_fc_layers (eeyore/models/mlp.py:9-43) and the choice of
+ * loss_functions[...] (eeyore/constants/constants.py:15-18).  dims has n_layers+1 entries; bias/act n_layers. */
+int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias, const int* act, int likelihood,
+                   int dtype, int device_id);
+int ey_plan_destroy(ey_plan* plan);
+/* Model.num_params (eeyore/models/model.py:34-36) */
+int ey_plan_num_params(const ey_plan* plan, int64_t* P);
+/* name of the kernel family that serves ey_hmc_step for this plan: "generic" or "mfma32" */
+const char* ey_plan_kernel(const ey_plan* plan);
+
+/* The (x, y) full batch the samplers receive from their DataLoader (eeyore/samplers/serial_sampler.py:41-46).
+ * x [N, d_0]; y [N, d_K] (one-hot for CE as XYDataset(yonehot=True) yields, {0,1} for BCE).  Copied into the plan. */
+int ey_plan_set_data(ey_plan* plan, const void* x, const void* y, int64_t N, void* stream);
+/* model.prior = Normal(mu, sigma) elementwise (eeyore/models/mlp.py:31-35).  mu, sigma [P].  Copied. */
+int ey_plan_set_prior(ey_plan* plan, const void* mu, const void* sigma, void* stream);
+
+/* BayesianModel.log_lik / log_prior / log_target (eeyore/models/bayesian_model.py:30-56) for C chains.
+ * temp: per-chain temperature [C] or NULL (model.temperature = None); multiplies BOTH outputs (:33-34,48-49).
+ * log_lik, log_prior: [C] outputs (either may be NULL). */
+int ey_log_target(ey_plan* plan, const void* theta, const void* temp, int64_t C, void* log_lik, void* log_prior,
+                  void* stream);
+/* LogTargetModel.upto_grad_log_target (eeyore/models/log_target_model.py:15-23): target [C], grad [C,P]. */
+int ey_log_target_grad(ey_plan* plan, const void* theta, const void* temp, int64_t C, void* target, void* grad,
+                       void* stream);
+
+/* One HMC.draw (eeyore/samplers/hmc.py:126-156, full-batch path) for C chains: momentum draw, HMC.leapfrog
+ * (:100-124), Hamiltonians (:91-98), accept `u < min(exp(H_cur-H_prop),1)` (:143-148), state update.
+ *  theta [C,P], target [C], grad [C,P]: current state, updated in place for accepted chains;
+ *  p0 [C,P] replaces torch.randn (:134) and u [C] replaces torch.rand(1) (:148); NULL => the in-kernel
+ *    Philox4x32-10 stream keyed by (seed, chain_offset + chain, iter) -- see ey_philox_normal/uniform;
+ *  step: scalar step size; step_vec [C] overrides it per chain when not NULL; L = num_steps;
+ *  accepted [C] uint8, accept_rate [C], H_cur [C], H_prop [C]: outputs (the last three may be NULL). */
+int ey_hmc_step(ey_plan* plan, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                uint64_t chain_offset, uint32_t flags, void* accepted, void* accept_rate, void* H_cur, void* H_prop,
+                void* stream);
+
+/* HMC.leapfrog(position0, momentum0, x, y) (eeyore/samplers/hmc.py:100-124) for C chains, exactly as the
+ * reference runs it: L steps, L+1 gradient evaluations, final momentum negated.  theta [C,P] and p [C,P] are
+ * in/out (position_L, momentum_L); target [C] and grad [C,P] receive the log-target and its gradient at
+ * position_L.  Used by HMC.init_step (:38-77) and by callers of the public leapfrog method. */
+int ey_hmc_leapfrog(ey_plan* plan, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                    int64_t C, void* target, void* grad, void* stream);
+
+/* One MALA.draw (eeyore/samplers/mala.py:46-82) with the default NormalKernel(theta + step/2 grad, sqrt(step))
+ * (:35-41; eeyore/kernels/normal_kernel.py:5-23): z [C,P] standard normals (NULL => Philox), u [C].
+ * Accept iff log(u) < log_rate (:66).  log_rate [C] output may be NULL. */
+int ey_mala_step(ey_plan* plan, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                 const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                 uint64_t chain_offset, uint32_t flags, void* accepted, void* log_rate, void* stream);
+
+/* One MetropolisHastings.draw (eeyore/samplers/metropolis_hastings.py:41-73), symmetric NormalKernel(theta,
+ * scale): prop = theta + scale * z; scale [P] device array.  log_rate = target(prop) - target(theta) (:50). */
+int ey_mh_step(ey_plan* plan, void* theta, void* target, const void* z, const void* u, const void* scale,
+               const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
+               void* accepted, void* log_rate, void* stream);
+
+/* PowerPosteriorSampler.between_chain_move (eeyore/samplers/power_posterior_sampler.py:135-163) decision for C
+ * chain pairs: log_rate = dlogq + (t_i - t_j) * (ell_j - ell_i) with ell the UNTEMPERED log-target; swap iff
+ * log(u) < log_rate (:160).  All arrays [C] of `dtype`; dlogq may be NULL (symmetric partner choice). */
+int ey_pt_swap_decide(const void* ell_i, const void* ell_j, const void* t_i, const void* t_j, const void* dlogq,
+                      const void* u, int64_t C, int dtype, void* swap /* uint8 [C] */, void* log_rate, void* stream);
+
+/* The in-kernel random streams, exposed so a caller (or a test) can reproduce them:
+ *  normal  out[c, i] = N(0,1) for parameter i of chain chain_offset + c at iteration iter (what p0/z = NULL uses)
+ *  uniform out[c]    = U[0,1) accept variate of that chain and iteration (what u = NULL uses). */
+int ey_philox_normal(void* out, int64_t C, int64_t P, uint64_t seed, uint64_t iter, uint64_t chain_offset, int dtype,
+                     void* stream);
+int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, int dtype,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEYORE_AMD_H */

@@ -1,0 +1,389 @@
+"""Parity of the HIP path (through the C ABI, eeyore_amd.plan.Plan) with the oracle and the golden vectors.
+
+Tolerances (stated per north_star): f64 results within 1e-10 relative of the reference's fp64 values; f32 results
+within 2e-4 relative / 2e-3 absolute on log-targets that are O(100) (f32 has ~7 digits; sums run over 150 rows and
+1315 parameters in a different order than torch's).  Accept decisions must be bit-exact for every draw whose
+|u - rate| (or |log u - log_rate|) exceeds the stated margin; the number of in-margin draws is asserted to be 0
+for the committed traces.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.c_oracle import COracle
+from tests.helpers import groups, load
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _plan(rec, dtype=torch.float64):
+    from eeyore_amd.plan import Plan
+    dims = rec["dims"].tolist()
+    pl = Plan(dims, [1] * (len(dims) - 1), rec["acts"].tolist(), int(rec["lik"]), dtype, DEV)
+    pl.set_data(torch.tensor(rec["x"], dtype=dtype, device=DEV), torch.tensor(rec["y"], dtype=dtype, device=DEV))
+    pl.set_prior(torch.tensor(rec["prior_mu"]), torch.tensor(rec["prior_sigma"]))
+    return pl
+
+
+def _t(a, dtype=torch.float64):
+    return torch.tensor(np.asarray(a), dtype=dtype, device=DEV).contiguous()
+
+
+def _temp(rec):
+    return None if ("temperature" not in rec or np.isnan(rec["temperature"])) else float(rec["temperature"])
+
+
+def test_library_is_the_hip_one():
+    from eeyore_amd import _lib as L
+    assert L.lib().ey_version() >= 100
+
+
+def test_g1_kats_f64():
+    for name, rec in groups(load("g1_kats.npz")).items():
+        pl = _plan(rec)
+        th = _t(rec["theta"])[None]
+        lik, prior = pl.log_target(th)
+        t, g = pl.log_target_grad(th)
+        np.testing.assert_allclose(lik.item(), rec["log_lik"], rtol=1e-12)
+        np.testing.assert_allclose(prior.item(), rec["log_prior"], rtol=1e-12)
+        np.testing.assert_allclose(t.item(), rec["log_target"], rtol=1e-12)
+        np.testing.assert_allclose(g[0].cpu().numpy(), rec["grad"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_g2_log_target_grad(tag):
+    dt = torch.float64 if tag == "f64" else torch.float32
+    rtol, atol = (1e-10, 1e-11) if tag == "f64" else (2e-4, 2e-4)
+    n = 0
+    for name, rec in groups(load("g2_grads.npz")).items():
+        if not name.startswith(tag):
+            continue
+        pl = _plan(rec, dt)
+        th = _t(rec["theta"], dt)
+        temp = _temp(rec)
+        t, g = pl.log_target_grad(th, temp=temp)
+        lik, prior = pl.log_target(th, temp=temp)
+        np.testing.assert_allclose(t.cpu().numpy(), rec["log_target"], rtol=rtol, atol=atol * 10)
+        np.testing.assert_allclose(g.cpu().numpy(), rec["grad"], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(lik.cpu().numpy(), rec["log_lik"], rtol=rtol, atol=atol * 10)
+        np.testing.assert_allclose(prior.cpu().numpy(), rec["log_prior"], rtol=rtol, atol=atol * 10)
+        n += 1
+    assert n >= 3
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_g3_leapfrog(tag):
+    dt = torch.float64 if tag == "f64" else torch.float32
+    rtol, atol = (1e-9, 1e-10) if tag == "f64" else (5e-4, 5e-4)
+    n = 0
+    for name, rec in groups(load("g3_leapfrog.npz")).items():
+        if not name.startswith(tag):
+            continue
+        pl = _plan(rec, dt)
+        th, p = _t(rec["theta0"], dt)[None].clone(), _t(rec["p0"], dt)[None].clone()
+        t, g = pl.leapfrog(th, p, float(rec["step"]), int(rec["L"]))
+        np.testing.assert_allclose(th[0].cpu().numpy(), rec["thetaL"], rtol=rtol, atol=atol)
+        np.testing.assert_allclose(p[0].cpu().numpy(), rec["pL"], rtol=rtol, atol=atol * 10)
+        np.testing.assert_allclose(t.item(), rec["target"], rtol=rtol, atol=atol * 10)
+        np.testing.assert_allclose(g[0].cpu().numpy(), rec["grad"], rtol=rtol * 10, atol=atol * 10)
+        n += 1
+    assert n >= 2
+
+
+def _replay(rec, kind, flags=0, margin=1e-9):
+    pl = _plan(rec)
+    th = _t(rec["theta0"])[None].clone()
+    tv = _t([rec["init_target"]])
+    g = _t(rec["init_grad"])[None].clone()
+    in_margin = 0
+    for it in range(rec["z"].shape[0]):
+        z, u = _t(rec["z"][it])[None], _t([rec["u"][it]])
+        if kind == "hmc":
+            out = pl.hmc_step(th, tv, g, float(rec["step"]), int(rec["L"]), p0=z, u=u, flags=flags)
+            m = abs(float(rec["u"][it]) - out["rate"].item())
+        elif kind == "mala":
+            out = pl.mala_step(th, tv, g, float(rec["par"]), z=z, u=u)
+            m = abs(np.log(float(rec["u"][it])) - out["log_rate"].item())
+        else:
+            out = pl.mh_step(th, tv, torch.full((pl.P,), float(rec["par"])), z=z, u=u)
+            m = abs(np.log(float(rec["u"][it])) - out["log_rate"].item())
+        if m <= margin:
+            in_margin += 1
+        assert int(out["accepted"].item()) == int(rec["accepted"][it]), (it, m)
+        np.testing.assert_allclose(th[0].cpu().numpy(), rec["sample"][it], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(tv.item(), rec["target_val"][it], rtol=1e-9)
+        if kind == "hmc":
+            np.testing.assert_allclose(out["h_cur"].item(), rec["hamiltonian"][it], rtol=1e-9)
+    assert in_margin == 0
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_g4_hmc_traces_accept_bit_exact(flags):
+    for name, rec in groups(load("g4_hmc_traces.npz")).items():
+        _replay(rec, "hmc", flags=flags)
+
+
+def test_g5_mala_mh_traces_accept_bit_exact():
+    for name, rec in groups(load("g5_mala_mh_traces.npz")).items():
+        _replay(rec, "mala" if name.startswith("mala") else "mh")
+
+
+def test_g6_pt_swap_decide():
+    from eeyore_amd.plan import pt_swap_decide
+    z = load("g6_power_posterior.npz")
+    i, j = z["pairs"][:, 0], z["pairs"][:, 1]
+    ell, lad = z["ell"], z["ladder"]
+    u = np.linspace(0.05, 0.95, len(i))
+    dlogq = z["log_q"][:, 0] - z["log_q"][:, 1]
+    swap, lr = pt_swap_decide(_t(ell[i]), _t(ell[j]), _t(lad[i]), _t(lad[j]), _t(u), dlogq=_t(dlogq))
+    np.testing.assert_allclose(lr.cpu().numpy(), z["log_rate"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_array_equal(swap.cpu().numpy(), (np.log(u) < z["log_rate"]).astype(np.uint8))
+
+
+# --------------------------------------------------------------------------------------------- vs the C oracle
+def _oracle(rec, dtype, temperature=None):
+    return COracle(rec["dims"].tolist(), rec["acts"].tolist(), int(rec["lik"]), rec["x"], rec["y"], rec["prior_mu"],
+                   rec["prior_sigma"], dtype=dtype, temperature=temperature, nthreads=8)
+
+
+@pytest.mark.parametrize("model,C,step,L,tag", [
+    ("mlp2321", 256, 0.5, 8, "f64"), ("mlp2321", 256, 0.5, 8, "f32"),
+    ("mlp433", 64, 0.05, 10, "f64"),
+    ("mlp432323_synth", 48, 0.02, 20, "f64"), ("mlp432323_synth", 48, 0.02, 20, "f32"),
+])
+def test_hmc_step_multichain_vs_oracle(model, C, step, L, tag):
+    rec = groups(load("g4_hmc_traces.npz"))[model]
+    npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    pl = _plan(rec, dt)
+    co = _oracle(rec, npdt)
+    rng = np.random.default_rng(3)
+    P = pl.P
+    th0 = (0.2 * rng.standard_normal((C, P))).astype(npdt)
+    tv0 = np.zeros(C, dtype=npdt); g0 = np.zeros((C, P), dtype=npdt)
+    for c in range(C):
+        tv0[c], g0[c], _, _ = co.log_target_grad(th0[c])
+    th, tv, g = _t(th0, dt).clone(), _t(tv0, dt).clone(), _t(g0, dt).clone()
+    tho, tvo, go = th0.copy(), tv0.copy(), g0.copy()
+    tol = 1e-9 if tag == "f64" else 2e-3
+    n_in_margin = 0
+    for it in range(3):
+        p0 = rng.standard_normal((C, P)).astype(npdt)
+        u = rng.random(C).astype(npdt)
+        out = pl.hmc_step(th, tv, g, step, L, p0=_t(p0, dt), u=_t(u, dt))
+        acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, step, L)
+        with np.errstate(over="ignore"):
+            rate = np.minimum(np.exp(hc - hp), 1)
+        decided = np.abs(u - rate) > tol * np.maximum(1.0, np.abs(hc - hp))
+        n_in_margin += int((~decided).sum())
+        got = out["accepted"].cpu().numpy()
+        np.testing.assert_array_equal(got[decided], acc[decided])
+        np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=tol, atol=tol * 10)
+        # keep both sides on the same state where a within-margin decision differed
+        same = got == acc
+        np.testing.assert_allclose(th.cpu().numpy()[same], tho[same], rtol=tol * 10, atol=tol * 10)
+        tho, tvo, go = th.cpu().numpy().copy(), tv.cpu().numpy().copy(), g.cpu().numpy().copy()
+        assert 0 < got.sum() < C or C < 8
+    assert n_in_margin <= (0 if tag == "f64" else 2)
+
+
+def test_cfg2_mala_256_chains_vs_oracle():
+    """BASELINE config 2: MALA, 256 chains, MLP(2-3-2-1), binary classification."""
+    rec = groups(load("g5_mala_mh_traces.npz"))["mala_mlp2321"]
+    for tag, tol in (("f64", 1e-9), ("f32", 1e-3)):
+        npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+        pl = _plan(rec, dt)
+        co = _oracle(rec, npdt)
+        rng = np.random.default_rng(5)
+        C, P = 256, pl.P
+        tho = (0.5 * rng.standard_normal((C, P))).astype(npdt)
+        tvo = np.zeros(C, dtype=npdt); go = np.zeros((C, P), dtype=npdt)
+        for c in range(C):
+            tvo[c], go[c], _, _ = co.log_target_grad(tho[c])
+        th, tv, g = _t(tho, dt).clone(), _t(tvo, dt).clone(), _t(go, dt).clone()
+        for it in range(5):
+            z = rng.standard_normal((C, P)).astype(npdt)
+            u = rng.random(C).astype(npdt)
+            out = pl.mala_step(th, tv, g, 0.3, z=_t(z, dt), u=_t(u, dt))
+            acc, lr = co.mala_draw(tho, tvo, go, z, u, 0.3)
+            decided = np.abs(np.log(u) - lr) > tol * np.maximum(1.0, np.abs(lr))
+            got = out["accepted"].cpu().numpy()
+            np.testing.assert_array_equal(got[decided], acc[decided])
+            np.testing.assert_allclose(out["log_rate"].cpu().numpy(), lr, rtol=tol * 10, atol=tol * 10)
+            assert 0 < got.sum() < C
+            tho, tvo, go = th.cpu().numpy().copy(), tv.cpu().numpy().copy(), g.cpu().numpy().copy()
+
+
+def test_temperature_per_chain():
+    rec = groups(load("g2_grads.npz"))["f64/mlp433/s1/t0.3"]
+    pl = _plan(rec)
+    th = _t(rec["theta"])
+    C = th.shape[0]
+    temps = torch.linspace(0.1, 1.0, C, dtype=torch.float64)
+    t, g = pl.log_target_grad(th, temp=temps)
+    t1, g1 = pl.log_target_grad(th)
+    np.testing.assert_allclose(t.cpu().numpy(), (temps.numpy() * t1.cpu().numpy()), rtol=1e-12)
+    np.testing.assert_allclose(g.cpu().numpy(), temps.numpy()[:, None] * g1.cpu().numpy(), rtol=1e-11, atol=1e-13)
+
+
+# --------------------------------------------------------------------------------------------- RNG
+def test_philox_streams_and_fused_use():
+    rec = groups(load("g4_hmc_traces.npz"))["mlp433"]
+    for dt in (torch.float32, torch.float64):
+        pl = _plan(rec, dt)
+        C = 512
+        z = pl.philox_normal(C, seed=11, it=3)
+        u = pl.philox_uniform(C, seed=11, it=3)
+        zz = z.double().cpu().numpy()
+        assert abs(zz.mean()) < 0.02 and abs(zz.std() - 1) < 0.02 and np.isfinite(zz).all()
+        uu = u.double().cpu().numpy()
+        assert 0 <= uu.min() and uu.max() < 1 and abs(uu.mean() - 0.5) < 0.05
+        # different iteration / chain offset => different stream; same arguments => same stream
+        assert not torch.equal(z, pl.philox_normal(C, seed=11, it=4))
+        assert torch.equal(z[10:20], pl.philox_normal(10, seed=11, it=3, chain_offset=10))
+        th = 0.1 * pl.philox_normal(C, seed=1, it=0)
+        t, g = pl.log_target_grad(th)
+        a = [th.clone(), t.clone(), g.clone()]
+        b = [th.clone(), t.clone(), g.clone()]
+        oa = pl.hmc_step(*a, 0.05, 7, seed=11, it=3)                 # in-kernel Philox
+        ob = pl.hmc_step(*b, 0.05, 7, p0=z, u=u)                     # the same streams passed as inputs
+        for k in oa:
+            assert torch.equal(oa[k], ob[k]), k
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        assert 0 < oa["accepted"].sum().item() < C
+
+
+# --------------------------------------------------------------------------------------------- edge cases
+def test_ragged_and_tiny_row_counts():
+    rec = groups(load("g2_grads.npz"))["f64/mlp433/s1/tNone"]
+    th = rec["theta"]
+    for N in (1, 63, 64, 65, 129):
+        sub = dict(rec)
+        idx = np.arange(N) % rec["x"].shape[0]
+        sub["x"], sub["y"] = rec["x"][idx], rec["y"][idx]
+        pl = _plan(sub)
+        co = _oracle(sub, np.float64)
+        t, g = pl.log_target_grad(_t(th))
+        for c in range(th.shape[0]):
+            to, go, _, _ = co.log_target_grad(th[c])
+            np.testing.assert_allclose(t[c].item(), to, rtol=1e-11)
+            np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=1e-9, atol=1e-12)
+
+
+def test_saturated_bce_is_nan_and_rejected():
+    """eeyore/stats/loss.py:2: log(1-h)*(1-y) with h == 1 is -inf*0 = NaN; a NaN Hamiltonian is rejected (hmc.py:148)."""
+    rec = groups(load("g4_hmc_traces.npz"))["cfg1"]
+    pl = _plan(rec, torch.float32)
+    th = torch.full((2, pl.P), 60.0, dtype=torch.float32, device=DEV)
+    th[1] = _t(rec["theta0"], torch.float32)
+    lik, _ = pl.log_target(th)
+    assert torch.isnan(lik[0]) and torch.isfinite(lik[1])
+    t, g = pl.log_target_grad(th)
+    th2 = th.clone()
+    out = pl.hmc_step(th2, t, g, 0.1, 5, seed=1, it=0)
+    assert out["accepted"][0].item() == 0 and torch.equal(th2[0], th[0])
+
+
+def test_empty_chain_batch_and_bad_arguments():
+    rec = groups(load("g4_hmc_traces.npz"))["cfg1"]
+    pl = _plan(rec)
+    th = torch.empty(0, pl.P, dtype=torch.float64, device=DEV)
+    t, g = pl.log_target_grad(th)
+    assert t.shape == (0,) and g.shape == (0, pl.P)
+    with pytest.raises(ValueError):
+        pl.hmc_step(_t(rec["theta0"])[None], _t([0.0]), _t(rec["theta0"])[None], 0.1, 0)  # num_steps >= 1
+    with pytest.raises(ValueError):
+        pl.log_target_grad(torch.zeros(1, pl.P + 1, dtype=torch.float64, device=DEV))
+    from eeyore_amd.plan import Plan
+    fresh = Plan([2, 2, 1], [1, 1], [1, 1], 0, torch.float64, DEV)
+    with pytest.raises(RuntimeError, match="set_data"):
+        fresh.log_target_grad(torch.zeros(1, 9, dtype=torch.float64, device=DEV))
+
+
+# --------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_cfg3_reversibility_and_energy():
+    """BASELINE config 3 shape (4096 chains, MLP(4-32-32-3), N=150, L=20), size-independent properties:
+    leapfrog is time-reversible (run it again from (theta_L, p_L): the momentum flip is built in, hmc.py:122) and
+    the energy error shrinks ~ quadratically with the step size."""
+    rec = groups(load("g4_hmc_traces.npz"))["mlp432323_synth"]
+    pl = _plan(rec, torch.float32)
+    C = 4096
+    th0 = 0.1 * pl.philox_normal(C, seed=5, it=0)
+    p0 = pl.philox_normal(C, seed=5, it=1)
+    th, p = th0.clone(), p0.clone()
+    t0, _ = pl.log_target_grad(th0)
+    t1, _ = pl.leapfrog(th, p, 0.01, 20)
+    h0 = -t0 + 0.5 * (p0 ** 2).sum(1)
+    h1 = -t1 + 0.5 * (p ** 2).sum(1)
+    err_small = (h1 - h0).abs().median().item()
+    t2, _ = pl.leapfrog(th, p, 0.01, 20)  # back again
+    assert (th - th0).abs().max().item() < 5e-4
+    assert (p + p0).abs().max().item() < 5e-3  # returns with the momentum negated
+    np.testing.assert_allclose(t2.cpu().numpy(), t0.cpu().numpy(), rtol=1e-4, atol=2e-2)
+    th, p = th0.clone(), p0.clone()
+    t3, _ = pl.leapfrog(th, p, 0.02, 10)
+    err_big = (-t3 + 0.5 * (p ** 2).sum(1) - h0).abs().median().item()
+    assert err_small < 0.5 and err_big < 2.0 and err_small < err_big + 0.05
+
+
+# --------------------------------------------------------------------------------------------- sampler surface
+def test_sampler_surface_single_chain_cfg1():
+    """BASELINE config 1 through the drop-in surface: HMC, 1 chain, MLP(2-2-1) on XOR, recorded randomness."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.chains import ChainList
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import XYDataset
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    rec = groups(load("g4_hmc_traces.npz"))["cfg1_big_step"]
+    xor = XYDataset.from_eeyore('xor', dtype=torch.float64, device=DEV)
+    hp = mlp.Hyperparameters(dims=[2, 2, 1], bias=[True, True], activations=[torch.sigmoid, torch.sigmoid])
+    model = mlp.MLP(loss=loss_functions['binary_classification'], hparams=hp, dtype=torch.float64, device=DEV)
+    model.prior = Normal(torch.zeros(9, dtype=torch.float64, device=DEV), 100 * torch.ones(9, dtype=torch.float64, device=DEV))
+    loader = DataLoader(xor, batch_size=len(xor), shuffle=False)
+    s = HMC(model, theta0=_t(rec["theta0"]), dataloader=loader, step=float(rec["step"]), num_steps=int(rec["L"]),
+            chain=ChainList())
+    it = {"i": 0}
+    s._randn = lambda C, P: _t(rec["z"][it["i"]])[None]
+    def rand(C):
+        v = _t([rec["u"][it["i"]]]); it["i"] += 1
+        return v
+    s._rand = rand
+    s.run(num_epochs=rec["z"].shape[0], num_burnin_epochs=10)
+    ch = s.get_chain()
+    assert ch.vals['accepted'] == rec["accepted"][10:].tolist()
+    np.testing.assert_allclose(ch.get_samples().cpu().numpy(), rec["sample"][10:], rtol=1e-8, atol=1e-9)
+    lt = model.log_target(_t(rec["theta0"]), xor.x, xor.y)
+    np.testing.assert_allclose(lt.item(), rec["init_target"], rtol=1e-12)
+    np.testing.assert_allclose(model.log_prior().item() + model.log_lik(xor.x, xor.y).item(),
+                               model.log_target(model.get_params(), xor.x, xor.y).item(), rtol=1e-12)
+
+
+def test_sampler_surface_batched_philox():
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC, MALA, MetropolisHastings
+    data = synthetic.iris_shaped(dtype=torch.float32, device=DEV)
+    hp = mlp.Hyperparameters(dims=[4, 32, 32, 3], bias=3 * [True], activations=[torch.sigmoid, torch.sigmoid, None])
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'], hparams=hp, dtype=torch.float32, device=DEV)
+    P = model.num_params()
+    model.prior = Normal(torch.zeros(P, device=DEV), (3 * torch.ones(P, device=DEV)).sqrt())
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    C = 128
+    th0 = 0.1 * torch.randn(C, P, device=DEV)
+    for S, kw in ((HMC, dict(step=0.02, num_steps=10)), (MALA, dict(step=0.0005)), (MetropolisHastings, {})):
+        s = S(model, theta0=th0, dataloader=loader, seed=7, **kw)
+        if S is MetropolisHastings:
+            s.kernel.set_density_params(s.current['sample'], scale=torch.full((P,), 0.01, device=DEV))
+        s.run(num_epochs=12, num_burnin_epochs=2)
+        ch = s.get_chain()
+        assert ch.get_samples().shape == (10, C, P)
+        acc = ch.acceptance_rate().mean().item()
+        assert 0.05 < acc <= 1.0, (S.__name__, acc)
+        assert torch.isfinite(ch.get_target_vals()).all()
