@@ -62,10 +62,12 @@ def cpu_baseline(x, y, sigma, budget_s=12.0):
                         STEP_SIZE, L_STEPS)
         return time.perf_counter() - t0
 
-    C0 = 2 * cores
-    t_probe = run(C0, 1)
-    iters = max(1, int(budget_s / max(t_probe, 1e-3)))
-    iters = min(iters, 50)
+    t_probe = run(2 * cores, 1)
+    # scale the sample to ~budget_s of wall time: more chains first (keeps every core busy), then iterations
+    per_chain_iter = t_probe / 2.0
+    total = max(1.0, budget_s / max(per_chain_iter, 1e-4))
+    iters = int(min(10, max(1, total // 64)))
+    C0 = int(cores * max(2, min(256, total // iters)))
     t = run(C0, iters)
     return {"value": C0 * iters * L_STEPS / t, "unit": "leapfrog-steps/sec x chains", "cores": cores, "kind": "port",
             "sample": f"{C0} chains x {iters} HMC iterations (L={L_STEPS}, L+1 gradient evaluations each as "
@@ -117,6 +119,10 @@ def main():
     it = 1
     for _ in range(args.warmup):
         step(it); it += 1
+        stats.update(theta, out["accepted"])  # also warms the torch elementwise kernels used in the timed region
+    if args.warmup > 1:
+        stats.summary()
+    stats = ChainStats(C, P, dev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -175,7 +175,7 @@ static int check_ready(const ey_plan* pl, int64_t C, const char* who) {
   if (!pl->has_data) EY_FAIL(EY_ERR_STATE, std::string(who) + ": ey_plan_set_data has not been called");
   if (!pl->has_prior) EY_FAIL(EY_ERR_STATE, std::string(who) + ": ey_plan_set_prior has not been called");
   if (C < 0 || C > 0x7fffffffLL) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": chain count out of range");
-  return EY_OK;
+  return C == 0 ? 1 : EY_OK;  // 1 = nothing to do (an empty chain batch has null buffers)
 }
 
 int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* log_lik, void* log_prior,
@@ -189,7 +189,7 @@ int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, v
     return ey_generic_log_target(pl, theta, temp, C, nullptr, log_prior, nullptr, nullptr, (hipStream_t)stream);
   }
   int rc = check_ready(pl, C, "ey_log_target");
-  if (rc) return rc;
+  if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta) EY_FAIL(EY_ERR_INVALID, "ey_log_target: null theta");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
@@ -199,7 +199,7 @@ int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, v
 int ey_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,
                        void* stream) {
   int rc = check_ready(pl, C, "ey_log_target_grad");
-  if (rc) return rc;
+  if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !target || !grad) EY_FAIL(EY_ERR_INVALID, "ey_log_target_grad: null argument");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
@@ -211,7 +211,7 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
                 uint64_t chain_offset, uint32_t flags, void* accepted, void* accept_rate, void* H_cur, void* H_prop,
                 void* stream) {
   int rc = check_ready(pl, C, "ey_hmc_step");
-  if (rc) return rc;
+  if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: null argument");
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: num_steps must be >= 1");
   if (C == 0) return EY_OK;
@@ -226,7 +226,7 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
 int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                     int64_t C, void* target, void* grad, void* stream) {
   int rc = check_ready(pl, C, "ey_hmc_leapfrog");
-  if (rc) return rc;
+  if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !p || !target || !grad) EY_FAIL(EY_ERR_INVALID, "ey_hmc_leapfrog: null argument");
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_leapfrog: num_steps must be >= 1");
   if (C == 0) return EY_OK;
@@ -239,7 +239,7 @@ int ey_mala_step(ey_plan* pl, void* theta, void* target, void* grad, const void*
                  uint64_t chain_offset, uint32_t flags, void* accepted, void* log_rate, void* stream) {
   (void)flags;
   int rc = check_ready(pl, C, "ey_mala_step");
-  if (rc) return rc;
+  if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: null argument");
   if (!(step > 0.0) && !step_vec) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: step must be positive");
   if (C == 0) return EY_OK;
@@ -253,7 +253,7 @@ int ey_mh_step(ey_plan* pl, void* theta, void* target, const void* z, const void
                void* accepted, void* log_rate, void* stream) {
   (void)flags;
   int rc = check_ready(pl, C, "ey_mh_step");
-  if (rc) return rc;
+  if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !target || !scale || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mh_step: null argument");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
