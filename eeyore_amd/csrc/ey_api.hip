@@ -203,6 +203,7 @@ int ey_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t
   if (!theta || !target || !grad) EY_FAIL(EY_ERR_INVALID, "ey_log_target_grad: null argument");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
+  if (pl->mfma32_ok) return ey_mfma32_log_target_grad(pl, theta, temp, C, target, grad, (hipStream_t)stream);
   return ey_generic_log_target(pl, theta, temp, C, nullptr, nullptr, target, grad, (hipStream_t)stream);
 }
 
@@ -231,6 +232,7 @@ int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* 
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_leapfrog: num_steps must be >= 1");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
+  if (pl->mfma32_ok) return ey_mfma32_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
   return ey_generic_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
 }
 

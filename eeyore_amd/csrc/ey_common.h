@@ -87,6 +87,8 @@ int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void
                   hipStream_t s);
 int ey_mfma32_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,
                               hipStream_t s);
+int ey_mfma32_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                       int64_t C, void* target, void* grad, hipStream_t s);
 
 // ----------------------------------------------------------------------------------------------- Philox4x32-10
 // Counter-based generator (Salmon et al. 2011).  One call per (element, chain, iteration, stream): the value a

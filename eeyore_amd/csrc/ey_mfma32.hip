@@ -1,12 +1,538 @@
-// MFMA kernel family for MLP(d0-32-32-dK) in f32 -- placeholder until the fused trajectory kernel lands.
+// Fused HMC trajectory kernel on the f32 matrix cores for MLP(4-32-32-3)-shaped models (BASELINE configs 3/4).
+//
+// One wavefront per chain, four chains per workgroup.  The whole draw -- momentum, L leapfrog steps with the MLP
+// forward + hand-coded backward over all data rows, Hamiltonians, accept -- runs in one launch; theta, momentum and
+// the gradient never leave registers, weights are re-staged through LDS once per leapfrog step, activations once
+// per 32-row tile.  HBM is touched at trajectory start and end only.
+//
+// Reference semantics restated (paths relative to papamarkou/eeyore): MLP.forward eeyore/models/mlp.py:45-50,
+// CE-sum eeyore/constants/constants.py:17, log_target eeyore/models/bayesian_model.py:30-56, gradient
+// eeyore/models/log_target_model.py:15-23 (autograd there), HMC.leapfrog / draw eeyore/samplers/hmc.py:100-156.
+//
+// Data layout ("T" layout): a 32x32 tile X[feature][row] lives in the 16 accumulator registers of
+// v_mfma_f32_32x32x2_f32: lane (c = lane&31, h = lane>>5), register r = 4q+j  <->  X[feature = 8q+4h+j][row = c].
+// Computing every layer transposed (H_l^T = W_l H_{l-1}^T) makes that accumulator tile directly the B operand of the
+// next product when its k-step (q,j) assigns k-slot h to feature 8q+4h+j, so the forward chain F0 -> F1 and the
+// backward chain dH1 -> dH0 need no data movement at all.  Only the weight-gradient products, which contract over
+// the row index (the lane index of a T tile), need a transpose: the tile is written to LDS [feature][36] and read
+// back with ds_read_b128 as lane <-> feature, 4 consecutive rows per read (conflict-free at stride 36).
+// The 32->3 output layer and the 4->32 input-weight gradient use v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4
+// outer products per instruction) so that the skinny dimension does not waste a 32-wide tile.
+//
+// Per-lane canonical registers of theta / momentum / gradient (29 floats each):
+//   w1[4q+j] = W1[out = 8q+4h+j][in = c]   (the D layout of dW1 and the A operand of dH0 = W1^T delta1)
+//   w0[i]    = W0[out = 4(c>>2)+i][in = c&3]  (D layout of the 4x4x1 product; both halves hold the same values)
+//   w2[o]    = W2[o][k = c]                 (ditto)      b1 = b1[c], b0 = b0[c], b2[o] uniform
+#include <cstring>
+#include <vector>
+
 #include "ey_common.h"
 
-bool ey_mfma32_supports(const ey_plan*) { return false; }
-int ey_mfma32_set_data(ey_plan*, hipStream_t) { return EY_OK; }
-int ey_mfma32_hmc(ey_plan*, void*, void*, void*, const void*, const void*, double, const void*, int, const void*,
-                  int64_t, uint64_t, uint64_t, uint64_t, uint32_t, void*, void*, void*, void*, hipStream_t) {
-  EY_FAIL(EY_ERR_UNSUPPORTED, "mfma32 path not built");
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MF_WAVES 4
+#define MF_THREADS (MF_WAVES * 64)
+#define MF_MAX_TILES 12
+// per-wave LDS carve, in floats (all offsets multiples of 4 => 16-byte aligned b128 accesses)
+#define TS36 36
+#define O_W1IMG 0
+#define O_TB0 1152
+#define O_TB1 2304
+#define O_W0IMG 3456   // [32][5]
+#define O_W2IMG 3616   // [4][36]
+#define O_W2TIMG 3760  // [32][4]
+#define O_B0IMG 3888
+#define O_B1IMG 3920
+#define O_D2BUF 3952   // [4][2][16]
+#define WAVE_FLOATS 4080
+#define XTILE_FLOATS 288  // per row tile: [32][5] (x0..x3, label) + [4][2][16] (x regrouped for the 4x4x1 product)
+
+// canonical offsets of MLP(4-32-32-3) in theta
+#define I_W0 0
+#define I_B0 128
+#define I_W1 160
+#define I_B1 1184
+#define I_W2 1216
+#define I_B2 1312
+#define NPAR 1315
+
+enum { MODE_HMC = 0, MODE_GRAD = 1, MODE_LEAPFROG = 2 };
+
+struct MfArgs {
+  const float* xpack;  // [ntiles][288]
+  const float* mu;
+  const float* inv_var;
+  float prior_const;
+  int ntiles;
+  int64_t C;
+  float* theta;        // [C,P] in/out
+  float* target;       // [C]
+  float* grad;         // [C,P]
+  const float* p0;     // HMC: [C,P] or null (Philox); LEAPFROG: unused
+  float* pio;          // LEAPFROG: [C,P] in/out
+  const float* u;      // [C] or null
+  float step;
+  const float* step_vec;
+  int L;
+  const float* temp;
+  uint64_t seed, iter, chain_offset;
+  int recompute;
+  unsigned char* accepted;
+  float *rate, *hcur, *hprop;
+};
+
+struct Vec {
+  float w1[16];
+  float w0[4];
+  float w2[3];
+  float b1, b0;
+  float b2[3];
+};
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
 }
-int ey_mfma32_log_target_grad(ey_plan*, const void*, const void*, int64_t, void*, void*, hipStream_t) {
-  EY_FAIL(EY_ERR_UNSUPPORTED, "mfma32 path not built");
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float fast_sigmoid(float g) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+}
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in issue order; this only stops the compiler from moving them.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// visit every canonical element a lane holds: f(value&, canonical index, counts) where `counts` says whether this
+// lane's copy is the one that enters sums over parameters (replicas in the other half / other lanes do not)
+template <typename F>
+__device__ __forceinline__ void for_each(Vec& v, int c, int h, int lane, F f) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) f(v.w1[r], I_W1 + (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + c, true);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f(v.w0[i], I_W0 + (4 * (c >> 2) + i) * 4 + (c & 3), h == 0);
+#pragma unroll
+  for (int o = 0; o < 3; ++o) f(v.w2[o], I_W2 + o * 32 + c, h == 0);
+  f(v.b1, I_B1 + c, h == 0);
+  f(v.b0, I_B0 + c, h == 0);
+#pragma unroll
+  for (int o = 0; o < 3; ++o) f(v.b2[o], I_B2 + o, lane == 0);
+}
+template <typename F>
+__device__ __forceinline__ void for_each_pair(Vec& a, Vec& b, int c, int h, int lane, F f) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) f(a.w1[r], b.w1[r], I_W1 + (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + c, true);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f(a.w0[i], b.w0[i], I_W0 + (4 * (c >> 2) + i) * 4 + (c & 3), h == 0);
+#pragma unroll
+  for (int o = 0; o < 3; ++o) f(a.w2[o], b.w2[o], I_W2 + o * 32 + c, h == 0);
+  f(a.b1, b.b1, I_B1 + c, h == 0);
+  f(a.b0, b.b0, I_B0 + c, h == 0);
+#pragma unroll
+  for (int o = 0; o < 3; ++o) f(a.b2[o], b.b2[o], I_B2 + o, lane == 0);
+}
+template <typename F>
+__device__ __forceinline__ void for_each2(Vec& a, Vec& b, F f) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) f(a.w1[r], b.w1[r]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f(a.w0[i], b.w0[i]);
+#pragma unroll
+  for (int o = 0; o < 3; ++o) f(a.w2[o], b.w2[o]);
+  f(a.b1, b.b1);
+  f(a.b0, b.b0);
+#pragma unroll
+  for (int o = 0; o < 3; ++o) f(a.b2[o], b.b2[o]);
+}
+
+// stage the operand images of theta in this wave's LDS region
+__device__ __forceinline__ void write_images(float* lw, const Vec& th, int c, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = th.w1[r];
+  if (h == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lw[O_W0IMG + (4 * (c >> 2) + i) * 5 + (c & 3)] = th.w0[i];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      lw[O_W2IMG + o * TS36 + c] = th.w2[o];
+      lw[O_W2TIMG + c * 4 + o] = th.w2[o];
+    }
+    lw[O_W2IMG + 3 * TS36 + c] = 0.0f;
+    lw[O_W2TIMG + c * 4 + 3] = 0.0f;
+    lw[O_B1IMG + c] = th.b1;
+    lw[O_B0IMG + c] = th.b0;
+  }
+  wave_lds_fence();
+}
+
+__device__ __forceinline__ void store_T(float* tb, const f32x16& v, int c, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tb[(8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = v[r];
+}
+
+// log-target and gradient of the position whose images are staged in lw.  Returns the (tempered) log-target.
+__device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec& g, bool has_temp, float temp, int c,
+                      int h, int lane) {
+  const int jj = lane & 3;
+  f32x16 dW1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dW1[r] = 0.0f;
+  f32x4 dW0a = {0, 0, 0, 0}, dW0b = {0, 0, 0, 0}, dW2a = {0, 0, 0, 0}, dW2b = {0, 0, 0, 0};
+  float db1 = 0.0f, db0 = 0.0f, db2[3] = {0.0f, 0.0f, 0.0f}, lik = 0.0f;
+
+#pragma unroll 1
+  for (int t = 0; t < A.ntiles; ++t) {
+    const float* xt = xs + t * XTILE_FLOATS;
+    // ---- F0: H0^T = sigmoid(W0 X^T + b0)                                  (mlp.py:45-50)
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(lw + O_B0IMG + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw[O_W0IMG + c * 5 + 2 * s + h], xt[c * 5 + 2 * s + h], acc, 0, 0, 0);
+    const int lab = __float_as_int(xt[c * 5 + 4]);
+    f32x16 H0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H0[r] = fast_sigmoid(acc[r]);
+    // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(lw + O_B1IMG + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + O_W1IMG + c * TS36 + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], H0[4 * q + j], acc, 0, 0, 0);
+    }
+    f32x16 H1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H1[r] = fast_sigmoid(acc[r]);
+    // ---- F2: logits = W2 H1^T + b2 with the 16-block 4x4x1 product; each half sums its 16 features
+    f32x4 lg0 = {0, 0, 0, 0}, lg1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + O_W2IMG + jj * TS36 + 8 * q + 4 * h);
+      lg0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[0], H1[4 * q + 0], lg0, 0, 0, 0);
+      lg1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[1], H1[4 * q + 1], lg1, 0, 0, 0);
+      lg0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[2], H1[4 * q + 2], lg0, 0, 0, 0);
+      lg1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[3], H1[4 * q + 3], lg1, 0, 0, 0);
+    }
+    float l0 = lg0[0] + lg1[0], l1 = lg0[1] + lg1[1], l2 = lg0[2] + lg1[2];
+    l0 += xhalf(l0); l1 += xhalf(l1); l2 += xhalf(l2);
+    l0 += th.b2[0]; l1 += th.b2[1]; l2 += th.b2[2];
+    // ---- CE-sum log-likelihood and output delta = onehot - softmax           (constants.py:17)
+    const bool valid = lab >= 0;
+    const float mx = fmaxf(l0, fmaxf(l1, l2));
+    const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx), e2 = __expf(l2 - mx);
+    const float ssum = e0 + e1 + e2;
+    const float llab = lab == 0 ? l0 : (lab == 1 ? l1 : l2);
+    if (valid && h == 0) lik += llab - (mx + __logf(ssum));
+    const float rs = __builtin_amdgcn_rcpf(ssum);
+    float d2[3];
+    d2[0] = valid ? ((lab == 0 ? 1.0f : 0.0f) - e0 * rs) : 0.0f;
+    d2[1] = valid ? ((lab == 1 ? 1.0f : 0.0f) - e1 * rs) : 0.0f;
+    d2[2] = valid ? ((lab == 2 ? 1.0f : 0.0f) - e2 * rs) : 0.0f;
+    if (h == 0) {
+      db2[0] += d2[0]; db2[1] += d2[1]; db2[2] += d2[2];
+      // delta2 regrouped [o][half][s'][i] with row = 8s'+4*half+i, the k order of the transposed reads below
+      const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
+      lw[O_D2BUF + 0 * 32 + a2] = d2[0];
+      lw[O_D2BUF + 1 * 32 + a2] = d2[1];
+      lw[O_D2BUF + 2 * 32 + a2] = d2[2];
+      lw[O_D2BUF + 3 * 32 + a2] = 0.0f;
+    }
+    store_T(lw + O_TB0, H1, c, h);
+    wave_lds_fence();
+    // ---- B2(2): dW2[o][k] += sum_n delta2[n][o] H1[n][k]                    (contracts over rows: transposed reads)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
+      const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_D2BUF + jj * 32 + h * 16 + 4 * s);
+      dW2a = __builtin_amdgcn_mfma_f32_4x4x1f32(du[0], hu[0], dW2a, 0, 0, 0);
+      dW2b = __builtin_amdgcn_mfma_f32_4x4x1f32(du[1], hu[1], dW2b, 0, 0, 0);
+      dW2a = __builtin_amdgcn_mfma_f32_4x4x1f32(du[2], hu[2], dW2a, 0, 0, 0);
+      dW2b = __builtin_amdgcn_mfma_f32_4x4x1f32(du[3], hu[3], dW2b, 0, 0, 0);
+    }
+    // ---- B1(2): dH1^T = W2^T delta2^T, delta1 = dH1 * H1 (1 - H1)
+    f32x16 D1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 wt = *reinterpret_cast<const f32x4*>(lw + O_W2TIMG + (8 * q + 4 * h + jj) * 4);
+      f32x4 d = {0, 0, 0, 0};
+      d = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[0], d2[0], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[1], d2[1], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[2], d2[2], d, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i] * H1[4 * q + i] * (1.0f - H1[4 * q + i]);
+    }
+    wave_lds_fence();
+    store_T(lw + O_TB0, D1, c, h);
+    store_T(lw + O_TB1, H0, c, h);
+    wave_lds_fence();
+    // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
+      const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB1 + c * TS36 + 8 * s + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(du[i], hu[i], dW1, 0, 0, 0);
+      db1 += (du[0] + du[1]) + (du[2] + du[3]);
+    }
+    // ---- B1(1): dH0^T = W1^T delta1^T, delta0 = dH0 * H0 (1 - H0); theta's own registers are the A operand
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(th.w1[r], D1[r], acc, 0, 0, 0);
+    f32x16 D0v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D0v[r] = acc[r] * H0[r] * (1.0f - H0[r]);
+    wave_lds_fence();
+    store_T(lw + O_TB0, D0v, c, h);
+    wave_lds_fence();
+    // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
+    const float* x2 = xt + 160 + (jj * 2 + h) * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
+      const f32x4 xu = *reinterpret_cast<const f32x4*>(x2 + 4 * s);
+      dW0a = __builtin_amdgcn_mfma_f32_4x4x1f32(du[0], xu[0], dW0a, 0, 0, 0);
+      dW0b = __builtin_amdgcn_mfma_f32_4x4x1f32(du[1], xu[1], dW0b, 0, 0, 0);
+      dW0a = __builtin_amdgcn_mfma_f32_4x4x1f32(du[2], xu[2], dW0a, 0, 0, 0);
+      dW0b = __builtin_amdgcn_mfma_f32_4x4x1f32(du[3], xu[3], dW0b, 0, 0, 0);
+      db0 += (du[0] + du[1]) + (du[2] + du[3]);
+    }
+    wave_lds_fence();
+  }
+  // ---- combine the two row-parity halves and the lanes
+#pragma unroll
+  for (int r = 0; r < 16; ++r) g.w1[r] = dW1[r];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = dW0a[i] + dW0b[i];
+    g.w0[i] = v + xhalf(v);
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    const float v = dW2a[o] + dW2b[o];
+    g.w2[o] = v + xhalf(v);
+    g.b2[o] = wsum(db2[o]);
+  }
+  g.b1 = db1 + xhalf(db1);
+  g.b0 = db0 + xhalf(db0);
+  lik = wsum(lik);
+  // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
+  float qsum = 0.0f;
+  for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int idx, bool counts) {
+    const float d = tv - A.mu[idx];
+    const float iv = A.inv_var[idx];
+    if (counts) qsum += d * d * iv;
+    float gn = gv - d * iv;
+    if (has_temp) gn *= temp;
+    gv = gn;
+  });
+  qsum = wsum(qsum);
+  float prior = A.prior_const - 0.5f * qsum;
+  if (has_temp) { lik *= temp; prior *= temp; }
+  return lik + prior;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(MF_THREADS, 2) k_mfma32(MfArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  // shared, read-only data images
+  const int xfloats = A.ntiles * XTILE_FLOATS;
+  for (int i = tid; i < xfloats; i += MF_THREADS) smem[i] = A.xpack[i];
+  __syncthreads();
+  const float* xs = smem;
+  float* lw = smem + xfloats + wave * WAVE_FLOATS;
+  const int64_t chain = (int64_t)blockIdx.x * MF_WAVES + wave;
+  if (chain >= A.C) return;  // whole wave; no further block-level synchronisation below
+  float* thg = A.theta + chain * NPAR;
+  float* grg = A.grad + chain * NPAR;
+  const bool has_temp = A.temp != nullptr;
+  const float temp = has_temp ? A.temp[chain] : 1.0f;
+  const float eps = A.step_vec ? A.step_vec[chain] : A.step;
+
+  Vec th, g, p;
+  for_each(th, c, h, lane, [&](float& v, int idx, bool) { v = thg[idx]; });
+
+  if (MODE == MODE_GRAD) {
+    write_images(lw, th, c, h);
+    const float t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane);
+    for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
+    if (lane == 0) A.target[chain] = t;
+    return;
+  }
+
+  float t_cur = 0.0f, kin = 0.0f;
+  if (MODE == MODE_HMC) {
+    const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_NORMAL);
+    const float* p0 = A.p0 ? A.p0 + chain * NPAR : nullptr;
+    for_each(p, c, h, lane, [&](float& v, int idx, bool counts) {
+      v = p0 ? p0[idx] : ey_rng_normal<float>(rn, (uint32_t)idx);   // hmc.py:134
+      if (counts) kin += v * v;
+    });
+    kin = wsum(kin);
+    t_cur = A.target[chain];
+    if (!A.recompute) for_each(g, c, h, lane, [&](float& v, int idx, bool) { v = grg[idx]; });
+  } else {
+    const float* pin = A.pio + chain * NPAR;
+    for_each(p, c, h, lane, [&](float& v, int idx, bool) { v = pin[idx]; });
+  }
+  const float h_cur = -t_cur + 0.5f * kin;  // hmc.py:91-98,137
+  float t = t_cur;
+  if (MODE == MODE_LEAPFROG || A.recompute) {  // hmc.py:104
+    write_images(lw, th, c, h);
+    t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane);
+  }
+  // leapfrog, hmc.py:100-124 (grad_potential = -grad)
+  for_each2(p, g, [&](float& pv, float& gv) { pv = pv + 0.5f * eps * gv; });
+#pragma unroll 1
+  for (int k = 1; k <= A.L; ++k) {
+    for_each2(th, p, [&](float& tv, float& pv) { tv = tv + eps * pv; });
+    write_images(lw, th, c, h);
+    t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane);
+    const float w = (k < A.L) ? eps : 0.5f * eps;
+    for_each2(p, g, [&](float& pv, float& gv) { pv = pv + w * gv; });
+  }
+
+  if (MODE == MODE_LEAPFROG) {
+    float* pout = A.pio + chain * NPAR;
+    for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) thg[idx] = v; });
+    for_each(p, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) pout[idx] = -v; });  // hmc.py:122
+    for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
+    if (lane == 0) A.target[chain] = t;
+    return;
+  }
+
+  kin = 0.0f;
+  for_each(p, c, h, lane, [&](float& v, int, bool counts) { if (counts) kin += v * v; });
+  kin = wsum(kin);
+  const float h_prop = -t + 0.5f * kin;
+  float rate = __expf(h_cur - h_prop);  // hmc.py:143-146
+  if (rate > 1.0f) rate = 1.0f;
+  const EyRng ru = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_UNIFORM);
+  const float u = A.u ? A.u[chain] : ey_rng_uniform<float>(ru);
+  const bool acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
+  if (acc) {
+    for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) thg[idx] = v; });
+    for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
+  }
+  if (lane == 0) {
+    if (acc) A.target[chain] = t;
+    A.accepted[chain] = acc ? 1 : 0;
+    if (A.rate) A.rate[chain] = rate;
+    if (A.hcur) A.hcur[chain] = h_cur;
+    if (A.hprop) A.hprop[chain] = h_prop;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- host side
+bool ey_mfma32_supports(const ey_plan* pl) {
+  const EyModel& m = pl->m;
+  if (pl->dtype != EY_F32 || m.nl != 3 || m.lik != EY_LIK_CE_SUM) return false;
+  if (m.dims[0] != 4 || m.dims[1] != 32 || m.dims[2] != 32 || m.dims[3] != 3) return false;
+  if (!m.bias[0] || !m.bias[1] || !m.bias[2]) return false;
+  return m.act[0] == EY_ACT_SIGMOID && m.act[1] == EY_ACT_SIGMOID && m.act[2] == EY_ACT_NONE;
+}
+
+static size_t mf_lds_bytes(int ntiles) { return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + MF_WAVES * WAVE_FLOATS); }
+
+// Pack (x, labels) into the per-tile LDS images.  Rows beyond N are zero with label -1 (they contribute nothing).
+int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
+  const EyModel& m = pl->m;
+  const int ntiles = (m.N + 31) / 32;
+  if (ntiles > MF_MAX_TILES) {  // the shared data image would crowd out a second workgroup per CU
+    pl->mfma32_ok = false;
+    return EY_OK;
+  }
+  std::vector<float> hx((size_t)m.N * 4);
+  std::vector<int> hl(m.N);
+  EY_HIP(hipMemcpyAsync(hx.data(), pl->d_x, hx.size() * 4, hipMemcpyDeviceToHost, s));
+  EY_HIP(hipMemcpyAsync(hl.data(), pl->d_labels, hl.size() * 4, hipMemcpyDeviceToHost, s));
+  EY_HIP(hipStreamSynchronize(s));
+  std::vector<float> img((size_t)ntiles * XTILE_FLOATS, 0.0f);
+  for (int t = 0; t < ntiles; ++t) {
+    float* xt = img.data() + (size_t)t * XTILE_FLOATS;
+    for (int cc = 0; cc < 32; ++cc) {
+      const int n = 32 * t + cc;
+      int lab = -1;
+      float xv[4] = {0, 0, 0, 0};
+      if (n < m.N) {
+        lab = hl[n];
+        for (int i = 0; i < 4; ++i) xv[i] = hx[(size_t)n * 4 + i];
+      }
+      for (int i = 0; i < 4; ++i) xt[cc * 5 + i] = xv[i];
+      memcpy(&xt[cc * 5 + 4], &lab, 4);
+      // regrouped copy for the 4x4x1 weight-gradient product: [in][half][s'][i], row = 8s' + 4 half + i
+      const int sp = cc >> 3, hh = (cc >> 2) & 1, ii = cc & 3;
+      for (int i = 0; i < 4; ++i) xt[160 + (i * 2 + hh) * 16 + sp * 4 + ii] = xv[i];
+    }
+  }
+  (void)hipFree(pl->d_xpack);
+  pl->d_xpack = nullptr;
+  EY_HIP(hipMalloc(&pl->d_xpack, img.size() * 4));
+  EY_HIP(hipMemcpy(pl->d_xpack, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  return EY_OK;
+}
+
+template <int MODE>
+static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
+  const EyModel& m = pl->m;
+  a.xpack = (const float*)pl->d_xpack;
+  a.mu = (const float*)m.mu;
+  a.inv_var = (const float*)m.inv_var;
+  a.prior_const = (float)m.prior_const;
+  a.ntiles = (m.N + 31) / 32;
+  const size_t bytes = mf_lds_bytes(a.ntiles);
+  static bool attr_done[3] = {false, false, false};
+  if (!attr_done[MODE]) {
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)mf_lds_bytes(MF_MAX_TILES)));
+    attr_done[MODE] = true;
+  }
+  const unsigned grid = (unsigned)((a.C + MF_WAVES - 1) / MF_WAVES);
+  hipLaunchKernelGGL(k_mfma32<MODE>, dim3(grid), dim3(MF_THREADS), bytes, s, a);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                  const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                  uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                  hipStream_t s) {
+  MfArgs a = {};
+  a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)grad;
+  a.p0 = (const float*)p0; a.u = (const float*)u; a.step = (float)step; a.step_vec = (const float*)step_vec;
+  a.L = L; a.temp = (const float*)temp; a.seed = seed; a.iter = iter; a.chain_offset = chain_offset;
+  a.recompute = (flags & EY_RECOMPUTE_INITIAL_GRAD) ? 1 : 0;
+  a.accepted = (unsigned char*)accepted; a.rate = (float*)rate; a.hcur = (float*)hcur; a.hprop = (float*)hprop;
+  return mf_launch<MODE_HMC>(pl, a, s);
+}
+
+int ey_mfma32_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,
+                              hipStream_t s) {
+  MfArgs a = {};
+  a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)grad; a.temp = (const float*)temp;
+  return mf_launch<MODE_GRAD>(pl, a, s);
+}
+
+int ey_mfma32_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                       int64_t C, void* target, void* grad, hipStream_t s) {
+  MfArgs a = {};
+  a.C = C; a.theta = (float*)theta; a.pio = (float*)p; a.target = (float*)target; a.grad = (float*)grad;
+  a.step = (float)step; a.step_vec = (const float*)step_vec; a.L = L; a.temp = (const float*)temp;
+  return mf_launch<MODE_LEAPFROG>(pl, a, s);
 }
