@@ -387,3 +387,91 @@ def test_sampler_surface_batched_philox():
         acc = ch.acceptance_rate().mean().item()
         assert 0.05 < acc <= 1.0, (S.__name__, acc)
         assert torch.isfinite(ch.get_target_vals()).all()
+
+
+# --------------------------------------------------------------------------------------------- MFMA kernel family
+def _cfg3_plan(N=None, seed=0):
+    from eeyore_amd.datasets import synthetic
+    rec = dict(groups(load("g4_hmc_traces.npz"))["mlp432323_synth"])
+    if N is not None:
+        x, y = synthetic.iris_shaped_arrays(seed=seed, per_class=(N + 2) // 3)
+        perm = np.random.default_rng(1).permutation(x.shape[0])[:N]
+        rec["x"], rec["y"] = x[perm], y[perm]
+    return rec, _plan(rec, torch.float32)
+
+
+def test_mfma32_serves_config3_and_matches_generic_kernel():
+    from eeyore_amd import _lib as L
+    rec, pl = _cfg3_plan()
+    assert pl.kernel == "mfma32"
+    C = 37  # not a multiple of the 4 chains per workgroup
+    th = 0.2 * pl.philox_normal(C, seed=3, it=0)
+    t, g = pl.log_target_grad(th)
+    p0, u = pl.philox_normal(C, seed=3, it=1), pl.philox_uniform(C, seed=3, it=1)
+    a = [th.clone(), t.clone(), g.clone()]
+    b = [th.clone(), t.clone(), g.clone()]
+    oa = pl.hmc_step(*a, 0.03, 12, p0=p0, u=u)
+    ob = pl.hmc_step(*b, 0.03, 12, p0=p0, u=u, flags=L.EY_FORCE_GENERIC)
+    decided = (u - oa["rate"]).abs() > 2e-3
+    assert torch.equal(oa["accepted"][decided], ob["accepted"][decided])
+    np.testing.assert_allclose(oa["h_prop"].cpu().numpy(), ob["h_prop"].cpu().numpy(), rtol=2e-4, atol=2e-2)
+    same = (oa["accepted"] == ob["accepted"]).cpu().numpy()
+    np.testing.assert_allclose(a[0].cpu().numpy()[same], b[0].cpu().numpy()[same], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(a[2].cpu().numpy()[same], b[2].cpu().numpy()[same], rtol=5e-3, atol=5e-3)
+    assert 0 < oa["accepted"].sum().item() < C
+
+
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 150, 160, 384])
+def test_mfma32_row_counts_vs_oracle(N):
+    rec, pl = _cfg3_plan(N)
+    assert pl.kernel == "mfma32"
+    co = _oracle(rec, np.float32)
+    th = 0.3 * pl.philox_normal(5, seed=9, it=N)
+    temps = torch.tensor([1.0, 0.5, 0.25, 1.0, 0.1])
+    t, g = pl.log_target_grad(th)
+    tt, gt = pl.log_target_grad(th, temp=temps)
+    for c in range(5):
+        to, go, _, _ = co.log_target_grad(th[c].cpu().numpy())
+        np.testing.assert_allclose(t[c].item(), to, rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(go).max()))
+        np.testing.assert_allclose(tt[c].item(), temps[c].item() * to, rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(gt[c].cpu().numpy(), temps[c].item() * go, rtol=2e-4,
+                                   atol=2e-4 * max(1.0, np.abs(go).max()))
+
+
+def test_mfma32_falls_back_to_generic_beyond_its_row_limit():
+    rec, pl = _cfg3_plan(400)
+    assert pl.kernel == "generic"
+    co = _oracle(rec, np.float32)
+    th = 0.3 * pl.philox_normal(2, seed=9, it=0)
+    t, g = pl.log_target_grad(th)
+    to, go, _, _ = co.log_target_grad(th[0].cpu().numpy())
+    np.testing.assert_allclose(t[0].item(), to, rtol=2e-4)
+
+
+def test_mfma32_philox_and_per_chain_step():
+    rec, pl = _cfg3_plan()
+    C = 256
+    th = 0.1 * pl.philox_normal(C, seed=1, it=0)
+    t, g = pl.log_target_grad(th)
+    z, u = pl.philox_normal(C, seed=21, it=5, chain_offset=1000), pl.philox_uniform(C, seed=21, it=5, chain_offset=1000)
+    steps = torch.linspace(0.005, 0.08, C)
+    a = [th.clone(), t.clone(), g.clone()]
+    b = [th.clone(), t.clone(), g.clone()]
+    oa = pl.hmc_step(*a, 0.0, 9, step_vec=steps, seed=21, it=5, chain_offset=1000)
+    ob = pl.hmc_step(*b, 0.0, 9, step_vec=steps, p0=z, u=u)
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    acc = oa["accepted"].float()
+    assert acc[:64].mean() > acc[-64:].mean()  # larger steps are rejected more often
+    # leapfrog operator: the mfma kernel against the oracle with a per-chain step
+    co = _oracle(rec, np.float32)
+    th2, p2 = th[:4].clone(), z[:4].clone()
+    tl, gl = pl.leapfrog(th2, p2, 0.0, 6, step_vec=steps[100:104].clone())
+    for c in range(4):
+        tho, po, to, go = co.leapfrog(th[c].cpu().numpy(), z[c].cpu().numpy(), float(steps[100 + c]), 6)
+        np.testing.assert_allclose(th2[c].cpu().numpy(), tho, rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(p2[c].cpu().numpy(), po, rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(tl[c].item(), to, rtol=2e-4, atol=2e-3)
