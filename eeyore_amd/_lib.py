@@ -37,6 +37,7 @@ SYMBOLS = {
     "ey_pt_swap_decide": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "ey_philox_normal": (_i, [_vp, _i64, _i64, _u64, _u64, _u64, _i, _vp]),
     "ey_philox_uniform": (_i, [_vp, _i64, _u64, _u64, _u64, _i, _vp]),
+    "ey_debug_set_variant": (_i, [_i]),
 }
 
 

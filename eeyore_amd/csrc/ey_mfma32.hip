@@ -31,8 +31,6 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define MF_WAVES 4
-#define MF_THREADS (MF_WAVES * 64)
 #define MF_MAX_TILES 12
 // per-wave LDS carve, in floats (all offsets multiples of 4 => 16-byte aligned b128 accesses)
 #define TS36 36
@@ -96,8 +94,11 @@ __device__ __forceinline__ float wsum(float v) {
   return v;
 }
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
-__device__ __forceinline__ float fast_sigmoid(float g) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+// The staged images of W0, b0, W1, b1 carry the factor -log2(e), so the accumulator holds -g*log2(e) and
+// sigmoid(g) = 1 / (1 + 2^acc): one v_exp_f32, one v_add_f32, one v_rcp_f32 per element.
+#define NEG_LOG2E (-1.4426950408889634f)
+__device__ __forceinline__ float sigmoid_from_scaled(float a) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in issue order; this only stops the compiler from moving them.
@@ -150,10 +151,10 @@ __device__ __forceinline__ void for_each2(Vec& a, Vec& b, F f) {
 // stage the operand images of theta in this wave's LDS region
 __device__ __forceinline__ void write_images(float* lw, const Vec& th, int c, int h) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = th.w1[r];
+  for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = NEG_LOG2E * th.w1[r];
   if (h == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lw[O_W0IMG + (4 * (c >> 2) + i) * 5 + (c & 3)] = th.w0[i];
+    for (int i = 0; i < 4; ++i) lw[O_W0IMG + (4 * (c >> 2) + i) * 5 + (c & 3)] = NEG_LOG2E * th.w0[i];
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
       lw[O_W2IMG + o * TS36 + c] = th.w2[o];
@@ -161,8 +162,8 @@ __device__ __forceinline__ void write_images(float* lw, const Vec& th, int c, in
     }
     lw[O_W2IMG + 3 * TS36 + c] = 0.0f;
     lw[O_W2TIMG + c * 4 + 3] = 0.0f;
-    lw[O_B1IMG + c] = th.b1;
-    lw[O_B0IMG + c] = th.b0;
+    lw[O_B1IMG + c] = NEG_LOG2E * th.b1;
+    lw[O_B0IMG + c] = NEG_LOG2E * th.b0;
   }
   wave_lds_fence();
 }
@@ -199,7 +200,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     const int lab = __float_as_int(xt[c * 5 + 4]);
     f32x16 H0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) H0[r] = fast_sigmoid(acc[r]);
+    for (int r = 0; r < 16; ++r) H0[r] = sigmoid_from_scaled(acc[r]);
     // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -215,7 +216,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     }
     f32x16 H1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) H1[r] = fast_sigmoid(acc[r]);
+    for (int r = 0; r < 16; ++r) H1[r] = sigmoid_from_scaled(acc[r]);
     // ---- F2: logits = W2 H1^T + b2 with the 16-block 4x4x1 product; each half sums its 16 features
     f32x4 lg0 = {0, 0, 0, 0}, lg1 = {0, 0, 0, 0};
 #pragma unroll
@@ -272,7 +273,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
       d = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[1], d2[1], d, 0, 0, 0);
       d = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[2], d2[2], d, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i] * H1[4 * q + i] * (1.0f - H1[4 * q + i]);
+      for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i] * __builtin_fmaf(-H1[4 * q + i], H1[4 * q + i], H1[4 * q + i]);
     }
     wave_lds_fence();
     store_T(lw + O_TB0, D1, c, h);
@@ -294,7 +295,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(th.w1[r], D1[r], acc, 0, 0, 0);
     f32x16 D0v;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) D0v[r] = acc[r] * H0[r] * (1.0f - H0[r]);
+    for (int r = 0; r < 16; ++r) D0v[r] = acc[r] * __builtin_fmaf(-H0[r], H0[r], H0[r]);
     wave_lds_fence();
     store_T(lw + O_TB0, D0v, c, h);
     wave_lds_fence();
@@ -345,8 +346,12 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
   return lik + prior;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(MF_THREADS, 2) k_mfma32(MfArgs A) {
+// WAVES chains per workgroup (4: two workgroups per CU; 8: one, waves w and w+4 share a SIMD).  PRIO raises the
+// issue priority of the second-dispatched half so the two waves of a SIMD leave lockstep (one in its matrix
+// phase while the other is in its vector/LDS phase).
+template <int MODE, int WAVES, int PRIO>
+__global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
+  constexpr int MF_WAVES = WAVES, MF_THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -359,6 +364,11 @@ __global__ void __launch_bounds__(MF_THREADS, 2) k_mfma32(MfArgs A) {
   float* lw = smem + xfloats + wave * WAVE_FLOATS;
   const int64_t chain = (int64_t)blockIdx.x * MF_WAVES + wave;
   if (chain >= A.C) return;  // whole wave; no further block-level synchronisation below
+  if (PRIO > 0 && WAVES == 8) {
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(PRIO);
+  } else if (PRIO > 0) {
+    if (__builtin_amdgcn_readfirstlane((int)(blockIdx.x & 1))) __builtin_amdgcn_s_setprio(PRIO);
+  }
   float* thg = A.theta + chain * NPAR;
   float* grg = A.grad + chain * NPAR;
   const bool has_temp = A.temp != nullptr;
@@ -448,7 +458,17 @@ bool ey_mfma32_supports(const ey_plan* pl) {
   return m.act[0] == EY_ACT_SIGMOID && m.act[1] == EY_ACT_SIGMOID && m.act[2] == EY_ACT_NONE;
 }
 
-static size_t mf_lds_bytes(int ntiles) { return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + MF_WAVES * WAVE_FLOATS); }
+static size_t mf_lds_bytes(int ntiles, int waves) {
+  return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * WAVE_FLOATS);
+}
+
+// kernel variant: bit0 = 8 chains per workgroup, bits 1-2 = s_setprio level of the second half (tuning knob)
+static int g_variant = 0;
+extern "C" int ey_debug_set_variant(int v) {
+  const int old = g_variant;
+  g_variant = v;
+  return old;
+}
 
 // Pack (x, labels) into the per-tile LDS images.  Rows beyond N are zero with label -1 (they contribute nothing).
 int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
@@ -488,6 +508,21 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
   return EY_OK;
 }
 
+template <int MODE, int WAVES, int PRIO>
+static int mf_launch_v(MfArgs& a, hipStream_t s) {
+  const size_t bytes = mf_lds_bytes(a.ntiles, WAVES);
+  static bool attr_done = false;
+  if (!attr_done) {
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PRIO>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_bytes(MF_MAX_TILES, WAVES)));
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)((a.C + WAVES - 1) / WAVES);
+  hipLaunchKernelGGL((k_mfma32<MODE, WAVES, PRIO>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
 template <int MODE>
 static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   const EyModel& m = pl->m;
@@ -496,17 +531,15 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.inv_var = (const float*)m.inv_var;
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
-  const size_t bytes = mf_lds_bytes(a.ntiles);
-  static bool attr_done[3] = {false, false, false};
-  if (!attr_done[MODE]) {
-    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)mf_lds_bytes(MF_MAX_TILES)));
-    attr_done[MODE] = true;
+  if (MODE != MODE_HMC) return mf_launch_v<MODE, 4, 0>(a, s);
+  switch (g_variant) {
+    case 1: return mf_launch_v<MODE, 8, 0>(a, s);
+    case 2: return mf_launch_v<MODE, 4, 1>(a, s);
+    case 3: return mf_launch_v<MODE, 8, 1>(a, s);
+    case 5: return mf_launch_v<MODE, 8, 2>(a, s);
+    case 7: return mf_launch_v<MODE, 8, 3>(a, s);
+    default: return mf_launch_v<MODE, 4, 0>(a, s);
   }
-  const unsigned grid = (unsigned)((a.C + MF_WAVES - 1) / MF_WAVES);
-  hipLaunchKernelGGL(k_mfma32<MODE>, dim3(grid), dim3(MF_THREADS), bytes, s, a);
-  EY_HIP(hipGetLastError());
-  return EY_OK;
 }
 
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,

@@ -125,6 +125,10 @@ int ey_philox_normal(void* out, int64_t C, int64_t P, uint64_t seed, uint64_t it
 int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, int dtype,
                       void* stream);
 
+/* Tuning knob for the MFMA kernel family (not part of the drop-in surface): selects the workgroup shape /
+ * issue-priority variant of the fused trajectory kernel; returns the previous value.  Results do not depend on it. */
+int ey_debug_set_variant(int variant);
+
 #ifdef __cplusplus
 }
 #endif
