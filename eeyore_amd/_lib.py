@@ -8,7 +8,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libeeyore_amd.so")
+LIB_PATH = os.environ.get("EEYORE_AMD_LIB", os.path.join(HERE, "lib", "libeeyore_amd.so"))  # override: diagnostics
 CSRC = os.path.join(HERE, "csrc")
 
 EY_F32, EY_F64 = 0, 1
@@ -37,6 +37,7 @@ SYMBOLS = {
     "ey_pt_swap_decide": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "ey_philox_normal": (_i, [_vp, _i64, _i64, _u64, _u64, _u64, _i, _vp]),
     "ey_philox_uniform": (_i, [_vp, _i64, _u64, _u64, _u64, _i, _vp]),
+    "ey_stats_update": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
     "ey_debug_set_variant": (_i, [_i]),
 }
 

@@ -349,3 +349,56 @@ int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64
 }
 
 }  // extern "C"
+
+// ----------------------------------------------------------------------------------------------- chain moments
+// Running per-chain sums for ChainLists.mean / multi_rhat-style summaries (eeyore/chains/chain_lists.py:65-66,
+// eeyore/stats/multi_rhat.py): s1 += theta, s2 += theta^2 in double, acc += accepted; one streaming pass.
+template <typename T>
+__global__ void k_stats_update(const T* __restrict__ theta, double* __restrict__ s1, double* __restrict__ s2,
+                               int64_t n4, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t b = 4 * i;
+    if (b + 3 < n && sizeof(T) == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(theta) + b);
+      double2* p1 = reinterpret_cast<double2*>(s1 + b);
+      double2* p2 = reinterpret_cast<double2*>(s2 + b);
+      double2 a0 = p1[0], a1 = p1[1], q0 = p2[0], q1 = p2[1];
+      a0.x += t.x; a0.y += t.y; a1.x += t.z; a1.y += t.w;
+      q0.x += (double)t.x * t.x; q0.y += (double)t.y * t.y; q1.x += (double)t.z * t.z; q1.y += (double)t.w * t.w;
+      p1[0] = a0; p1[1] = a1; p2[0] = q0; p2[1] = q1;
+    } else {
+      for (int64_t k = b; k < n && k < b + 4; ++k) {
+        const double t = (double)theta[k];
+        s1[k] += t;
+        s2[k] += t * t;
+      }
+    }
+  }
+}
+
+__global__ void k_acc_update(const unsigned char* __restrict__ accepted, double* __restrict__ acc, int64_t C) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) acc[c] += (double)accepted[c];
+}
+
+extern "C" int ey_stats_update(const void* theta, const void* accepted, int64_t C, int64_t P, int dtype, void* s1,
+                               void* s2, void* acc, void* stream) {
+  if (!theta || !s1 || !s2) EY_FAIL(EY_ERR_INVALID, "ey_stats_update: null argument");
+  if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_stats_update: bad dtype");
+  if (C <= 0 || P <= 0) return EY_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = C * P, n4 = (n + 3) / 4;
+  const unsigned nb = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  if (dtype == EY_F32)
+    hipLaunchKernelGGL(k_stats_update<float>, dim3(nb), dim3(256), 0, s, (const float*)theta, (double*)s1, (double*)s2,
+                       n4, n);
+  else
+    hipLaunchKernelGGL(k_stats_update<double>, dim3(nb), dim3(256), 0, s, (const double*)theta, (double*)s1,
+                       (double*)s2, n4, n);
+  if (accepted && acc)
+    hipLaunchKernelGGL(k_acc_update, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned char*)accepted, (double*)acc, C);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}

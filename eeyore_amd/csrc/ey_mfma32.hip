@@ -97,8 +97,18 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); 
 // The staged images of W0, b0, W1, b1 carry the factor -log2(e), so the accumulator holds -g*log2(e) and
 // sigmoid(g) = 1 / (1 + 2^acc): one v_exp_f32, one v_add_f32, one v_rcp_f32 per element.
 #define NEG_LOG2E (-1.4426950408889634f)
+// EY_ABLATE (diagnostic builds only, tools/ablate.sh): 1 = no transpose stores, 2 = no 4x4x1 products,
+// 4 = no transcendental in the sigmoid, 8 = no dW1 product.  Results are wrong in such a build; only its timing is read.
+#ifndef EY_ABLATE
+#define EY_ABLATE 0
+#endif
 __device__ __forceinline__ float sigmoid_from_scaled(float a) {
+  if (EY_ABLATE & 4) return a * 0.01f + 0.5f;
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
+}
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  if (EY_ABLATE & 2) { c[0] += a * 1e-9f; return c; }
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in issue order; this only stops the compiler from moving them.
@@ -169,6 +179,7 @@ __device__ __forceinline__ void write_images(float* lw, const Vec& th, int c, in
 }
 
 __device__ __forceinline__ void store_T(float* tb, const f32x16& v, int c, int h) {
+  if (EY_ABLATE & 1) { tb[c] = v[0] + v[5] + v[10] + v[15]; return; }
 #pragma unroll
   for (int r = 0; r < 16; ++r) tb[(8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = v[r];
 }
@@ -222,10 +233,10 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + O_W2IMG + jj * TS36 + 8 * q + 4 * h);
-      lg0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[0], H1[4 * q + 0], lg0, 0, 0, 0);
-      lg1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[1], H1[4 * q + 1], lg1, 0, 0, 0);
-      lg0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[2], H1[4 * q + 2], lg0, 0, 0, 0);
-      lg1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[3], H1[4 * q + 3], lg1, 0, 0, 0);
+      lg0 = mfma4(wv[0], H1[4 * q + 0], lg0);
+      lg1 = mfma4(wv[1], H1[4 * q + 1], lg1);
+      lg0 = mfma4(wv[2], H1[4 * q + 2], lg0);
+      lg1 = mfma4(wv[3], H1[4 * q + 3], lg1);
     }
     float l0 = lg0[0] + lg1[0], l1 = lg0[1] + lg1[1], l2 = lg0[2] + lg1[2];
     l0 += xhalf(l0); l1 += xhalf(l1); l2 += xhalf(l2);
@@ -258,10 +269,10 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     for (int s = 0; s < 4; ++s) {
       const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
       const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_D2BUF + jj * 32 + h * 16 + 4 * s);
-      dW2a = __builtin_amdgcn_mfma_f32_4x4x1f32(du[0], hu[0], dW2a, 0, 0, 0);
-      dW2b = __builtin_amdgcn_mfma_f32_4x4x1f32(du[1], hu[1], dW2b, 0, 0, 0);
-      dW2a = __builtin_amdgcn_mfma_f32_4x4x1f32(du[2], hu[2], dW2a, 0, 0, 0);
-      dW2b = __builtin_amdgcn_mfma_f32_4x4x1f32(du[3], hu[3], dW2b, 0, 0, 0);
+      dW2a = mfma4(du[0], hu[0], dW2a);
+      dW2b = mfma4(du[1], hu[1], dW2b);
+      dW2a = mfma4(du[2], hu[2], dW2a);
+      dW2b = mfma4(du[3], hu[3], dW2b);
     }
     // ---- B1(2): dH1^T = W2^T delta2^T, delta1 = dH1 * H1 (1 - H1)
     f32x16 D1;
@@ -269,9 +280,9 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     for (int q = 0; q < 4; ++q) {
       const f32x4 wt = *reinterpret_cast<const f32x4*>(lw + O_W2TIMG + (8 * q + 4 * h + jj) * 4);
       f32x4 d = {0, 0, 0, 0};
-      d = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[0], d2[0], d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[1], d2[1], d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[2], d2[2], d, 0, 0, 0);
+      d = mfma4(wt[0], d2[0], d);
+      d = mfma4(wt[1], d2[1], d);
+      d = mfma4(wt[2], d2[2], d);
 #pragma unroll
       for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i] * __builtin_fmaf(-H1[4 * q + i], H1[4 * q + i], H1[4 * q + i]);
     }
@@ -280,35 +291,39 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     store_T(lw + O_TB1, H0, c, h);
     wave_lds_fence();
     // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
+    f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
       const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB1 + c * TS36 + 8 * s + 4 * h);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(du[i], hu[i], dW1, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        H0U[4 * s + i] = hu[i];
+        if (EY_ABLATE & 8) dW1[i] += du[i] * hu[i];
+        else dW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(du[i], hu[i], dW1, 0, 0, 0);
+      }
       db1 += (du[0] + du[1]) + (du[2] + du[3]);
     }
-    // ---- B1(1): dH0^T = W1^T delta1^T, delta0 = dH0 * H0 (1 - H0); theta's own registers are the A operand
+    // ---- B1(1): dH0 = delta1 W1 computed UNtransposed (A = delta1 tile with M = rows, B = theta's own W1
+    // registers), so its accumulator is already lane <-> input feature, register <-> row: delta0 = dH0 * H0 (1 - H0)
+    // comes out in the layout the dW0 product needs, with no LDS round trip (layer 0 is the last consumer).
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(th.w1[r], D1[r], acc, 0, 0, 0);
-    f32x16 D0v;
+    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
+    f32x16 D0u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) D0v[r] = acc[r] * __builtin_fmaf(-H0[r], H0[r], H0[r]);
-    wave_lds_fence();
-    store_T(lw + O_TB0, D0v, c, h);
-    wave_lds_fence();
+    for (int r = 0; r < 16; ++r) D0u[r] = acc[r] * __builtin_fmaf(-H0U[r], H0U[r], H0U[r]);
     // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
     const float* x2 = xt + 160 + (jj * 2 + h) * 16;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
+      const f32x4 du = {D0u[4 * s], D0u[4 * s + 1], D0u[4 * s + 2], D0u[4 * s + 3]};
       const f32x4 xu = *reinterpret_cast<const f32x4*>(x2 + 4 * s);
-      dW0a = __builtin_amdgcn_mfma_f32_4x4x1f32(du[0], xu[0], dW0a, 0, 0, 0);
-      dW0b = __builtin_amdgcn_mfma_f32_4x4x1f32(du[1], xu[1], dW0b, 0, 0, 0);
-      dW0a = __builtin_amdgcn_mfma_f32_4x4x1f32(du[2], xu[2], dW0a, 0, 0, 0);
-      dW0b = __builtin_amdgcn_mfma_f32_4x4x1f32(du[3], xu[3], dW0b, 0, 0, 0);
+      dW0a = mfma4(du[0], xu[0], dW0a);
+      dW0b = mfma4(du[1], xu[1], dW0b);
+      dW0a = mfma4(du[2], xu[2], dW0a);
+      dW0b = mfma4(du[3], xu[3], dW0b);
       db0 += (du[0] + du[1]) + (du[2] + du[3]);
     }
     wave_lds_fence();
@@ -531,15 +546,10 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.inv_var = (const float*)m.inv_var;
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
-  if (MODE != MODE_HMC) return mf_launch_v<MODE, 4, 0>(a, s);
-  switch (g_variant) {
-    case 1: return mf_launch_v<MODE, 8, 0>(a, s);
-    case 2: return mf_launch_v<MODE, 4, 1>(a, s);
-    case 3: return mf_launch_v<MODE, 8, 1>(a, s);
-    case 5: return mf_launch_v<MODE, 8, 2>(a, s);
-    case 7: return mf_launch_v<MODE, 8, 3>(a, s);
-    default: return mf_launch_v<MODE, 4, 0>(a, s);
+  if constexpr (MODE == MODE_HMC) {
+    if (g_variant == 1) return mf_launch_v<MODE, 8, 0>(a, s);
   }
+  return mf_launch_v<MODE, 4, 0>(a, s);
 }
 
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,

@@ -50,6 +50,17 @@ class ChainStats:
         self.acc = torch.zeros(num_chains, dtype=torch.float64, device=device)
 
     def update(self, theta, accepted=None):
+        if theta.is_cuda and theta.dtype in (torch.float32, torch.float64) and theta.is_contiguous():
+            # one streaming HIP pass (ey_stats_update) instead of several elementwise torch kernels
+            import ctypes as ct
+            from . import _lib as L
+            C, P = theta.shape
+            L.check(L.lib().ey_stats_update(
+                L.ptr(theta), L.ptr(accepted), C, P, 0 if theta.dtype == torch.float32 else 1, L.ptr(self.s1),
+                L.ptr(self.s2), L.ptr(self.acc) if accepted is not None else None,
+                ct.c_void_p(torch.cuda.current_stream(theta.device).cuda_stream)), "ey_stats_update")
+            self.n += 1
+            return
         t = theta.to(torch.float64)
         self.s1 += t
         self.s2.addcmul_(t, t)

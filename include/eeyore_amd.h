@@ -125,6 +125,12 @@ int ey_philox_normal(void* out, int64_t C, int64_t P, uint64_t seed, uint64_t it
 int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, int dtype,
                       void* stream);
 
+/* Running per-chain moments for ChainLists.mean / R-hat style summaries (eeyore/chains/chain_lists.py:65-66,
+ * eeyore/stats/multi_rhat.py:10-40): s1 += theta, s2 += theta^2 ([C,P] double accumulators), acc += accepted
+ * ([C] double; `accepted` uint8 [C]; both may be NULL).  theta [C,P] of `dtype`.  One streaming pass. */
+int ey_stats_update(const void* theta, const void* accepted, int64_t C, int64_t P, int dtype, void* s1, void* s2,
+                    void* acc, void* stream);
+
 /* Tuning knob for the MFMA kernel family (not part of the drop-in surface): selects the workgroup shape /
  * issue-priority variant of the fused trajectory kernel; returns the previous value.  Results do not depend on it. */
 int ey_debug_set_variant(int variant);

@@ -475,3 +475,20 @@ def test_mfma32_philox_and_per_chain_step():
         np.testing.assert_allclose(th2[c].cpu().numpy(), tho, rtol=5e-4, atol=5e-5)
         np.testing.assert_allclose(p2[c].cpu().numpy(), po, rtol=2e-3, atol=2e-3)
         np.testing.assert_allclose(tl[c].item(), to, rtol=2e-4, atol=2e-3)
+
+
+def test_chain_stats_hip_pass_equals_torch_formulas():
+    from eeyore_amd.distributed import ChainStats
+    for dt, C, P in ((torch.float32, 37, 1315), (torch.float64, 5, 9)):
+        g = torch.Generator(device="cpu").manual_seed(1)
+        xs = torch.randn(12, C, P, generator=g, dtype=dt)
+        acc = (torch.rand(12, C, generator=g) < 0.6).to(torch.uint8)
+        hip, ref = ChainStats(C, P, DEV), ChainStats(C, P, "cpu")
+        for i in range(12):
+            hip.update(xs[i].to(DEV), acc[i].to(DEV))
+            ref.update(xs[i], acc[i])
+        assert torch.equal(hip.s1.cpu(), ref.s1) and torch.equal(hip.acc.cpu(), ref.acc)
+        np.testing.assert_allclose(hip.s2.cpu().numpy(), ref.s2.numpy(), rtol=1e-15)
+        a, b = hip.summary(), ref.summary()
+        np.testing.assert_allclose(a["rhat"].cpu().numpy(), b["rhat"].numpy(), rtol=1e-12)
+        assert abs(a["acceptance"] - b["acceptance"]) < 1e-15
