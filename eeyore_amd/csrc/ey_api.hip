@@ -281,11 +281,12 @@ __global__ void k_pt_swap(const T* ell_i, const T* ell_j, const T* t_i, const T*
 
 template <typename T>
 __global__ void k_philox_normal(T* out, int64_t C, int64_t P, uint64_t seed, uint64_t iter, uint64_t chain_offset) {
-  const int64_t c = blockIdx.y;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const EyRng r = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
-  out[c * P + i] = ey_rng_normal<T>(r, (uint32_t)i);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < C * P; k += stride) {
+    const int64_t c = k / P, i = k - c * P;
+    const EyRng r = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
+    out[k] = ey_rng_normal<T>(r, (uint32_t)i);
+  }
 }
 
 template <typename T>
@@ -322,8 +323,8 @@ int ey_philox_normal(void* out, int64_t C, int64_t P, uint64_t seed, uint64_t it
   if (!out) EY_FAIL(EY_ERR_INVALID, "ey_philox_normal: null argument");
   if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_philox_normal: bad dtype");
   if (C <= 0 || P <= 0) return EY_OK;
-  if (C > 65535) EY_FAIL(EY_ERR_INVALID, "ey_philox_normal: at most 65535 chains per call");
-  const dim3 grid((unsigned)((P + 255) / 256), (unsigned)C);
+  const int64_t nblk = (C * P + 255) / 256;
+  const dim3 grid((unsigned)(nblk < 65536 ? nblk : 65536));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EY_F32)
     hipLaunchKernelGGL(k_philox_normal<float>, grid, dim3(256), 0, s, (float*)out, C, P, seed, iter, chain_offset);
