@@ -2,12 +2,14 @@ import torch
 
 from pathlib import Path
 
+import eeyore_amd.stats as st
+
 from .chain import Chain
 
 
 class ChainList(Chain):
     """Monte Carlo chain stored as python lists, one entry per saved iteration (eeyore/chains/chain_list.py:12-141).
-    Summary statistics (mc_se, multi_ess, ...) live in eeyore_amd.stats when that row is built."""
+    Summary statistics delegate to eeyore_amd.stats (chain_list.py:69-102)."""
 
     def __init__(self, keys=['sample', 'target_val', 'accepted'], vals=None):
         self.reset(keys=keys, vals=vals)
@@ -63,6 +65,31 @@ class ChainList(Chain):
 
     def mean(self):
         return self.get_samples().mean(0)
+
+    def running_mean(self, idx):
+        return st.running_mean(self.get_param(idx))
+
+    def running_means(self):
+        return st.running_mean(self.get_samples(), dim=0)
+
+    def mc_se(self, mc_cov_mat=None, method='inse', adjust=False):
+        if mc_cov_mat is None:
+            return st.mc_se(self.get_samples(), method=method, adjust=adjust, rowvar=False)
+        return st.mc_se_from_cov(mc_cov_mat)
+
+    def mc_cov(self, method='inse', adjust=False):
+        return st.mc_cov(self.get_samples(), method=method, adjust=adjust, rowvar=False)
+
+    def mc_cor(self, mc_cov_mat=None, method='inse', adjust=False):
+        if mc_cov_mat is None:
+            return st.mc_cor(self.get_samples(), method=method, adjust=adjust, rowvar=False)
+        return st.cor_from_cov(mc_cov_mat)
+
+    def multi_ess(self, mc_cov_mat=None, method='inse', adjust=False):
+        return st.multi_ess(self.get_samples(), mc_cov_mat=mc_cov_mat, method=method, adjust=adjust)
+
+    def block_acceptance_rate(self):
+        return torch.stack(self.vals['accepted']).sum(axis=0) / self.num_samples()
 
     def acceptance_rate(self):
         """Proportion of accepted samples: sum(accepted) / num_samples (chain_list.py:94-96)."""

@@ -1,5 +1,7 @@
 import torch
 
+import eeyore_amd.stats as st
+
 from .chain_file import ChainFile
 
 
@@ -64,3 +66,50 @@ class ChainLists:
 
     def acceptance_summary(self, g=lambda x: sum(x) / len(x)):
         return g(self.acceptance())
+
+    def mc_se(self, mc_cov_mat=None, method='inse', adjust=False):
+        return torch.stack([
+            st.mc_se(self.get_chain(i, key='sample'), method=method, adjust=adjust, rowvar=False)
+            if mc_cov_mat is None else st.mc_se_from_cov(mc_cov_mat[i]) for i in range(self.num_chains())])
+
+    def mc_se_summary(self, g=lambda x: torch.mean(x, dim=0), mc_cov_mat=None, method='inse', adjust=False):
+        return g(self.mc_se(mc_cov_mat=mc_cov_mat, method=method, adjust=adjust))
+
+    def mc_cov(self, method='inse', adjust=False):
+        return torch.stack([st.mc_cov(self.get_chain(i, key='sample'), method=method, adjust=adjust, rowvar=False)
+                            for i in range(self.num_chains())])
+
+    def mc_cov_summary(self, g=lambda m: torch.mean(m, dim=0), method='inse', adjust=False):
+        return g(self.mc_cov(method=method, adjust=adjust))
+
+    def multi_ess(self, mc_cov_mat=None, method='inse', adjust=False):
+        return [st.multi_ess(self.get_chain(i, key='sample'), mc_cov_mat=None if mc_cov_mat is None else mc_cov_mat[i],
+                             method=method, adjust=adjust) for i in range(self.num_chains())]
+
+    def multi_ess_summary(self, g=lambda x: sum(x) / len(x), mc_cov_mat=None, method='inse', adjust=False):
+        return g(self.multi_ess(mc_cov_mat=mc_cov_mat, method=method, adjust=adjust))
+
+    def multi_rhat(self, mc_cov_mat=None, method='inse', adjust=False):
+        return st.multi_rhat(self.get_samples(), mc_cov_mat=mc_cov_mat, method=method, adjust=adjust)
+
+    def summary(self, keys=['multi_ess', 'multi_rhat'], g_mean_summary=lambda x: torch.mean(x, dim=0),
+                g_mc_se_summary=lambda x: torch.mean(x, dim=0), g_acceptance_summary=lambda x: sum(x) / len(x),
+                g_multi_ess_summary=lambda x: sum(x) / len(x), mc_cov_mat=None, method='inse', adjust=False):
+        """chain_lists.py:125-155."""
+        summaries = {}
+        if any(item in keys for item in ['mc_se', 'multi_ess', 'multi_rhat']):
+            if mc_cov_mat is None:
+                mc_cov_mat = self.mc_cov(method=method, adjust=adjust)
+        for key in keys:
+            if key == 'mean':
+                summaries[key] = self.mean_summary(g=g_mean_summary)
+            elif key == 'mc_se':
+                summaries[key] = self.mc_se_summary(g=g_mc_se_summary, mc_cov_mat=mc_cov_mat, method=method, adjust=adjust)
+            elif key == 'acceptance':
+                summaries[key] = self.acceptance_summary(g=g_acceptance_summary)
+            elif key == 'multi_ess':
+                summaries[key] = self.multi_ess_summary(g=g_multi_ess_summary, mc_cov_mat=mc_cov_mat, method=method,
+                                                        adjust=adjust)
+            elif key == 'multi_rhat':
+                summaries[key] = self.multi_rhat(mc_cov_mat=mc_cov_mat, method=method, adjust=adjust)[0]
+        return summaries

@@ -165,6 +165,9 @@ class Plan:
                                    L.ptr(out["accepted"]), L.ptr(out["log_rate"]), _stream(self.device)), "ey_mh_step")
         return out
 
+    def pt_swap_decide(self, ell_i, ell_j, t_i, t_j, u, dlogq=None):
+        return pt_swap_decide(ell_i, ell_j, t_i, t_j, u, dlogq=dlogq)
+
     def philox_normal(self, C, seed, it, chain_offset=0):
         out = self.empty(C, self.P)
         L.check(L.lib().ey_philox_normal(L.ptr(out), C, self.P, int(seed), int(it), int(chain_offset), _DT[self.dtype],

@@ -18,9 +18,11 @@ class HMC(SingleChainSerialSampler):
     reference's default argument is one ChainList shared by every sampler, hmc.py:11)."""
 
     def __init__(self, model, theta0=None, dataloader=None, data0=None, counter=None, step=0.1, num_steps=10,
-                 tuner=None, chain=None, rng=None, seed=0, chain_offset=0, recompute_initial_grad=False):
+                 tuner=None, chain=None, rng=None, seed=0, chain_offset=0, recompute_initial_grad=False,
+                 temperature=None):
         super(HMC, self).__init__(counter or DataCounter.from_dataloader(dataloader))
         self.model = model
+        self.temperature = temperature  # per-chain temperatures [C] (parallel tempering); None -> model.temperature
         self.dataloader = dataloader
         self.tuner = tuner
         self.recompute_initial_grad = recompute_initial_grad
@@ -66,7 +68,7 @@ class HMC(SingleChainSerialSampler):
         x, y = super().set_current(theta, data=data)
         self._theta = self._state_tensor(theta)
         plan = self.model._plan(x, y)
-        self._target, self._grad = plan.log_target_grad(self._theta, temp=self.model.temperature)
+        self._target, self._grad = plan.log_target_grad(self._theta, temp=self._temp())
         self._publish(torch.zeros(self.num_chains, dtype=torch.uint8))
         self.current['accepted'] = None
 
@@ -76,7 +78,8 @@ class HMC(SingleChainSerialSampler):
         single = position0.dim() == 1
         th = (position0[None] if single else position0).detach().to(self.model.device, self.model.dtype).contiguous().clone()
         p = (momentum0[None] if single else momentum0).detach().to(self.model.device, self.model.dtype).contiguous().clone()
-        t, g = plan.leapfrog(th, p, self.step, self.num_steps, temp=self.model.temperature)
+        step, step_vec = self._step_args()
+        t, g = plan.leapfrog(th, p, step, self.num_steps, step_vec=step_vec, temp=self._temp())
         return (th[0], p[0], t[0], g[0]) if single else (th, p, t, g)
 
     def init_step(self, theta):
@@ -100,7 +103,7 @@ class HMC(SingleChainSerialSampler):
         """hmc.py:126-170."""
         plan = self.model._plan(x, y)
         C, P = self._theta.shape
-        temp = self.model.temperature
+        temp = self._temp()
         if self.counter.num_batches != 1:
             # minibatching: the cached target/gradient belong to another batch (hmc.py:129-131)
             self._target, self._grad = plan.log_target_grad(self._theta, temp=temp)
@@ -109,7 +112,9 @@ class HMC(SingleChainSerialSampler):
             p0 = self._randn(C, P)
             u = self._rand(C)
         flags = L.EY_RECOMPUTE_INITIAL_GRAD if self.recompute_initial_grad else 0
-        out = plan.hmc_step(self._theta, self._target, self._grad, self.step, self.num_steps, p0=p0, u=u, temp=temp,
+        step, step_vec = self._step_args()
+        out = plan.hmc_step(self._theta, self._target, self._grad, step, self.num_steps, p0=p0, u=u, temp=temp,
+                            step_vec=step_vec,
                             seed=self.seed, it=self._iter, chain_offset=self.chain_offset, flags=flags)
         self._iter += 1
         self._publish(out['accepted'])

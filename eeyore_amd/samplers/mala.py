@@ -12,9 +12,10 @@ class MALA(SingleChainSerialSampler):
     a user-supplied ``kernel`` other than that has no HIP counterpart and is rejected."""
 
     def __init__(self, model, theta0=None, dataloader=None, data0=None, counter=None, step=0.1, kernel=None,
-                 chain=None, rng=None, seed=0, chain_offset=0):
+                 chain=None, rng=None, seed=0, chain_offset=0, temperature=None):
         super().__init__(counter or DataCounter.from_dataloader(dataloader))
         self.model = model
+        self.temperature = temperature
         self.dataloader = dataloader
         self.step = step
         if kernel is not None:
@@ -31,7 +32,7 @@ class MALA(SingleChainSerialSampler):
         x, y = super().set_current(theta, data=data)
         self._theta = self._state_tensor(theta)
         plan = self.model._plan(x, y)
-        self._target, self._grad = plan.log_target_grad(self._theta, temp=self.model.temperature)
+        self._target, self._grad = plan.log_target_grad(self._theta, temp=self._temp())
         self._publish(torch.zeros(self.num_chains, dtype=torch.uint8))
         self.current['accepted'] = None
 
@@ -52,14 +53,16 @@ class MALA(SingleChainSerialSampler):
         """mala.py:46-82."""
         plan = self.model._plan(x, y)
         C, P = self._theta.shape
-        temp = self.model.temperature
+        temp = self._temp()
+        step, step_vec = self._step_args()
         if self.counter.num_batches != 1:
             self._target, self._grad = plan.log_target_grad(self._theta, temp=temp)
         z = u = None
         if self.rng == 'torch':
             z = self._randn(C, P)
             u = self._rand(C)
-        out = plan.mala_step(self._theta, self._target, self._grad, self.step, z=z, u=u, temp=temp, seed=self.seed,
+        out = plan.mala_step(self._theta, self._target, self._grad, step, z=z, u=u, step_vec=step_vec, temp=temp,
+                             seed=self.seed,
                              it=self._iter, chain_offset=self.chain_offset)
         self._iter += 1
         self._publish(out['accepted'])

@@ -11,9 +11,10 @@ class MetropolisHastings(SingleChainSerialSampler):
     For a Normal random walk q(a|b) = q(b|a), so ``symmetric=False`` gives the same log-rate (:51-54)."""
 
     def __init__(self, model, theta0=None, dataloader=None, data0=None, counter=None, symmetric=True, kernel=None,
-                 chain=None, rng=None, seed=0, chain_offset=0):
+                 chain=None, rng=None, seed=0, chain_offset=0, temperature=None):
         super(MetropolisHastings, self).__init__(counter or DataCounter.from_dataloader(dataloader))
         self.model = model
+        self.temperature = temperature
         self.dataloader = dataloader
         self.symmetric = symmetric
         if kernel is not None and not isinstance(kernel, NormalKernel):
@@ -36,7 +37,7 @@ class MetropolisHastings(SingleChainSerialSampler):
         x, y = super().set_current(theta, data=data)
         self._theta = self._state_tensor(theta)
         plan = self.model._plan(x, y)
-        lik, prior = plan.log_target(self._theta, temp=self.model.temperature)
+        lik, prior = plan.log_target(self._theta, temp=self._temp())
         self._target = lik + prior
         self._publish(torch.zeros(self.num_chains, dtype=torch.uint8))
         self.current['accepted'] = None
@@ -48,7 +49,7 @@ class MetropolisHastings(SingleChainSerialSampler):
         """metropolis_hastings.py:41-73."""
         plan = self.model._plan(x, y)
         C, P = self._theta.shape
-        temp = self.model.temperature
+        temp = self._temp()
         if self.counter.num_batches != 1:
             lik, prior = plan.log_target(self._theta, temp=temp)
             self._target = lik + prior

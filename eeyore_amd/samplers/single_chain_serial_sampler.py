@@ -30,6 +30,17 @@ class SingleChainSerialSampler(SerialSampler):
         self.seed = int(seed)
         self.chain_offset = int(chain_offset)
 
+    def _temp(self):
+        """Temperature(s) of the chains: the sampler's own per-chain vector if given, else model.temperature."""
+        t = getattr(self, 'temperature', None)
+        return t if t is not None else self.model.temperature
+
+    def _step_args(self):
+        """(scalar step, per-chain step vector or None) for the C ABI."""
+        if isinstance(self.step, torch.Tensor) and self.step.dim() == 1:
+            return 0.0, self.step
+        return float(self.step), None
+
     def _state_tensor(self, theta):
         th = theta.detach().to(device=self.model.device, dtype=self.model.dtype)
         return (th if th.dim() == 2 else th[None]).contiguous().clone()

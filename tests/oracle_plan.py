@@ -100,7 +100,61 @@ class OraclePlan:
         return dict(accepted=torch.as_tensor(acc), log_rate=self._t(lr))
 
 
-def attach(model):
+def _groups(temp, C):
+    """Split a per-chain temperature vector into (value, index list) groups; None/scalar -> one group."""
+    if temp is None or not isinstance(temp, torch.Tensor) or temp.dim() == 0:
+        return [(None if temp is None else float(temp), list(range(C)))]
+    vals = temp.detach().cpu().numpy()
+    out = {}
+    for c, v in enumerate(vals):
+        out.setdefault(float(v), []).append(c)
+    return list(out.items())
+
+
+class VectorTempOraclePlan(OraclePlan):
+    """OraclePlan accepting a per-chain temperature vector (parallel tempering): chains are processed per
+    temperature group and the results scattered back in place."""
+
+    def log_target(self, theta, temp=None, prior_only=False):
+        lik, prior = self.empty(theta.shape[0]), self.empty(theta.shape[0])
+        for t, idx in _groups(temp, theta.shape[0]):
+            a, b = super().log_target(theta[idx].contiguous(), temp=t)
+            lik[idx], prior[idx] = a, b
+        return lik, prior
+
+    def log_target_grad(self, theta, temp=None):
+        tv, g = self.empty(theta.shape[0]), self.empty(*theta.shape)
+        for t, idx in _groups(temp, theta.shape[0]):
+            a, b = super().log_target_grad(theta[idx].contiguous(), temp=t)
+            tv[idx], g[idx] = a, b
+        return tv, g
+
+    def mala_step(self, theta, target, grad, step, z=None, u=None, step_vec=None, temp=None, **kw):
+        C = theta.shape[0]
+        out = dict(accepted=torch.zeros(C, dtype=torch.uint8), log_rate=self.empty(C))
+        for t, idx in _groups(temp, C):
+            th, tv, g = theta[idx].contiguous(), target[idx].contiguous(), grad[idx].contiguous()
+            st = float(step_vec[idx[0]]) if step_vec is not None else step
+            o = super().mala_step(th, tv, g, st, z=z[idx].contiguous(), u=u[idx].contiguous(), temp=t)
+            theta[idx], target[idx], grad[idx] = th, tv, g
+            out["accepted"][idx], out["log_rate"][idx] = o["accepted"], o["log_rate"]
+        return out
+
+    def pt_swap_decide(self, ell_i, ell_j, t_i, t_j, u, dlogq=None):
+        lr = (t_i - t_j) * (ell_j - ell_i)
+        if dlogq is not None:
+            lr = lr + dlogq
+        return (torch.log(u) < lr).to(torch.uint8), lr
+
+
+def attach(model, vector_temp=False):
+    if vector_temp:
+        object.__setattr__(model, "_hip_plan", VectorTempOraclePlan.for_model(model))
+        return model
+    return _attach(model)
+
+
+def _attach(model):
     """Give ``model`` (device='cpu') the oracle test double in place of a HIP plan."""
     object.__setattr__(model, "_hip_plan", OraclePlan.for_model(model))
     return model
