@@ -90,6 +90,8 @@ def main():
     from eeyore_amd.plan import Plan
 
     rank, world, local = init_from_env()
+    local = local % max(1, torch.cuda.device_count())  # only differs in a gloo rehearsal on a smaller box
+    gloo = world > 1 and dist.get_backend() == "gloo"
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
@@ -128,7 +130,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc_sum = torch.zeros((), dtype=torch.float64, device=dev)
     for _ in range(args.steps):
         step(it); it += 1
         stats.update(theta, out["accepted"])
@@ -139,7 +140,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
