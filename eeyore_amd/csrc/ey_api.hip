@@ -239,13 +239,15 @@ int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* 
 int ey_mala_step(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                  const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                  uint64_t chain_offset, uint32_t flags, void* accepted, void* log_rate, void* stream) {
-  (void)flags;
   int rc = check_ready(pl, C, "ey_mala_step");
   if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: null argument");
   if (!(step > 0.0) && !step_vec) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: step must be positive");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
+  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+    return ey_mfma32_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
+                          log_rate, (hipStream_t)stream);
   return ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
                          log_rate, (hipStream_t)stream);
 }
@@ -253,12 +255,14 @@ int ey_mala_step(ey_plan* pl, void* theta, void* target, void* grad, const void*
 int ey_mh_step(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
                void* accepted, void* log_rate, void* stream) {
-  (void)flags;
   int rc = check_ready(pl, C, "ey_mh_step");
   if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !target || !scale || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mh_step: null argument");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
+  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+    return ey_mfma32_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
+                        (hipStream_t)stream);
   return ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
                        (hipStream_t)stream);
 }

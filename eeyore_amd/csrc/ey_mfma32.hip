@@ -55,7 +55,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define I_B2 1312
 #define NPAR 1315
 
-enum { MODE_HMC = 0, MODE_GRAD = 1, MODE_LEAPFROG = 2 };
+enum { MODE_HMC = 0, MODE_GRAD = 1, MODE_LEAPFROG = 2, MODE_MALA = 3, MODE_MH = 4 };
 
 struct MfArgs {
   const float* xpack;  // [ntiles][288]
@@ -71,6 +71,8 @@ struct MfArgs {
   float* pio;          // LEAPFROG: [C,P] in/out
   const float* u;      // [C] or null
   float step;
+  float sqrt_step;     // MALA: sqrt(step) computed on the host in double (mala.py:39)
+  const float* scale;  // MH: proposal scale [P]
   const float* step_vec;
   int L;
   const float* temp;
@@ -143,6 +145,19 @@ __device__ __forceinline__ void for_each_pair(Vec& a, Vec& b, int c, int h, int 
   f(a.b0, b.b0, I_B0 + c, h == 0);
 #pragma unroll
   for (int o = 0; o < 3; ++o) f(a.b2[o], b.b2[o], I_B2 + o, lane == 0);
+}
+template <typename F>
+__device__ __forceinline__ void for_each3(Vec& a, Vec& b, Vec& d, int c, int h, int lane, F f) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) f(a.w1[r], b.w1[r], d.w1[r], I_W1 + (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + c, true);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f(a.w0[i], b.w0[i], d.w0[i], I_W0 + (4 * (c >> 2) + i) * 4 + (c & 3), h == 0);
+#pragma unroll
+  for (int o = 0; o < 3; ++o) f(a.w2[o], b.w2[o], d.w2[o], I_W2 + o * 32 + c, h == 0);
+  f(a.b1, b.b1, d.b1, I_B1 + c, h == 0);
+  f(a.b0, b.b0, d.b0, I_B0 + c, h == 0);
+#pragma unroll
+  for (int o = 0; o < 3; ++o) f(a.b2[o], b.b2[o], d.b2[o], I_B2 + o, lane == 0);
 }
 template <typename F>
 __device__ __forceinline__ void for_each2(Vec& a, Vec& b, F f) {
@@ -401,6 +416,54 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
     return;
   }
 
+  if (MODE == MODE_MALA || MODE == MODE_MH) {
+    // MALA.draw (eeyore/samplers/mala.py:46-82) / MetropolisHastings.draw (metropolis_hastings.py:41-73): one
+    // evaluation at the proposal; p holds the proposal, gp its gradient
+    const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_NORMAL);
+    const float* zin = A.p0 ? A.p0 + chain * NPAR : nullptr;
+    const float sc = A.step_vec ? sqrtf(eps) : A.sqrt_step;  // scale = sqrt(step), mala.py:39
+    float qf = 0.0f;
+    Vec gp;
+    if (MODE == MODE_MALA) for_each(g, c, h, lane, [&](float& v, int idx, bool) { v = grg[idx]; });
+    for_each3(th, g, p, c, h, lane, [&](float& tv, float& gv, float& pv, int idx, bool counts) {
+      const float zi = zin ? zin[idx] : ey_rng_normal<float>(rn, (uint32_t)idx);
+      if (MODE == MODE_MALA) {
+        const float loc = tv + 0.5f * eps * gv;  // kernel_mean, mala.py:35-36
+        pv = loc + sc * zi;
+        const float d = pv - loc;
+        if (counts) qf += d * d;
+      } else {
+        pv = tv + A.scale[idx] * zi;  // NormalKernel(theta, scale).sample()
+      }
+    });
+    write_images(lw, p, c, h);
+    const float tv = eval(A, xs, lw, p, gp, has_temp, temp, c, h, lane);
+    float log_rate = tv - A.target[chain];  // symmetric kernel: metropolis_hastings.py:50
+    if (MODE == MODE_MALA) {
+      float qb = 0.0f;
+      for_each3(th, gp, p, c, h, lane, [&](float& tv0, float& gpv, float& pv, int, bool counts) {
+        const float d = tv0 - (pv + 0.5f * eps * gpv);
+        if (counts) qb += d * d;
+      });
+      const float inv2v = 1.0f / (2.0f * sc * sc);
+      log_rate += (wsum(qf) - wsum(qb)) * inv2v;  // the -P log s - P/2 log 2pi terms cancel (mala.py:58-64)
+    }
+    const EyRng ru = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_UNIFORM);
+    const float u = A.u ? A.u[chain] : ey_rng_uniform<float>(ru);
+    const bool acc = __logf(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
+    if (acc) {
+      for_each(p, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) thg[idx] = v; });
+      if (MODE == MODE_MALA)
+        for_each(gp, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
+    }
+    if (lane == 0) {
+      if (acc) A.target[chain] = tv;
+      A.accepted[chain] = acc ? 1 : 0;
+      if (A.rate) A.rate[chain] = log_rate;
+    }
+    return;
+  }
+
   float t_cur = 0.0f, kin = 0.0f;
   if (MODE == MODE_HMC) {
     const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_NORMAL);
@@ -563,6 +626,28 @@ int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void
   a.recompute = (flags & EY_RECOMPUTE_INITIAL_GRAD) ? 1 : 0;
   a.accepted = (unsigned char*)accepted; a.rate = (float*)rate; a.hcur = (float*)hcur; a.hprop = (float*)hprop;
   return mf_launch<MODE_HMC>(pl, a, s);
+}
+
+int ey_mfma32_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                   const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                   uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
+  MfArgs a = {};
+  a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)grad;
+  a.p0 = (const float*)z; a.u = (const float*)u; a.step = (float)step; a.sqrt_step = (float)sqrt(step);
+  a.step_vec = (const float*)step_vec; a.temp = (const float*)temp; a.seed = seed; a.iter = iter;
+  a.chain_offset = chain_offset; a.accepted = (unsigned char*)accepted; a.rate = (float*)log_rate;
+  return mf_launch<MODE_MALA>(pl, a, s);
+}
+
+int ey_mfma32_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
+                 const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
+                 void* log_rate, hipStream_t s) {
+  MfArgs a = {};
+  a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)theta;  // grad unused by MH
+  a.p0 = (const float*)z; a.u = (const float*)u; a.scale = (const float*)scale; a.temp = (const float*)temp;
+  a.seed = seed; a.iter = iter; a.chain_offset = chain_offset; a.accepted = (unsigned char*)accepted;
+  a.rate = (float*)log_rate;
+  return mf_launch<MODE_MH>(pl, a, s);
 }
 
 int ey_mfma32_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,

@@ -477,6 +477,54 @@ def test_mfma32_philox_and_per_chain_step():
         np.testing.assert_allclose(tl[c].item(), to, rtol=2e-4, atol=2e-3)
 
 
+def test_mfma32_mala_and_mh_vs_oracle_and_generic():
+    from eeyore_amd import _lib as L
+    rec, pl = _cfg3_plan()
+    co = _oracle(rec, np.float32)
+    C, P = 96, pl.P
+    th0 = 0.2 * pl.philox_normal(C, seed=4, it=0)
+    t0, g0 = pl.log_target_grad(th0)
+    z, u = pl.philox_normal(C, seed=4, it=1), pl.philox_uniform(C, seed=4, it=1)
+    # ---- MALA
+    n_acc = []
+    for step in (2e-4, 4e-3):
+        a = [th0.clone(), t0.clone(), g0.clone()]
+        b = [th0.clone(), t0.clone(), g0.clone()]
+        oa = pl.mala_step(*a, step, z=z, u=u)
+        ob = pl.mala_step(*b, step, z=z, u=u, flags=L.EY_FORCE_GENERIC)
+        tho, tvo, go = th0.cpu().numpy().copy(), t0.cpu().numpy().copy(), g0.cpu().numpy().copy()
+        acc, lr = co.mala_draw(tho, tvo, go, z.cpu().numpy().copy(), u.cpu().numpy().copy(), step)
+        np.testing.assert_allclose(oa["log_rate"].cpu().numpy(), lr, rtol=2e-3, atol=2e-2)
+        np.testing.assert_allclose(oa["log_rate"].cpu().numpy(), ob["log_rate"].cpu().numpy(), rtol=2e-3, atol=2e-2)
+        decided = np.abs(np.log(u.cpu().numpy()) - lr) > 5e-2
+        np.testing.assert_array_equal(oa["accepted"].cpu().numpy()[decided], acc[decided])
+        same = oa["accepted"].cpu().numpy() == acc
+        np.testing.assert_allclose(a[0].cpu().numpy()[same], tho[same], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(a[2].cpu().numpy()[same], go[same], rtol=5e-3, atol=5e-3)
+        n_acc.append(int(acc.sum()))
+    assert n_acc[0] > 0 and n_acc[1] < C
+    step = 2e-4
+    a = [th0.clone(), t0.clone(), g0.clone()]
+    oa = pl.mala_step(*a, step, z=z, u=u)
+    # in-kernel Philox == streams passed in
+    c1 = [th0.clone(), t0.clone(), g0.clone()]
+    oc = pl.mala_step(*c1, step, seed=4, it=1)
+    assert torch.equal(oc["accepted"], oa["accepted"]) and torch.equal(c1[0], a[0])
+    # ---- MH
+    scale = torch.full((P,), 4e-3)
+    a = [th0.clone(), t0.clone()]
+    b = [th0.clone(), t0.clone()]
+    oa = pl.mh_step(*a, scale, z=z, u=u)
+    ob = pl.mh_step(*b, scale, z=z, u=u, flags=L.EY_FORCE_GENERIC)
+    tho, tvo = th0.cpu().numpy().copy(), t0.cpu().numpy().copy()
+    acc, lr = co.mh_draw(tho, tvo, z.cpu().numpy().copy(), u.cpu().numpy().copy(), 4e-3)
+    np.testing.assert_allclose(oa["log_rate"].cpu().numpy(), lr, rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(oa["log_rate"].cpu().numpy(), ob["log_rate"].cpu().numpy(), rtol=2e-3, atol=2e-2)
+    decided = np.abs(np.log(u.cpu().numpy()) - lr) > 5e-2
+    np.testing.assert_array_equal(oa["accepted"].cpu().numpy()[decided], acc[decided])
+    assert 0 < acc.sum() < C
+
+
 def test_chain_stats_hip_pass_equals_torch_formulas():
     from eeyore_amd.distributed import ChainStats
     for dt, C, P in ((torch.float32, 37, 1315), (torch.float64, 5, 9)):
