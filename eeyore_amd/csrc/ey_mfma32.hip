@@ -376,10 +376,10 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
   return lik + prior;
 }
 
-// WAVES chains per workgroup (4: two workgroups per CU; 8: one, waves w and w+4 share a SIMD).  PRIO raises the
-// issue priority of the second-dispatched half so the two waves of a SIMD leave lockstep (one in its matrix
-// phase while the other is in its vector/LDS phase).
-template <int MODE, int WAVES, int PRIO>
+// WAVES chains per workgroup (4: two workgroups per CU; 8: one).  Either way two waves share a SIMD: f32 MFMA runs
+// on the vector ALUs, so the partner wave hides latency (LDS round trips, MFMA result latency) rather than adding
+// throughput (tools/coexec_probe*.hip); raising one wave's priority with s_setprio changed nothing and was removed.
+template <int MODE, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   constexpr int MF_WAVES = WAVES, MF_THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -394,11 +394,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   float* lw = smem + xfloats + wave * WAVE_FLOATS;
   const int64_t chain = (int64_t)blockIdx.x * MF_WAVES + wave;
   if (chain >= A.C) return;  // whole wave; no further block-level synchronisation below
-  if (PRIO > 0 && WAVES == 8) {
-    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(PRIO);
-  } else if (PRIO > 0) {
-    if (__builtin_amdgcn_readfirstlane((int)(blockIdx.x & 1))) __builtin_amdgcn_s_setprio(PRIO);
-  }
   float* thg = A.theta + chain * NPAR;
   float* grg = A.grad + chain * NPAR;
   const bool has_temp = A.temp != nullptr;
@@ -540,7 +535,7 @@ static size_t mf_lds_bytes(int ntiles, int waves) {
   return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * WAVE_FLOATS);
 }
 
-// kernel variant: bit0 = 8 chains per workgroup, bits 1-2 = s_setprio level of the second half (tuning knob)
+// kernel variant (tuning knob): 1 = 8 chains per workgroup instead of 4
 static int g_variant = 0;
 extern "C" int ey_debug_set_variant(int v) {
   const int old = g_variant;
@@ -586,17 +581,17 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
   return EY_OK;
 }
 
-template <int MODE, int WAVES, int PRIO>
+template <int MODE, int WAVES>
 static int mf_launch_v(MfArgs& a, hipStream_t s) {
   const size_t bytes = mf_lds_bytes(a.ntiles, WAVES);
   static bool attr_done = false;
   if (!attr_done) {
-    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PRIO>),
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_bytes(MF_MAX_TILES, WAVES)));
     attr_done = true;
   }
   const unsigned grid = (unsigned)((a.C + WAVES - 1) / WAVES);
-  hipLaunchKernelGGL((k_mfma32<MODE, WAVES, PRIO>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+  hipLaunchKernelGGL((k_mfma32<MODE, WAVES>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
@@ -610,9 +605,9 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
   if constexpr (MODE == MODE_HMC) {
-    if (g_variant == 1) return mf_launch_v<MODE, 8, 0>(a, s);
+    if (g_variant == 1) return mf_launch_v<MODE, 8>(a, s);
   }
-  return mf_launch_v<MODE, 4, 0>(a, s);
+  return mf_launch_v<MODE, 4>(a, s);
 }
 
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,

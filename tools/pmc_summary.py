@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSV output: mean counter value per dispatch of the dominant kernel."""
+"""Summarise rocprofv3 --pmc CSV output: mean counter value per dispatch of the dominant kernel.
+usage: pmc_summary.py <dir> [kernel-substring] [json-out]"""
 import csv
 import glob
+import json
 import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-kern = sys.argv[2] if len(sys.argv) > 2 else "k_mfma32<0>"
+kern = sys.argv[2] if len(sys.argv) > 2 else "k_mfma32<0"
 acc = defaultdict(list)
 for f in glob.glob(f"{root}/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         if kern in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-print(f"kernel {kern}: mean per dispatch over {max((len(v) for v in acc.values()), default=0)} dispatches")
-for k in sorted(acc):
-    v = acc[k]
-    print(f"{k:28s} {sum(v) / len(v):18.1f}")
+n = max((len(v) for v in acc.values()), default=0)
+print(f"kernel {kern}: mean per dispatch over {n} dispatches")
+mean = {k: sum(v) / len(v) for k, v in acc.items()}
+for k in sorted(mean):
+    print(f"{k:28s} {mean[k]:18.1f}")
+if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
+    print(f"matrix-pipe busy fraction    {mean['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (mean['GRBM_GUI_ACTIVE'] / 8):18.3f}")
+if len(sys.argv) > 3 and "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+    json.dump({"kernel": "k_mfma32<0,4> (HMC trajectory)", "FETCH_SIZE_KB": mean["FETCH_SIZE"],
+               "WRITE_SIZE_KB": mean["WRITE_SIZE"], "dispatches": n,
+               "source": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes), 4096 chains x L=20 per dispatch"},
+              open(sys.argv[3], "w"), indent=1)
