@@ -1,5 +1,2 @@
-from .chain import Chain
-from .chain_file import ChainFile
-from .chain_list import ChainList
-from .chain_lists import ChainLists
+from .storage import Chain, ChainFile, ChainList, ChainLists
 from .chain_buffer import ChainBuffer

@@ -1,8 +1,6 @@
 import torch
 
-from .chain import Chain
-from .chain_list import ChainList
-from .chain_lists import ChainLists
+from .storage import Chain, ChainList, ChainLists
 
 
 class ChainBuffer(Chain):

@@ -1,5 +1,2 @@
-from .data_counter import DataCounter
-from .data_info import data_paths
-from .empty_dataset import EmptyXYDataset
-from .xydataset import XYDataset
+from .core import DataCounter, EmptyXYDataset, XYDataset, data_paths
 from . import synthetic

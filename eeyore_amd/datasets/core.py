@@ -1,0 +1,136 @@
+"""Datasets and iteration bookkeeping behind the reference's names (``XYDataset``, ``EmptyXYDataset``, ``DataCounter``).
+
+``DataCounter`` exposes the attributes the samplers and scripts read -- ``num_batches``, ``num_epochs``, ``num_iters``,
+``num_burnin_epochs``, ``num_burnin_iters``, ``idx`` (eeyore/datasets/data_counter.py:1-80) -- but derives the iteration
+counts from the epoch counts (or the other way round) through one helper each instead of storing them independently.
+``num_batches == 1`` is what selects the samplers' cached-target fast path (eeyore/samplers/hmc.py:129,150).
+"""
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch.nn.functional import one_hot
+from torch.utils.data import Dataset
+
+from eeyore_amd.constants import torch_to_np_types
+
+data_paths = {name: Path(__file__).resolve().parent.parent / 'data' / name for name in ('iris', 'xor')}
+
+
+def _ceil_div(a, b):
+    return -(-a // b)
+
+
+class DataCounter:
+    def __init__(self, batch_size, sample_size, num_epochs=None, num_burnin_epochs=None, num_batches=None,
+                 drop_last=False):
+        self.set_data_info(batch_size, sample_size, num_batches=num_batches, drop_last=drop_last)
+        self.set_epoch_info(num_epochs, num_burnin_epochs)
+        self.idx = 0
+
+    @classmethod
+    def from_dataloader(cls, dataloader, num_epochs=None, num_burnin_epochs=None):
+        return cls(dataloader.batch_size, len(dataloader.dataset), num_epochs=num_epochs,
+                   num_burnin_epochs=num_burnin_epochs, num_batches=len(dataloader))
+
+    # -- how many batches make an epoch
+    def set_num_batches(self, drop_last=False):
+        full, ragged = divmod(self.sample_size, self.batch_size)
+        self.num_batches = full + (1 if ragged and not drop_last else 0)
+
+    def set_data_info(self, batch_size, sample_size, num_batches=None, drop_last=False):
+        self.batch_size, self.sample_size = batch_size, sample_size
+        if num_batches is None:
+            self.set_num_batches(drop_last=drop_last)
+        else:
+            self.num_batches = num_batches
+
+    def set_data_info_from_dataloader(self, dataloader):
+        self.set_data_info(dataloader.batch_size, len(dataloader.dataset), num_batches=len(dataloader))
+
+    # -- epochs -> iterations
+    def _iters(self, epochs):
+        return None if epochs is None else epochs * self.num_batches
+
+    def set_num_iters(self, num_epochs):
+        self.num_epochs, self.num_iters = num_epochs, self._iters(num_epochs)
+
+    def set_num_burnin_iters(self, num_burnin_epochs):
+        self.num_burnin_epochs, self.num_burnin_iters = num_burnin_epochs, self._iters(num_burnin_epochs)
+
+    def set_epoch_info(self, num_epochs, num_burnin_epochs):
+        self.set_num_iters(num_epochs)
+        self.set_num_burnin_iters(num_burnin_epochs)
+
+    # -- iterations -> epochs (rounded up to whole epochs)
+    def _epochs(self, iters):
+        return None if iters is None else _ceil_div(iters, self.num_batches)
+
+    def set_num_epochs(self, num_iters):
+        self.num_iters, self.num_epochs = num_iters, self._epochs(num_iters)
+
+    def set_num_burnin_epochs(self, num_burnin_iters):
+        self.num_burnin_iters, self.num_burnin_epochs = num_burnin_iters, self._epochs(num_burnin_iters)
+
+    def set_iter_info(self, num_iters, num_burnin_iters):
+        # the reference passes `self` twice here and raises (data_counter.py:62-64); this is what it means to do
+        self.set_num_epochs(num_iters)
+        self.set_num_burnin_epochs(num_burnin_iters)
+
+    def reset(self):
+        self.idx = 0
+
+    def increment_idx(self, incr=1):
+        self.idx += incr
+
+
+def _read_csv(file, dtype, skiprows, usecols, ndmin, device, onehot):
+    """One CSV column block as a tensor; integer class labels become one-hot rows when asked
+    (eeyore/datasets/xydataset.py:28-45)."""
+    arr = np.loadtxt(file, dtype=torch_to_np_types[dtype], delimiter=',', skiprows=skiprows, usecols=usecols, ndmin=ndmin)
+    t = torch.from_numpy(arr).to(device=device)
+    return one_hot(t.long()).to(t.dtype) if onehot else t
+
+
+class XYDataset(Dataset):
+    """(x, y) tensors served row by row; with ``batch_size=len(dataset)`` a DataLoader yields the full batch."""
+
+    def __init__(self, x, y):
+        self.set_data(x, y)
+
+    def set_data(self, x, y):
+        self.x, self.y = x, y
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, idx):
+        return self.x[idx], self.y[idx]
+
+    def __repr__(self):
+        return 'XYDataset'
+
+    @classmethod
+    def from_file(cls, path=Path.cwd(), xfile='x.csv', yfile='y.csv', xskiprows=1, yskiprows=1, xusecols=None,
+                  yusecols=None, xndmin=2, yndmin=2, dtype=torch.float64, device='cpu', xonehot=False, yonehot=False):
+        folder = Path(path)
+        return cls(_read_csv(folder / xfile, dtype, xskiprows, xusecols, xndmin, device, xonehot),
+                   _read_csv(folder / yfile, dtype, yskiprows, yusecols, yndmin, device, yonehot))
+
+    @classmethod
+    def from_eeyore(cls, data_name, xndmin=2, yndmin=2, dtype=torch.float64, device='cpu', xonehot=False,
+                    yonehot=False):
+        """The bundled data sets ('iris', 'xor')."""
+        return cls.from_file(path=data_paths[data_name], xndmin=xndmin, yndmin=yndmin, dtype=dtype, device=device,
+                             xonehot=xonehot, yonehot=yonehot)
+
+
+class EmptyXYDataset(XYDataset):
+    """A dataset with one empty row, for targets that ignore the data (eeyore/datasets/empty_dataset.py:5-7)."""
+
+    def __init__(self, dtype=torch.float64, device='cpu'):
+        empty = torch.empty(1, 0, dtype=dtype, device=device)
+        super().__init__(empty, empty.clone())
+
+    def __repr__(self):
+        return 'Empty XYDataset'

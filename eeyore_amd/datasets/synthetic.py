@@ -2,7 +2,7 @@
 import numpy as np
 import torch
 
-from .xydataset import XYDataset
+from .core import XYDataset
 
 _IRIS_MEANS = np.array([[5.0, 3.4, 1.5, 0.2], [5.9, 2.8, 4.3, 1.3], [6.6, 3.0, 5.6, 2.0]])
 _IRIS_SDS = np.array([[0.35, 0.38, 0.17, 0.10], [0.52, 0.31, 0.47, 0.20], [0.64, 0.32, 0.55, 0.27]])

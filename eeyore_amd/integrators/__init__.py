@@ -1,2 +1,1 @@
-from .integrator import Integrator
-from .mcintegrator import MCIntegrator
+from .mcintegrator import Integrator, MCIntegrator

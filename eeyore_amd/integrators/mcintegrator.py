@@ -1,34 +1,60 @@
+"""Monte Carlo integration over stored samples behind the reference's names ``Integrator`` / ``MCIntegrator``
+(eeyore/integrators/mcintegrator.py:10-63): the running mean of f(sample, x, y) with NaN integrands dropped and
+counted.  ``integrate_batched`` evaluates all samples in one chain-batched call into the HIP library."""
 import torch
+from torch.utils.data import DataLoader
 
-from .integrator import Integrator
+
+class Integrator:
+    def integrate(self, *args, **kwargs):
+        raise NotImplementedError
 
 
 class MCIntegrator(Integrator):
-    """Monte Carlo integration of f(sample, x, y) over stored samples with NaN integrands dropped and counted
-    (eeyore/integrators/mcintegrator.py:10-30).  ``samples`` may be a list of [P] tensors or a [S, P] tensor; when
-    ``f`` accepts a batch the whole integral is one call into the HIP library (``integrate_batched``)."""
-
     def __init__(self, f=None, samples=None):
-        super().__init__()
         self.f = f
         self.samples = samples
 
     def integrate(self, x, y):
-        integral = 0.
-        num_kept_samples = 1
-        num_dropped_samples = 0
+        """(estimate, number of dropped samples); the estimate is the mean of the non-NaN integrands, accumulated as
+        a running mean in sample order."""
+        kept, dropped, mean = 0, 0, 0.
         for sample in self.samples:
-            integrand = self.f(sample, x, y)
-            if torch.isnan(integrand):
-                num_dropped_samples = num_dropped_samples + 1
-            else:
-                integral = ((num_kept_samples - 1) * integral + integrand) / num_kept_samples
-                num_kept_samples = num_kept_samples + 1
-        return integral, num_dropped_samples
+            value = self.f(sample, x, y)
+            if torch.isnan(value):
+                dropped += 1
+                continue
+            kept += 1
+            mean = mean + (value - mean) / kept
+        return mean, dropped
 
     def integrate_batched(self, x, y):
-        """Same estimate with all samples evaluated in one chain-batched call: mean of the non-NaN integrands."""
-        samples = self.samples if isinstance(self.samples, torch.Tensor) else torch.stack(list(self.samples))
-        vals = self.f(samples, x, y)
-        keep = ~torch.isnan(vals)
-        return vals[keep].mean(), int((~keep).sum().item())
+        """The same estimate with ``f`` called once on the [S, P] stack of samples (``f`` must accept a batch, as the
+        models' ``set_params_and_lik`` does)."""
+        stack = self.samples if torch.is_tensor(self.samples) else torch.stack(list(self.samples))
+        values = self.f(stack, x, y)
+        ok = ~torch.isnan(values)
+        return values[ok].mean(), int((~ok).sum().item())
+
+    def integrate_from_dataset(self, dataset, num_points, shuffle=True, dtype=torch.float64, device='cpu',
+                               verbose=False, verbose_step=1):
+        """Integrate at ``num_points`` data points drawn one at a time from ``dataset`` (items (x, y) or (x, y, index)).
+        Returns (integrals, indices, numbers of dropped samples)."""
+        integrals = torch.empty(num_points, dtype=dtype, device=device)
+        indices = torch.full((num_points,), -1, dtype=torch.int64, device=device)
+        dropped = torch.empty(num_points, dtype=torch.int64, device=device)
+        done = 0
+        while done < num_points:
+            for item in DataLoader(dataset, batch_size=1, shuffle=shuffle):
+                if done == num_points:
+                    break
+                x, y = item[0], item[1]
+                value, n_dropped = self.integrate(x, y)
+                integrals[done] = float(value)
+                if len(item) > 2:
+                    indices[done] = int(item[2])
+                dropped[done] = n_dropped
+                done += 1
+                if verbose and done % verbose_step == 0:
+                    print(f"Iteration {done} out of {num_points}")
+        return integrals, indices, dropped

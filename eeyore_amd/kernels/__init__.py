@@ -1,3 +1,1 @@
-from .kernel import Kernel
-from .normalized_kernel import NormalizedKernel
-from .normal_kernel import NormalKernel
+from .proposal import Kernel, NormalizedKernel, NormalKernel

@@ -1,60 +1,59 @@
+"""``mlp.Hyperparameters`` and ``mlp.MLP`` with the reference's constructors (eeyore/models/mlp.py:9-50).
+
+The layers are ``nn.Linear`` modules so that ``parameters()`` order, ``state_dict`` and ``forward`` are what scripts
+written for the reference expect; the sampler hot path never runs them -- it goes through ``_plan(x, y)``, the C-ABI plan
+that carries this model's dims / bias flags / activation codes / likelihood code, its prior and the data.
+"""
 import torch
 import torch.nn as nn
 from torch.distributions import Normal
 
 from eeyore_amd.plan import Plan
 
-from .bayesian_model import BayesianModel
+from .base import BayesianModel
 
-_ACT_CODES = {None: 0, torch.sigmoid: 1, torch.tanh: 2, torch.relu: 3}
+# activation -> kernel code (include/eeyore_amd.h: enum ey_act)
+_ACTIVATIONS = (
+    (0, (None,), ()),
+    (1, (torch.sigmoid, torch.nn.functional.sigmoid), (nn.Sigmoid,)),
+    (2, (torch.tanh, torch.nn.functional.tanh), (nn.Tanh,)),
+    (3, (torch.relu, torch.nn.functional.relu), (nn.ReLU,)),
+)
 
 
-def activation_code(a):
-    if a in _ACT_CODES:
-        return _ACT_CODES[a]
-    if isinstance(a, nn.Sigmoid) or a is torch.nn.functional.sigmoid:
-        return 1
-    if isinstance(a, nn.Tanh) or a is torch.nn.functional.tanh:
-        return 2
-    if isinstance(a, nn.ReLU) or a is torch.nn.functional.relu:
-        return 3
-    raise ValueError(f"activation {a!r} has no HIP kernel (supported: None, torch.sigmoid, torch.tanh, torch.relu)")
+def activation_code(fn):
+    for code, callables, module_types in _ACTIVATIONS:
+        if any(fn is c for c in callables) or (module_types and isinstance(fn, module_types)):
+            return code
+    raise ValueError(f"activation {fn!r} has no HIP kernel (supported: None, torch.sigmoid, torch.tanh, torch.relu)")
 
 
 class Hyperparameters:
-    """eeyore/models/mlp.py:9-19."""
+    """Layer widths, per-layer bias flags and activations; at least one hidden layer and one activation per layer,
+    otherwise ``ValueError`` (mlp.py:15-19)."""
 
     def __init__(self, dims=[1, 2, 1], bias=None, activations=None):
+        n_layers = len(dims) - 1
         self.dims = dims
-        self.bias = bias if bias is not None else (len(dims) - 1) * [True]
-        self.activations = activations if activations is not None else (len(dims) - 1) * [torch.sigmoid]
-
-        if len(self.dims) < 3:
-            raise ValueError
-
-        if (len(self.dims) != len(self.activations)+1):
-            raise ValueError
-
-        if (len(self.bias) != len(self.activations)):
+        self.bias = n_layers * [True] if bias is None else bias
+        self.activations = n_layers * [torch.sigmoid] if activations is None else activations
+        if len(self.dims) < 3 or len(self.activations) != n_layers or len(self.bias) != n_layers:
             raise ValueError
 
 
 class MLP(BayesianModel):
-    """eeyore/models/mlp.py:21-50.  Same constructor; ``device`` must name an MI355X for the hot path."""
-
     def __init__(self, loss, temperature=None, prior=None, hparams=Hyperparameters(), savefile=None,
                  dtype=torch.float64, device='cpu'):
         super().__init__(loss, temperature=temperature, dtype=dtype, device=device)
         self.hp = hparams
         self.fc_layers = self.set_fc_layers()
         self._hip_plan = None
-        self._prior = None
-        self._prior_dirty = True
         self.prior = prior or self.default_prior()
         if savefile:
             self.load_state_dict(torch.load(savefile), strict=False)
 
-    # `model.prior = Normal(...)` after construction is the idiom of the reference examples
+    # `model.prior = Normal(...)` after construction is the idiom of the reference's examples: a setter lets the plan
+    # notice the change and re-upload the prior
     @property
     def prior(self):
         return self._prior
@@ -62,49 +61,45 @@ class MLP(BayesianModel):
     @prior.setter
     def prior(self, value):
         object.__setattr__(self, "_prior", value)
-        object.__setattr__(self, "_prior_dirty", True)
+        object.__setattr__(self, "_prior_uploaded", False)
 
     def default_prior(self):
-        return Normal(
-            torch.zeros(self.num_params(), dtype=self.dtype, device=self.device),
-            torch.ones(self.num_params(), dtype=self.dtype, device=self.device)
-        )
+        """N(0, 1) on every parameter (mlp.py:31-35)."""
+        shape = (self.num_params(),)
+        return Normal(torch.zeros(shape, dtype=self.dtype, device=self.device),
+                      torch.ones(shape, dtype=self.dtype, device=self.device))
 
     def set_fc_layers(self):
-        fc = []
-        for i in range(len(self.hp.dims)-1):
-            fc.append(nn.Linear(
-                self.hp.dims[i], self.hp.dims[i+1], bias=self.hp.bias[i]
-            ).to(dtype=self.dtype, device=self.device))
-        return nn.ModuleList(fc)
+        widths = self.hp.dims
+        return nn.ModuleList(
+            nn.Linear(widths[k], widths[k + 1], bias=self.hp.bias[k]).to(dtype=self.dtype, device=self.device)
+            for k in range(len(widths) - 1))
 
     def forward(self, x):
-        for fc, activation in zip(self.fc_layers, self.hp.activations):
-            x = fc(x)
-            if activation is not None:
-                x = activation(x)
+        for layer, act in zip(self.fc_layers, self.hp.activations):
+            x = layer(x)
+            x = x if act is None else act(x)
         return x
 
     def num_hidden_layers(self):
-        return len(self.hp.dims)-2
+        return len(self.hp.dims) - 2
 
-    # ---- HIP plan plumbing
     def _plan(self, x, y):
-        """The C-ABI plan of this model with (x, y) and the current prior attached."""
-        if self._hip_plan is None:
+        """This model's C-ABI plan with the current prior and, when given, the (x, y) batch attached."""
+        plan = self._hip_plan
+        if plan is None:
             code = getattr(self.loss, "code", None)
             if code is None:
                 raise ValueError("loss must be one of eeyore_amd.constants.loss_functions (the kernels implement "
                                  "BCE-sum on probabilities and CE-sum on logits)")
             acts = [activation_code(a) for a in self.hp.activations]
-            object.__setattr__(self, "_hip_plan", Plan(self.hp.dims, self.hp.bias, acts, code, self.dtype, self.device))
-        plan = self._hip_plan
-        if self._prior_dirty:
-            pr = self._prior
-            if not isinstance(pr, Normal):
+            plan = Plan(self.hp.dims, self.hp.bias, acts, code, self.dtype, self.device)
+            object.__setattr__(self, "_hip_plan", plan)
+        if not self._prior_uploaded:
+            if not isinstance(self._prior, Normal):
                 raise ValueError("only an elementwise torch.distributions.Normal prior has a HIP kernel")
-            plan.set_prior(pr.loc, pr.scale)
-            object.__setattr__(self, "_prior_dirty", False)
+            plan.set_prior(self._prior.loc, self._prior.scale)
+            object.__setattr__(self, "_prior_uploaded", True)
         if x is not None:
             plan.set_data(x, y)
         return plan

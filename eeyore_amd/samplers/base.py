@@ -1,0 +1,212 @@
+"""Sampler base classes behind the reference's names (``Sampler``, ``SerialSampler``, ``SingleChainSerialSampler``).
+
+Semantics kept from the reference: ``run`` walks epochs x batches, calls ``draw(x, y, savestate)`` once per batch with
+``savestate`` true from the first post-burn-in iteration on, and advances the counter
+(eeyore/samplers/serial_sampler.py:35-52); ``benchmark`` repeats whole runs until enough succeed and writes
+``runNN/{<key>.csv, runtime.txt}``, ``runNN/errors/errorNN.txt`` and ``run_counts.txt`` (:54-126).
+What differs is what one ``draw`` advances: the reference holds one chain, a sampler here holds C chains as device
+tensors ``[C, ...]`` and advances all of them with one fused HIP launch.  ``theta0`` of shape [P] keeps the reference's
+single-chain view of the state (``current['sample']`` is [P], ``accepted`` a python int, the chain a ``ChainList``).
+"""
+from datetime import timedelta
+from pathlib import Path
+from timeit import default_timer as timer
+
+import torch
+
+from eeyore_amd.chains import ChainBuffer, ChainList
+from eeyore_amd.datasets import DataCounter
+
+
+class Sampler:
+    def draw(self, x, y, savestate=False):
+        raise NotImplementedError
+
+    def run(self, num_epochs, num_burnin_epochs, verbose=False, verbose_step=100):
+        raise NotImplementedError
+
+
+class _Progress:
+    """Times blocks of ``every`` iterations and prints one line per block when verbose."""
+
+    def __init__(self, enabled, every, counter):
+        self.enabled, self.every, self.counter = enabled, every, counter
+        wi, we = len(str(counter.num_iters)), len(str(counter.num_epochs))
+        self.template = (f'Iteration {{:{wi}}} out of {counter.num_iters} '
+                         f'(in epoch {{:{we}}} out of {counter.num_epochs}), duration {{}}')
+        self.t0 = None
+
+    def before(self, idx):
+        if self.enabled and idx % self.every == 0:
+            self.t0 = timer()
+
+    def after(self, idx, epoch):
+        if self.enabled and (idx + 1) % self.every == 0:
+            print(self.template.format(idx + 1, epoch + 1, timedelta(seconds=timer() - self.t0)))
+
+
+def _write_line(path, text):
+    with open(path, 'w') as handle:
+        handle.write(f"{text}\n")
+
+
+class SerialSampler(Sampler):
+    def __init__(self, counter):
+        self.counter = counter
+
+    def run(self, num_epochs, num_burnin_epochs, verbose=False, verbose_step=100):
+        counter = self.counter
+        counter.set_epoch_info(num_epochs, num_burnin_epochs)
+        progress = _Progress(verbose, verbose_step, counter)
+        for epoch in range(counter.num_epochs):
+            for x, y in self.dataloader:
+                progress.before(counter.idx)
+                self.draw(x, y, savestate=counter.idx >= counter.num_burnin_iters)
+                progress.after(counter.idx, epoch)
+                counter.increment_idx()
+
+    def benchmark(self, num_chains, num_epochs, num_burnin_epochs, path, init=None, check_conditions=None,
+                  verbose=False, verbose_step=100, print_acceptance=False, print_runtime=True):
+        root = Path(path)
+        width = len(str(num_chains))
+        done = rejected = crashed = 0
+        while done < num_chains:
+            if verbose:
+                print(f'Simulating chain {done + 1:{width}} out of {num_chains} ({rejected:{width}} failures due to not '
+                      f'meeting conditions and {crashed:{width}} failures due to runtime error)...')
+            run_dir = root / f'run{str(done + 1).zfill(width)}'
+            run_dir.mkdir(parents=True, exist_ok=True)
+            try:
+                start = self.get_model().prior.sample() if init is None else init[done]
+                self.reset(start.clone().detach(), data=None, reset_counter=True, reset_chain=True)
+                t0 = timer()
+                self.run(num_epochs=num_epochs, num_burnin_epochs=num_burnin_epochs, verbose=verbose,
+                         verbose_step=verbose_step)
+                runtime = timer() - t0
+            except RuntimeError as error:
+                err_dir = run_dir / 'errors'
+                err_dir.mkdir(parents=True, exist_ok=True)
+                _write_line(err_dir / f'error{str(crashed + 1).zfill(num_chains)}.txt', error)
+                crashed += 1
+                if verbose:
+                    print('Failed due to runtime error\n')
+                continue
+            accepted_run = check_conditions is None or check_conditions(self.get_chain(), runtime)
+            if accepted_run:
+                self.get_chain().to_chainfile(path=run_dir, mode='w')
+                _write_line(run_dir / 'runtime.txt', runtime)
+                done += 1
+            else:
+                rejected += 1
+            if verbose:
+                notes = ['Succeeded' if accepted_run else 'Failed due to not meeting conditions']
+                if print_acceptance:
+                    notes.append(f'acceptance rate = {self.get_chain().acceptance_rate()}')
+                if print_runtime:
+                    notes.append(f'runtime = {timedelta(seconds=runtime)}')
+                print('; '.join(notes) + '\n')
+        with open(root / 'run_counts.txt', 'w') as handle:
+            handle.write(f"{done},succesful\n{rejected},unmet_conditions\n{crashed},runtime_errors\n")
+
+
+class SingleChainSerialSampler(SerialSampler):
+    """State handling shared by HMC / MALA / MetropolisHastings."""
+
+    def __init__(self, counter):
+        super().__init__(counter=counter)
+
+    def _configure(self, model, dataloader, theta0, chain, rng, seed, chain_offset, temperature):
+        self.model = model
+        self.dataloader = dataloader
+        self.temperature = temperature  # per-chain temperatures [C] (tempering); None -> model.temperature
+        self.batched = theta0 is not None and theta0.dim() == 2
+        self.num_chains = theta0.shape[0] if self.batched else 1
+        self.chain = chain if chain is not None else (ChainBuffer() if self.batched else ChainList())
+        self.rng = rng or ('philox' if self.batched else 'torch')
+        if self.rng not in ('philox', 'torch'):
+            raise ValueError("rng must be 'philox' (in-kernel counter-based stream) or 'torch' (global torch generator)")
+        self.seed, self.chain_offset = int(seed), int(chain_offset)
+        self._iter = 0
+
+    # -- pieces the concrete samplers use
+    def _temp(self):
+        return self.temperature if self.temperature is not None else self.model.temperature
+
+    def _step_args(self):
+        """(scalar step, per-chain step vector or None) as the C ABI takes them."""
+        if torch.is_tensor(self.step) and self.step.dim() == 1:
+            return 0.0, self.step
+        return float(self.step), None
+
+    def _state_tensor(self, theta):
+        th = theta.detach().to(device=self.model.device, dtype=self.model.dtype)
+        return (th if th.dim() == 2 else th.unsqueeze(0)).contiguous().clone()
+
+    def _expose(self, t):
+        return t if self.batched else t[0]
+
+    def _draw_randoms(self, C, P):
+        """(normals [C, P], uniforms [C]) from the global torch generator, or (None, None) for the in-kernel stream."""
+        if self.rng != 'torch':
+            return None, None
+        return self._randn(C, P), self._rand(C)
+
+    def _randn(self, C, P):
+        kw = dict(dtype=self.model.dtype, device=self.model.device)
+        return torch.randn(C, P, **kw) if self.batched else torch.randn(P, **kw).unsqueeze(0)
+
+    def _rand(self, C):
+        return torch.rand(C if self.batched else 1, dtype=self.model.dtype, device=self.model.device)
+
+    def _publish(self, accepted):
+        cur = self.current
+        cur['sample'] = self._expose(self._theta)
+        cur['target_val'] = self._expose(self._target)
+        if 'grad_val' in cur and hasattr(self, '_grad'):
+            cur['grad_val'] = self._expose(self._grad)
+        cur['accepted'] = accepted if self.batched else int(accepted[0].item())
+        if not self.batched:
+            self.model.set_params(cur['sample'])  # the model's parameters follow the chain (hmc.py:149-155)
+
+    def _finish_draw(self, out, savestate):
+        self._iter += 1
+        self._publish(out['accepted'])
+        self.last = out
+        if savestate:
+            self.chain.detach_and_update(self.current)
+
+    # -- the reference's surface (single_chain_serial_sampler.py:10-41)
+    def get_model(self):
+        return self.model
+
+    def get_chain(self):
+        return self.chain
+
+    def get_param(self, idx):
+        return self.get_chain().get_param(idx)
+
+    def get_sample(self, idx):
+        return self.get_chain().get_sample(idx)
+
+    def set_current(self, theta, data=None):
+        self.current = dict.fromkeys(self.keys)
+        self.current['sample'] = theta
+        x, y = data or next(iter(self.dataloader))
+        return x, y
+
+    def set_all(self, theta, data=None):
+        self.set_current(theta, data=data)
+
+    def reset(self, theta, data=None, reset_counter=True, reset_chain=True):
+        if reset_counter:
+            self.counter.reset()
+        if reset_chain:
+            self.chain.reset(keys=self.chain.vals.keys())
+        self.set_all(theta, data=data)
+
+    def to_chainfile(self, path=Path.cwd(), mode='a'):
+        self.chain.to_chainfile(path=path, mode=mode)
+
+
+def default_counter(counter, dataloader):
+    return counter or DataCounter.from_dataloader(dataloader)

@@ -1,7 +1,6 @@
 import torch
 
-from .single_chain_serial_sampler import SingleChainSerialSampler
-from eeyore_amd.datasets import DataCounter
+from .base import SingleChainSerialSampler, default_counter
 from eeyore_amd.tuners import HMCDATuner
 from eeyore_amd import _lib as L
 
@@ -13,41 +12,34 @@ class HMC(SingleChainSerialSampler):
     update for every chain, fused in a HIP kernel.  Extensions over the reference: ``theta0`` may be [C, P]
     (C chains advanced together); ``rng`` ('torch' = momentum/uniform from the global torch generator as
     hmc.py:134,148 do, 'philox' = in-kernel counter-based stream keyed by (seed, chain, iteration));
-    ``recompute_initial_grad=True`` re-evaluates the gradient at the start of each trajectory exactly as
-    hmc.py:104 does (same values, one more evaluation).  ``chain`` defaults to a fresh chain per sampler (the
-    reference's default argument is one ChainList shared by every sampler, hmc.py:11)."""
+    ``recompute_initial_grad=True`` re-evaluates the gradient at the start of each trajectory exactly as hmc.py:104
+    does (same values, one more evaluation); ``step`` may be a [C] tensor and ``temperature`` a [C] tensor.
+    ``chain`` defaults to a fresh chain per sampler (the reference's default argument is one ChainList shared by
+    every sampler, hmc.py:11)."""
+
+    keys = ['sample', 'target_val', 'grad_val', 'momentum', 'hamiltonian', 'accepted']
 
     def __init__(self, model, theta0=None, dataloader=None, data0=None, counter=None, step=0.1, num_steps=10,
                  tuner=None, chain=None, rng=None, seed=0, chain_offset=0, recompute_initial_grad=False,
                  temperature=None):
-        super(HMC, self).__init__(counter or DataCounter.from_dataloader(dataloader))
-        self.model = model
-        self.temperature = temperature  # per-chain temperatures [C] (parallel tempering); None -> model.temperature
-        self.dataloader = dataloader
+        super().__init__(default_counter(counter, dataloader))
+        self._configure(model, dataloader, theta0, chain, rng, seed, chain_offset, temperature)
         self.tuner = tuner
         self.recompute_initial_grad = recompute_initial_grad
-        self._init_mode(theta0, chain, rng, seed, chain_offset)
-        self.keys = ['sample', 'target_val', 'grad_val', 'momentum', 'hamiltonian', 'accepted']
-        self._iter = 0
-
-        if self.tuner is not None:
-            if isinstance(self.tuner, HMCDATuner):
-                if self.tuner.e0 is None:
-                    self.init_step(theta0.clone().detach())
-                    if self.tuner.eub is not None:
-                        self.step = min(self.tuner.eub, self.step)
-                    self.tuner.set_m(self.step)
-                else:
-                    self.step = self.tuner.e0
-                self.num_steps = self.tuner.num_steps(self.step)
-        else:
-            self.step = step
-            self.num_steps = num_steps
-
+        self.step, self.num_steps = step, num_steps
+        if isinstance(tuner, HMCDATuner):
+            if tuner.e0 is None:  # find a starting step size, then let dual averaging shrink towards it (hmc.py:17-27)
+                self.init_step(theta0.clone().detach())
+                if tuner.eub is not None:
+                    self.step = min(tuner.eub, self.step)
+                tuner.set_m(self.step)
+            else:
+                self.step = tuner.e0
+            self.num_steps = tuner.num_steps(self.step)
         if theta0 is not None:
             self.set_current(theta0.clone().detach(), data=data0)
 
-    # ---- reference helpers (hmc.py:84-98)
+    # -- energies (hmc.py:84-98); momentum may carry a leading chain axis
     def potential_energy(self, position, x, y):
         return -self.model.log_target(position, x, y)
 
@@ -56,7 +48,7 @@ class HMC(SingleChainSerialSampler):
         return -target_val, -grad_val
 
     def log_proposal(self, momentum):
-        return - 0.5 * torch.sum(momentum**2, dim=-1)
+        return -0.5 * momentum.pow(2).sum(-1)
 
     def kinetic_energy(self, momentum):
         return -self.log_proposal(momentum)
@@ -67,66 +59,57 @@ class HMC(SingleChainSerialSampler):
     def set_current(self, theta, data=None):
         x, y = super().set_current(theta, data=data)
         self._theta = self._state_tensor(theta)
-        plan = self.model._plan(x, y)
-        self._target, self._grad = plan.log_target_grad(self._theta, temp=self._temp())
+        self._target, self._grad = self.model._plan(x, y).log_target_grad(self._theta, temp=self._temp())
         self._publish(torch.zeros(self.num_chains, dtype=torch.uint8))
         self.current['accepted'] = None
 
     def leapfrog(self, position0, momentum0, x, y):
-        """hmc.py:100-124: (position_L, momentum_L, target_val, grad_val); L+1 gradient evaluations."""
-        plan = self.model._plan(x, y)
+        """(position_L, momentum_L, target_val, grad_val) as hmc.py:100-124: L steps, L+1 gradient evaluations, the
+        final momentum negated."""
         single = position0.dim() == 1
-        th = (position0[None] if single else position0).detach().to(self.model.device, self.model.dtype).contiguous().clone()
-        p = (momentum0[None] if single else momentum0).detach().to(self.model.device, self.model.dtype).contiguous().clone()
+        th, p = self._state_tensor(position0), self._state_tensor(momentum0)
         step, step_vec = self._step_args()
-        t, g = plan.leapfrog(th, p, step, self.num_steps, step_vec=step_vec, temp=self._temp())
+        t, g = self.model._plan(x, y).leapfrog(th, p, step, self.num_steps, step_vec=step_vec, temp=self._temp())
         return (th[0], p[0], t[0], g[0]) if single else (th, p, t, g)
 
     def init_step(self, theta):
-        """Step-size doubling/halving heuristic for the dual-averaging tuner (hmc.py:38-77), chain 0 only."""
+        """Double or halve a unit step until the one-step acceptance ratio crosses 1/2 (hmc.py:38-77; chain 0)."""
         x, y = next(iter(self.dataloader))
-        self.step = 1.
-        self.num_steps = 1
-        th = theta if theta.dim() == 1 else theta[0]
-        th = th.to(self.model.device, self.model.dtype)
-        mom = torch.randn(self.model.num_params(), dtype=self.model.dtype, device=self.model.device)
-        cur_h = self.hamiltonian(-self.model.log_target(th.clone(), x, y), mom)
-        _, pm, pt, _ = self.leapfrog(th, mom, x, y)
-        ratio = torch.exp(cur_h - self.hamiltonian(-pt, pm))
-        a = 2 * (ratio > 0.5) - 1
-        while torch.pow(ratio, a) > torch.pow(2., -a):
-            self.step = (torch.pow(2., a) * self.step).item()
-            _, pm, pt, _ = self.leapfrog(th, mom, x, y)
-            ratio = torch.exp(cur_h - self.hamiltonian(-pt, pm))
+        self.step, self.num_steps = 1., 1
+        th = (theta if theta.dim() == 1 else theta[0]).to(self.model.device, self.model.dtype)
+        momentum = torch.randn(self.model.num_params(), dtype=self.model.dtype, device=self.model.device)
+        h_start = self.hamiltonian(-self.model.log_target(th.clone(), x, y), momentum)
+
+        def ratio_after_one_step():
+            _, p_new, t_new, _ = self.leapfrog(th, momentum, x, y)
+            return torch.exp(h_start - self.hamiltonian(-t_new, p_new))
+
+        ratio = ratio_after_one_step()
+        direction = 1 if ratio > 0.5 else -1
+        while ratio ** direction > 2. ** (-direction):
+            self.step = self.step * 2. ** direction
+            ratio = ratio_after_one_step()
 
     def draw(self, x, y, savestate=False):
-        """hmc.py:126-170."""
+        """One HMC iteration of every chain (hmc.py:126-170)."""
         plan = self.model._plan(x, y)
-        C, P = self._theta.shape
         temp = self._temp()
         if self.counter.num_batches != 1:
             # minibatching: the cached target/gradient belong to another batch (hmc.py:129-131)
             self._target, self._grad = plan.log_target_grad(self._theta, temp=temp)
-        p0 = u = None
-        if self.rng == 'torch':
-            p0 = self._randn(C, P)
-            u = self._rand(C)
-        flags = L.EY_RECOMPUTE_INITIAL_GRAD if self.recompute_initial_grad else 0
+        p0, u = self._draw_randoms(*self._theta.shape)
         step, step_vec = self._step_args()
         out = plan.hmc_step(self._theta, self._target, self._grad, step, self.num_steps, p0=p0, u=u, temp=temp,
-                            step_vec=step_vec,
-                            seed=self.seed, it=self._iter, chain_offset=self.chain_offset, flags=flags)
-        self._iter += 1
+                            step_vec=step_vec, seed=self.seed, it=self._iter, chain_offset=self.chain_offset,
+                            flags=L.EY_RECOMPUTE_INITIAL_GRAD if self.recompute_initial_grad else 0)
         self._publish(out['accepted'])
         self.current['momentum'] = None if p0 is None else self._expose(p0)
         self.current['hamiltonian'] = self._expose(out['h_cur'])
+        if isinstance(self.tuner, HMCDATuner) and self.counter.idx < self.counter.num_burnin_iters:
+            last_burnin = self.counter.idx == self.counter.num_burnin_iters - 1
+            self.step, self.num_steps = self.tuner.tune(out['rate'].mean().item(), self.counter.idx,
+                                                        return_e=not last_burnin)
+        self._iter += 1
         self.last = out
-
-        if self.tuner is not None and isinstance(self.tuner, HMCDATuner):
-            if self.counter.idx < self.counter.num_burnin_iters:
-                rate = out['rate'].mean().item()
-                self.step, self.num_steps = self.tuner.tune(
-                    rate, self.counter.idx, return_e=self.counter.idx != self.counter.num_burnin_iters - 1)
-
         if savestate:
             self.chain.detach_and_update(self.current)

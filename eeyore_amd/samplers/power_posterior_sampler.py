@@ -8,7 +8,7 @@ from pathlib import Path
 from .hmc import HMC
 from .mala import MALA
 from .metropolis_hastings import MetropolisHastings
-from .serial_sampler import SerialSampler
+from .base import SerialSampler
 from eeyore_amd.chains import ChainBuffer
 from eeyore_amd.datasets import DataCounter
 

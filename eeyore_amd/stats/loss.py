@@ -1,8 +1,11 @@
+import torch
+
+
 def binary_cross_entropy(x, y, reduction='mean'):
-    """Naive BCE on probabilities (eeyore/stats/loss.py:1-11): NaN once a probability is exactly 0 or 1."""
-    loss = -(x.log() * y + (1 - x).log() * (1 - y))
-    if reduction == 'mean':
-        return loss.mean()
-    if reduction == 'sum':
-        return loss.sum()
-    raise ValueError
+    """Binary cross entropy on probabilities with the plain logarithms of the reference (eeyore/stats/loss.py:1-11): a
+    probability of exactly 0 or 1 gives -inf * 0 = NaN rather than a clamped value, which the samplers then reject."""
+    per_element = torch.log(x) * y + torch.log(1 - x) * (1 - y)
+    reducers = {'mean': torch.mean, 'sum': torch.sum}
+    if reduction not in reducers:
+        raise ValueError
+    return -reducers[reduction](per_element)

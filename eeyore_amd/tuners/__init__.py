@@ -1,2 +1,1 @@
-from .tuner import Tuner
-from .hmcda_tuner import HMCDATuner
+from .dual_averaging import HMCDATuner, Tuner
