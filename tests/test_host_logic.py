@@ -246,3 +246,38 @@ def test_hmc_leapfrog_surface():
     np.testing.assert_allclose(th.numpy(), rec["thetaL"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(p.numpy(), rec["pL"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(t.item(), rec["target"], rtol=1e-10)
+
+
+def test_dual_averaging_tuner_matches_reference_recurrence():
+    """HMCDATuner against a direct evaluation of Hoffman & Gelman's algorithm 5 recurrences with the reference's
+    constants (eeyore/tuners/hmcda_tuner.py:43-59)."""
+    from eeyore_amd.tuners import HMCDATuner
+    tuner = HMCDATuner(l=1.0, e0=0.2, d=0.65, eub=0.5)
+    barh, logbare, m = 0.0, 0.0, np.log(10 * 0.2)
+    rates = [0.9, 0.2, 0.75, 1.0, 0.4, 0.66, 0.1]
+    for idx, rate in enumerate(rates):
+        it = idx + 1
+        d_w, e_w = 1 / (it + 10), 1 / it ** 0.75
+        barh = (1 - d_w) * barh + d_w * (0.65 - rate)
+        loge = min(m - np.sqrt(it) * barh / 0.05, np.log(0.5))
+        logbare = e_w * loge + (1 - e_w) * logbare
+        last = idx == len(rates) - 1
+        e, n = tuner.tune(rate, idx, return_e=not last)
+        want = np.exp(logbare if last else loge)
+        assert e == pytest.approx(want, rel=1e-12) and n == max(1, round(1.0 / want))
+    assert HMCDATuner(l=2.0).m is None and HMCDATuner(l=2.0).num_steps(0.3) == 7
+
+
+def test_hmc_with_dual_averaging_tuner_adapts_step():
+    from eeyore_amd.tuners import HMCDATuner
+    rec = groups(load("g4_hmc_traces.npz"))["mlp2321"]
+    m = _model_from(rec)
+    ds = XYDataset(torch.tensor(rec["x"]), torch.tensor(rec["y"]))
+    loader = DataLoader(ds, batch_size=len(ds), shuffle=False)
+    torch.manual_seed(4)
+    s = HMC(m, theta0=torch.tensor(rec["theta0"]), dataloader=loader, tuner=HMCDATuner(l=2.0, eub=2.0), chain=ChainList())
+    assert 0 < s.step <= 2.0 and s.num_steps == max(1, round(2.0 / s.step))  # init_step heuristic (hmc.py:38-77)
+    first = s.step
+    s.run(num_epochs=60, num_burnin_epochs=40)
+    assert s.step != first and s.num_steps == max(1, round(2.0 / s.step))
+    assert len(s.get_chain()) == 20 and 0.2 < s.get_chain().acceptance_rate() <= 1.0
