@@ -540,3 +540,88 @@ def test_chain_stats_hip_pass_equals_torch_formulas():
         a, b = hip.summary(), ref.summary()
         np.testing.assert_allclose(a["rhat"].cpu().numpy(), b["rhat"].numpy(), rtol=1e-12)
         assert abs(a["acceptance"] - b["acceptance"]) < 1e-15
+
+
+# --------------------------------------------------------------------------------------------- generic kernel breadth
+@pytest.mark.parametrize("dims,acts,bias,lik,tag", [
+    ([3, 5, 4, 2], [2, 3, 0], [1, 1, 1], 1, "f64"),      # tanh, relu, linear + CE
+    ([3, 5, 4, 2], [2, 3, 0], [1, 0, 1], 1, "f32"),      # a layer without bias
+    ([2, 4, 1], [3, 1], [0, 1], 0, "f64"),               # relu hidden, sigmoid output + BCE
+    ([6, 7, 3, 5, 2], [1, 2, 1, 1], [1, 1, 1, 1], 0, "f64"),  # four layers, two BCE outputs
+    ([4, 3], [0], [1], 1, "f64"),                        # single layer (multinomial logistic regression)
+    ([5, 70, 3], [1, 0], [1, 1], 1, "f64"),              # wider than one wave (70 hidden units)
+])
+def test_generic_kernels_on_other_architectures(dims, acts, bias, lik, tag):
+    from eeyore_amd.plan import Plan
+    npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    rng = np.random.default_rng(sum(dims))
+    N = 77
+    x = rng.standard_normal((N, dims[0]))
+    if lik == 1:
+        y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)]
+    else:
+        y = (rng.random((N, dims[-1])) < 0.5).astype(np.float64)
+    P = sum((dims[l] + bias[l]) * dims[l + 1] for l in range(len(dims) - 1))
+    mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+    pl = Plan(dims, bias, acts, lik, dt, DEV)
+    assert pl.P == P
+    pl.set_data(_t(x, dt), _t(y, dt))
+    pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+    co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, bias=bias, nthreads=4)
+    C = 9
+    th0 = (0.4 * rng.standard_normal((C, P))).astype(npdt)
+    tol = 1e-9 if tag == "f64" else 2e-4
+    t, g = pl.log_target_grad(_t(th0, dt))
+    lk, pr = pl.log_target(_t(th0, dt))
+    for c in range(C):
+        to, go, lo, po = co.log_target_grad(th0[c])
+        np.testing.assert_allclose(t[c].item(), to, rtol=tol, atol=tol * 10)
+        np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=tol * 10, atol=tol * 10)
+        np.testing.assert_allclose([lk[c].item(), pr[c].item()], [lo, po], rtol=tol, atol=tol * 10)
+    # one HMC, MALA and MH draw with recorded randomness
+    tv0 = t.cpu().numpy().astype(npdt); g0 = g.cpu().numpy().astype(npdt)
+    p0 = rng.standard_normal((C, P)).astype(npdt); u = rng.random(C).astype(npdt)
+    th, tv, gg = _t(th0, dt).clone(), t.clone(), g.clone()
+    out = pl.hmc_step(th, tv, gg, 0.03, 5, p0=_t(p0, dt), u=_t(u, dt))
+    tho, tvo, go = th0.copy(), tv0.copy(), g0.copy()
+    acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, 0.03, 5)
+    rate = np.minimum(np.exp(np.minimum(hc - hp, 0)), 1)
+    decided = np.abs(u - rate) > (1e-8 if tag == "f64" else 5e-3)
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+    np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=tol * 10, atol=tol * 100)
+    th, tv, gg = _t(th0, dt).clone(), t.clone(), g.clone()
+    out = pl.mala_step(th, tv, gg, 0.01, z=_t(p0, dt), u=_t(u, dt))
+    tho, tvo, go = th0.copy(), tv0.copy(), g0.copy()
+    acc, lr = co.mala_draw(tho, tvo, go, p0, u, 0.01)
+    np.testing.assert_allclose(out["log_rate"].cpu().numpy(), lr, rtol=tol * 100, atol=tol * 1000)
+    th, tv = _t(th0, dt).clone(), t.clone()
+    out = pl.mh_step(th, tv, torch.full((P,), 0.05, dtype=dt), z=_t(p0, dt), u=_t(u, dt))
+    tho, tvo = th0.copy(), tv0.copy()
+    acc, lr = co.mh_draw(tho, tvo, p0, u, 0.05)
+    np.testing.assert_allclose(out["log_rate"].cpu().numpy(), lr, rtol=tol * 100, atol=tol * 1000)
+
+
+def test_model_surface_predictive_posterior_and_batched_integrator():
+    """BayesianModel.predictive_posterior (bayesian_model.py:58-61) through MCIntegrator, and its batched form."""
+    from torch.distributions import Normal
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import XYDataset
+    from eeyore_amd.integrators import MCIntegrator
+    from eeyore_amd.models import mlp
+    iris = XYDataset.from_eeyore('iris', yndmin=1, yonehot=True, dtype=torch.float64, device=DEV)
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'],
+                    hparams=mlp.Hyperparameters(dims=[4, 3, 3], activations=[torch.sigmoid, None]), device=DEV)
+    P = model.num_params()
+    samples = 0.3 * torch.randn(20, P, dtype=torch.float64, device=DEV)
+    x, y = iris.x[:1], iris.y[:1]
+    est, dropped = model.predictive_posterior(list(samples.unbind(0)), x, y)
+    integ = MCIntegrator(f=lambda s, x, y: model.set_params_and_lik(s, x, y), samples=samples)
+    est_b, dropped_b = integ.integrate_batched(x, y)
+    assert dropped == 0 and dropped_b == 0
+    np.testing.assert_allclose(est.item(), est_b.item(), rtol=1e-12)
+    # independent check with the torch forward of the same module
+    probs = []
+    for s in samples:
+        model.set_params(s.clone())
+        probs.append(torch.softmax(model(x), 1)[0, int(y.argmax())].item())
+    np.testing.assert_allclose(est.item(), np.mean(probs), rtol=1e-10)
