@@ -62,6 +62,8 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
   pl->d_x = pl->d_y = pl->d_mu = pl->d_inv_var = nullptr;
   pl->d_labels = nullptr;
   pl->d_xpack = nullptr;
+  pl->d_work = nullptr;
+  pl->work_bytes = 0;
   hipDeviceProp_t prop;
   EY_HIP(hipGetDeviceProperties(&prop, device_id));
   pl->n_cu = prop.multiProcessorCount;
@@ -80,6 +82,7 @@ int ey_plan_destroy(ey_plan* pl) {
   (void)hipFree(pl->d_inv_var);
   (void)hipFree(pl->d_labels);
   (void)hipFree(pl->d_xpack);
+  ey_large_free(pl);
   delete pl;
   return EY_OK;
 }
@@ -90,7 +93,15 @@ int ey_plan_num_params(const ey_plan* pl, int64_t* P) {
   return EY_OK;
 }
 
-const char* ey_plan_kernel(const ey_plan* pl) { return (pl && pl->mfma32_ok) ? "mfma32" : "generic"; }
+int g_ey_force_large = 0;  // ey_debug_set_variant bit 4: route f32 plans through the batched-GEMM path (tests)
+static bool use_large(const ey_plan* pl) {
+  return pl->dtype == EY_F32 && (ey_large_needed(pl) || (g_ey_force_large && !pl->mfma32_ok));
+}
+const char* ey_plan_kernel(const ey_plan* pl) {
+  if (!pl) return "generic";
+  if (pl->mfma32_ok) return "mfma32";
+  return use_large(pl) ? "bgemm" : "generic";
+}
 
 static size_t esize(const ey_plan* pl) { return pl->dtype == EY_F32 ? 4 : 8; }
 
@@ -193,6 +204,7 @@ int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, v
   if (!theta) EY_FAIL(EY_ERR_INVALID, "ey_log_target: null theta");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
+  if (use_large(pl)) return ey_large_log_target(pl, theta, temp, C, log_lik, log_prior, nullptr, nullptr, (hipStream_t)stream);
   return ey_generic_log_target(pl, theta, temp, C, log_lik, log_prior, nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -204,6 +216,7 @@ int ey_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
   if (pl->mfma32_ok) return ey_mfma32_log_target_grad(pl, theta, temp, C, target, grad, (hipStream_t)stream);
+  if (use_large(pl)) return ey_large_log_target(pl, theta, temp, C, nullptr, nullptr, target, grad, (hipStream_t)stream);
   return ey_generic_log_target(pl, theta, temp, C, nullptr, nullptr, target, grad, (hipStream_t)stream);
 }
 
@@ -220,6 +233,9 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
   if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                          accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
+  if (use_large(pl))
+    return ey_large_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+                        accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
   return ey_generic_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                         accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
 }

@@ -60,6 +60,9 @@ struct ey_plan {
   bool mfma32_ok;
   void* d_xpack;
   int n_cu;
+  // layerwise batched-GEMM path for models whose parameters do not fit LDS (ey_large.hip): workspace it owns
+  void* d_work;
+  size_t work_bytes;
 };
 
 // generic kernels (ey_generic.hip)
@@ -77,6 +80,16 @@ int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const vo
 int ey_generic_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                   const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
                   void* log_rate, hipStream_t s);
+
+// layerwise batched-GEMM kernels for large models, f32 (ey_large.hip)
+bool ey_large_needed(const ey_plan* pl);   // true when the generic kernels cannot hold the model in LDS
+int ey_large_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+                        void* target, void* grad, hipStream_t s);
+int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                 const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                 uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                 hipStream_t s);
+void ey_large_free(ey_plan* pl);
 
 // mfma32 kernels (ey_mfma32.hip)
 bool ey_mfma32_supports(const ey_plan* pl);

@@ -1,0 +1,431 @@
+// Layerwise batched-GEMM path (f32) for models whose parameters do not fit the LDS of a CU -- BASELINE config 5's
+// MLP(784-128-10) has P = 101 770 (407 KB per chain per state vector).  theta, momentum, gradient and all activations
+// live in HBM; every layer of every chain is one tile job of a chain-batched GEMM on the f32 matrix cores:
+//
+//   forward    H_{l+1}[c] = act(H_l[c] W_l[c]^T + b_l[c])            M = rows, N = d_{l+1}, K = d_l   (H_0 = X, shared)
+//   dW         dW_l[c]    = delta_{l+1}[c]^T H_l[c]                  M = d_{l+1}, N = d_l, K = rows
+//   dH         delta_l[c] = (delta_{l+1}[c] W_l[c]) * act'(H_l[c])   M = rows, N = d_l, K = d_{l+1}
+//
+// with the same semantics as the other kernel families (MLP.forward eeyore/models/mlp.py:45-50, losses
+// eeyore/constants/constants.py:15-18, log_target eeyore/models/bayesian_model.py:30-56, gradient
+// eeyore/models/log_target_model.py:15-23, HMC eeyore/samplers/hmc.py:100-156).  One GEMM kernel serves the three
+// products through element strides; tiles are 64x64x16 through LDS, v_mfma_f32_32x32x2_f32 per 32x32 wave tile.
+#include <vector>
+
+#include "ey_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 64
+#define BN 64
+#define BK 16
+#define LDT (BM + 1)
+
+struct BG {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  long sAm, sAk, sBk, sBn, sCm, sCn;  // element strides
+  long bA, bB, bC;                    // batch strides (0 = shared operand)
+  const float* bias; long bBias;      // bias along n, per batch (nullable)
+  int act;                            // activation applied to acc + bias
+  const float* Hm; long sHm, sHn, bH; // if set: C = acc * act'(Hm[m][n]) with act_h
+  int act_h;
+};
+
+__device__ __forceinline__ float l_act(int code, float g) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-g));
+    case EY_ACT_TANH: return tanhf(g);
+    case EY_ACT_RELU: return g > 0.0f ? g : 0.0f;
+    default: return g;
+  }
+}
+__device__ __forceinline__ float l_dact(int code, float h) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return h * (1.0f - h);
+    case EY_ACT_TANH: return 1.0f - h * h;
+    case EY_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
+    default: return 1.0f;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bgemm(BG g) {
+  __shared__ float As[BK * LDT];
+  __shared__ float Bs[BK * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const long b = blockIdx.z;
+  const float* A = g.A + b * g.bA;
+  const float* B = g.B + b * g.bB;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    // stage the two operand tiles as [k][m] / [k][n]; the element -> thread map follows the contiguous stride
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int mm, kk;
+      if (a_kfast) { mm = e >> 4; kk = e & 15; } else { mm = e & 63; kk = e >> 6; }
+      const int gm = m0 + mm, gk = k0 + kk;
+      As[kk * LDT + mm] = (gm < g.M && gk < g.K) ? A[gm * g.sAm + gk * g.sAk] : 0.0f;
+      int nn, kb;
+      if (b_kfast) { nn = e >> 4; kb = e & 15; } else { nn = e & 63; kb = e >> 6; }
+      const int gn = n0 + nn, gkb = k0 + kb;
+      Bs[kb * LDT + nn] = (gn < g.N && gkb < g.K) ? B[gkb * g.sBk + gn * g.sBn] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(2 * s + h) * LDT + wm * 32 + c], Bs[(2 * s + h) * LDT + wn * 32 + c],
+                                                 acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + c;
+  if (n >= g.N) return;
+  float* C = g.C + b * g.bC;
+  const float bias = g.bias ? g.bias[b * g.bBias + n] : 0.0f;
+  const float* Hm = g.Hm ? g.Hm + b * g.bH : nullptr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+    if (m < g.M) {
+      float v = acc[r];
+      if (Hm) v *= l_dact(g.act_h, Hm[m * g.sHm + n * g.sHn]);
+      else v = l_act(g.act, v + bias);
+      C[m * g.sCm + n * g.sCn] = v;
+    }
+  }
+}
+
+static int bgemm(const BG& g, int batch, hipStream_t s) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
+  hipLaunchKernelGGL(k_bgemm, grid, dim3(256), 0, s, g);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
+}
+
+// log-likelihood of every chain and the output delta = dL/dh_K * act'(h_K); one block per chain
+__global__ void __launch_bounds__(256) k_loss(const float* __restrict__ out, float* __restrict__ delta,
+                                              const float* __restrict__ y, const int* __restrict__ labels, int N, int dK,
+                                              int lik_code, int act_last, float* __restrict__ lik_o) {
+  __shared__ float red[4];
+  const long c = blockIdx.x;
+  const float* o = out + c * (long)N * dK;
+  float* d = delta + c * (long)N * dK;
+  float lik = 0.0f;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    if (lik_code == EY_LIK_BCE_SUM) {
+      for (int j = 0; j < dK; ++j) {
+        const float p = o[n * dK + j], yy = y[n * dK + j];
+        lik += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
+        d[n * dK + j] = (yy / p - (1.0f - yy) / (1.0f - p)) * l_dact(act_last, p);
+      }
+    } else {
+      const int lab = labels[n];
+      float mx = o[n * dK];
+      for (int j = 1; j < dK; ++j) mx = fmaxf(mx, o[n * dK + j]);
+      float ssum = 0.0f;
+      for (int j = 0; j < dK; ++j) ssum += __expf(o[n * dK + j] - mx);
+      lik += o[n * dK + lab] - (mx + __logf(ssum));
+      const float rs = 1.0f / ssum;
+      for (int j = 0; j < dK; ++j) {
+        const float v = o[n * dK + j];
+        d[n * dK + j] = ((j == lab ? 1.0f : 0.0f) - __expf(v - mx) * rs) * l_dact(act_last, v);
+      }
+    }
+  }
+  lik = block_sum(lik, red);
+  if (threadIdx.x == 0) lik_o[c] = lik;
+}
+
+// db[c][j] = sum_n delta[c][n][j]
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ delta, int N, int d, float* __restrict__ grad,
+                                                long gstride) {
+  const long c = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= d) return;
+  const float* dl = delta + c * (long)N * d;
+  float a = 0.0f;
+  for (int n = 0; n < N; ++n) a += dl[n * d + j];
+  grad[c * gstride + j] = a;
+}
+
+// prior value and gradient, temperature, log-target; one block per chain
+__global__ void __launch_bounds__(256) k_prior(const float* __restrict__ theta, const float* __restrict__ mu,
+                                               const float* __restrict__ iv, float prior_const, int P,
+                                               const float* __restrict__ temp, const float* __restrict__ lik,
+                                               float* __restrict__ grad, float* lik_o, float* prior_o, float* target_o) {
+  __shared__ float red[4];
+  const long c = blockIdx.x;
+  const float t = temp ? temp[c] : 1.0f;
+  float q = 0.0f;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    const float d = theta[c * P + i] - mu[i];
+    q += d * d * iv[i];
+    if (grad) grad[c * P + i] = (grad[c * P + i] - d * iv[i]) * t;
+  }
+  q = block_sum(q, red);
+  if (threadIdx.x == 0) {
+    const float pr = (prior_const - 0.5f * q) * t, lk = lik[c] * t;
+    if (lik_o) lik_o[c] = lk;
+    if (prior_o) prior_o[c] = pr;
+    if (target_o) target_o[c] = lk + pr;
+  }
+}
+
+// ---- HMC elementwise pieces (one block per chain)
+__global__ void __launch_bounds__(256) k_hmc_begin(const float* theta, const float* grad, const float* p0, float* thp,
+                                                   float* p, float* gp, int P, uint64_t seed, uint64_t iter,
+                                                   uint64_t chain_offset, const float* target, float* hcur) {
+  __shared__ float red[4];
+  const long c = blockIdx.x;
+  const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
+  float kin = 0.0f;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    const long k = c * P + i;
+    const float pv = p0 ? p0[k] : ey_rng_normal<float>(rn, (uint32_t)i);  // hmc.py:134
+    p[k] = pv;
+    kin += pv * pv;
+    thp[k] = theta[k];
+    gp[k] = grad[k];
+  }
+  kin = block_sum(kin, red);
+  if (threadIdx.x == 0) hcur[c] = -target[c] + 0.5f * kin;  // hmc.py:91-98,137
+}
+
+// p += wp * eps * g ; then theta += wt * eps * p   (either weight may be 0)
+__global__ void __launch_bounds__(256) k_leap(float* thp, float* p, const float* gp, int P, float step,
+                                              const float* step_vec, float wp, float wt) {
+  const long c = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float eps = step_vec ? step_vec[c] : step;
+  const long k = c * P + i;
+  float pv = p[k];
+  if (wp != 0.0f) { pv = pv + wp * eps * gp[k]; p[k] = pv; }
+  if (wt != 0.0f) thp[k] = thp[k] + wt * eps * pv;
+}
+
+__global__ void __launch_bounds__(256) k_hmc_end(float* theta, float* grad, float* target, const float* thp,
+                                                 const float* p, const float* gp, const float* tprop, const float* hcur,
+                                                 const float* u_in, int P, uint64_t seed, uint64_t iter,
+                                                 uint64_t chain_offset, unsigned char* accepted, float* rate_o,
+                                                 float* hcur_o, float* hprop_o) {
+  __shared__ float red[4];
+  __shared__ int s_acc;
+  const long c = blockIdx.x;
+  float kin = 0.0f;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) kin += p[c * P + i] * p[c * P + i];
+  kin = block_sum(kin, red);
+  if (threadIdx.x == 0) {
+    const float h_prop = -tprop[c] + 0.5f * kin;
+    float rate = __expf(hcur[c] - h_prop);  // hmc.py:143-146
+    if (rate > 1.0f) rate = 1.0f;
+    const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
+    const float u = u_in ? u_in[c] : ey_rng_uniform<float>(ru);
+    const int acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
+    s_acc = acc;
+    accepted[c] = (unsigned char)acc;
+    if (acc) target[c] = tprop[c];
+    if (rate_o) rate_o[c] = rate;
+    if (hcur_o) hcur_o[c] = hcur[c];
+    if (hprop_o) hprop_o[c] = h_prop;
+  }
+  __syncthreads();
+  if (s_acc) {
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+      theta[c * P + i] = thp[c * P + i];
+      grad[c * P + i] = gp[c * P + i];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- host
+bool ey_large_needed(const ey_plan* pl) {
+  const EyModel& m = pl->m;
+  if (pl->dtype != EY_F32) return false;
+  const size_t Ppad = (m.P + 3) & ~3;
+  const size_t generic_bytes = 4 * (3 * Ppad + (size_t)m.hrows * 65 + 2 * (size_t)m.dmax * 65);
+  return generic_bytes > 160 * 1024;
+}
+
+void ey_large_free(ey_plan* pl) {
+  (void)hipFree(pl->d_work);
+  pl->d_work = nullptr;
+  pl->work_bytes = 0;
+}
+
+static int ensure_work(ey_plan* pl, size_t bytes) {
+  if (pl->work_bytes >= bytes) return EY_OK;
+  EY_HIP(hipDeviceSynchronize());
+  (void)hipFree(pl->d_work);
+  pl->d_work = nullptr;
+  pl->work_bytes = 0;
+  EY_HIP(hipMalloc(&pl->d_work, bytes));
+  pl->work_bytes = bytes;
+  return EY_OK;
+}
+
+static size_t act_floats_per_chain(const EyModel& m) {
+  size_t f = 0;
+  for (int l = 1; l <= m.nl; ++l) f += (size_t)m.N * m.dims[l];
+  return f;
+}
+
+// value (+ gradient when grad != null) for chains [0, C) of theta, using `ws` (2 * C * act_floats floats) as scratch
+static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C, float* lik_o, float* prior_o,
+                      float* target_o, float* grad, float* ws, float* lik_tmp, hipStream_t s) {
+  const EyModel& m = pl->m;
+  const int K = m.nl, N = m.N, P = m.P;
+  const size_t af = act_floats_per_chain(m);
+  float* Hbase = ws;
+  float* Dbase = ws + (size_t)C * af;
+  std::vector<float*> H(K + 1), D(K + 1);
+  {
+    size_t off = 0;
+    for (int l = 1; l <= K; ++l) {
+      H[l] = Hbase + off * C;
+      D[l] = Dbase + off * C;
+      off += (size_t)N * m.dims[l];
+    }
+  }
+  int rc;
+  // forward
+  for (int l = 0; l < K; ++l) {
+    BG g = {};
+    g.A = l == 0 ? (const float*)m.x : H[l];
+    g.B = theta + m.woff[l];
+    g.C = H[l + 1];
+    g.M = N; g.N = m.dims[l + 1]; g.K = m.dims[l];
+    g.sAm = m.dims[l]; g.sAk = 1; g.bA = l == 0 ? 0 : (long)N * m.dims[l];
+    g.sBk = 1; g.sBn = m.dims[l]; g.bB = P;
+    g.sCm = m.dims[l + 1]; g.sCn = 1; g.bC = (long)N * m.dims[l + 1];
+    g.bias = m.boff[l] >= 0 ? theta + m.boff[l] : nullptr; g.bBias = P;
+    g.act = m.act[l];
+    if ((rc = bgemm(g, C, s))) return rc;
+  }
+  hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
+                     m.dims[K], m.lik, m.act[K - 1], lik_tmp);
+  if (grad) {
+    for (int l = K - 1; l >= 0; --l) {
+      BG g = {};  // dW_l = delta_{l+1}^T H_l
+      g.A = D[l + 1]; g.sAm = 1; g.sAk = m.dims[l + 1]; g.bA = (long)N * m.dims[l + 1];
+      g.B = l == 0 ? (const float*)m.x : H[l]; g.sBk = m.dims[l]; g.sBn = 1; g.bB = l == 0 ? 0 : (long)N * m.dims[l];
+      g.C = grad + m.woff[l]; g.sCm = m.dims[l]; g.sCn = 1; g.bC = P;
+      g.M = m.dims[l + 1]; g.N = m.dims[l]; g.K = N; g.act = EY_ACT_NONE;
+      if ((rc = bgemm(g, C, s))) return rc;
+      if (m.boff[l] >= 0)
+        hipLaunchKernelGGL(k_colsum, dim3((m.dims[l + 1] + 255) / 256, C), dim3(256), 0, s, (const float*)D[l + 1], N,
+                           m.dims[l + 1], grad + m.boff[l], (long)P);
+      if (l > 0) {
+        BG d = {};  // delta_l = (delta_{l+1} W_l) * act'(H_l)
+        d.A = D[l + 1]; d.sAm = m.dims[l + 1]; d.sAk = 1; d.bA = (long)N * m.dims[l + 1];
+        d.B = theta + m.woff[l]; d.sBk = m.dims[l]; d.sBn = 1; d.bB = P;
+        d.C = D[l]; d.sCm = m.dims[l]; d.sCn = 1; d.bC = (long)N * m.dims[l];
+        d.M = N; d.N = m.dims[l]; d.K = m.dims[l + 1];
+        d.Hm = H[l]; d.sHm = m.dims[l]; d.sHn = 1; d.bH = (long)N * m.dims[l]; d.act_h = m.act[l - 1];
+        if ((rc = bgemm(d, C, s))) return rc;
+      }
+    }
+  }
+  hipLaunchKernelGGL(k_prior, dim3(C), dim3(256), 0, s, theta, (const float*)m.mu, (const float*)m.inv_var,
+                     (float)m.prior_const, P, temp, (const float*)lik_tmp, grad, lik_o, prior_o, target_o);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+static int chunk_size(const ey_plan* pl, int64_t C) {
+  const size_t per_chain = 2 * act_floats_per_chain(pl->m) * sizeof(float);
+  size_t cap = (size_t)3 << 30;  // activation scratch budget
+  int64_t cc = (int64_t)(cap / (per_chain ? per_chain : 1));
+  if (cc < 1) cc = 1;
+  if (cc > 32768) cc = 32768;  // gridDim.z
+  return (int)(cc < C ? cc : C);
+}
+
+int ey_large_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+                        void* target, void* grad, hipStream_t s) {
+  const EyModel& m = pl->m;
+  const int cc = chunk_size(pl, C);
+  const size_t ws_floats = 2 * (size_t)cc * act_floats_per_chain(m) + (size_t)cc;
+  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  if (rc) return rc;
+  float* ws = (float*)pl->d_work;
+  float* lik_tmp = ws + 2 * (size_t)cc * act_floats_per_chain(m);
+  for (int64_t c0 = 0; c0 < C; c0 += cc) {
+    const int n = (int)((C - c0) < cc ? (C - c0) : cc);
+    rc = eval_chunk(pl, (const float*)theta + c0 * m.P, temp ? (const float*)temp + c0 : nullptr, n,
+                    lik ? (float*)lik + c0 : nullptr, prior ? (float*)prior + c0 : nullptr,
+                    target ? (float*)target + c0 : nullptr, grad ? (float*)grad + c0 * m.P : nullptr, ws, lik_tmp, s);
+    if (rc) return rc;
+  }
+  return EY_OK;
+}
+
+int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                 const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                 uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                 hipStream_t s) {
+  const EyModel& m = pl->m;
+  const int P = m.P;
+  const int cc = chunk_size(pl, C);
+  const size_t af = act_floats_per_chain(m);
+  // workspace: activations for a chunk + lik + [thp, p, gp] for the chunk + tprop, hcur
+  const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc;
+  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  if (rc) return rc;
+  float* ws = (float*)pl->d_work;
+  float* lik_tmp = ws + 2 * (size_t)cc * af;
+  float* thp = lik_tmp + cc;
+  float* p = thp + (size_t)cc * P;
+  float* gp = p + (size_t)cc * P;
+  float* tprop = gp + (size_t)cc * P;
+  float* hc = tprop + cc;
+  const dim3 eg((P + 255) / 256, 1);
+  for (int64_t c0 = 0; c0 < C; c0 += cc) {
+    const int n = (int)((C - c0) < cc ? (C - c0) : cc);
+    float* th_c = (float*)theta + c0 * P;
+    float* g_c = (float*)grad + c0 * P;
+    float* t_c = (float*)target + c0;
+    const float* temp_c = temp ? (const float*)temp + c0 : nullptr;
+    const float* sv_c = step_vec ? (const float*)step_vec + c0 : nullptr;
+    hipLaunchKernelGGL(k_hmc_begin, dim3(n), dim3(256), 0, s, (const float*)th_c, (const float*)g_c,
+                       p0 ? (const float*)p0 + c0 * P : nullptr, thp, p, gp, P, seed, iter, chain_offset + (uint64_t)c0,
+                       (const float*)t_c, hc);
+    if (flags & EY_RECOMPUTE_INITIAL_GRAD) {  // hmc.py:104
+      if ((rc = eval_chunk(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s))) return rc;
+    }
+    const dim3 grid(eg.x, n);
+    // p += eps/2 g ; theta += eps p      (hmc.py:105,110)
+    hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, thp, p, (const float*)gp, P, (float)step, sv_c, 0.5f, 1.0f);
+    for (int k = 1; k <= L; ++k) {
+      if ((rc = eval_chunk(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s))) return rc;
+      // full momentum step + position step, or the closing half momentum step (hmc.py:113-119)
+      hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, thp, p, (const float*)gp, P, (float)step, sv_c,
+                         k < L ? 1.0f : 0.5f, k < L ? 1.0f : 0.0f);
+    }
+    hipLaunchKernelGGL(k_hmc_end, dim3(n), dim3(256), 0, s, th_c, g_c, t_c, (const float*)thp, (const float*)p,
+                       (const float*)gp, (const float*)tprop, (const float*)hc, u ? (const float*)u + c0 : nullptr, P,
+                       seed, iter, chain_offset + (uint64_t)c0, (unsigned char*)accepted + c0,
+                       rate ? (float*)rate + c0 : nullptr, hcur ? (float*)hcur + c0 : nullptr,
+                       hprop ? (float*)hprop + c0 : nullptr);
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}

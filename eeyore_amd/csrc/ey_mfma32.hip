@@ -537,9 +537,11 @@ static size_t mf_lds_bytes(int ntiles, int waves) {
 
 // kernel variant (tuning knob): 1 = 8 chains per workgroup instead of 4
 static int g_variant = 0;
+extern int g_ey_force_large;
 extern "C" int ey_debug_set_variant(int v) {
-  const int old = g_variant;
-  g_variant = v;
+  const int old = g_variant | (g_ey_force_large << 4);
+  g_variant = v & 15;
+  g_ey_force_large = (v >> 4) & 1;
   return old;
 }
 

@@ -625,3 +625,99 @@ def test_model_surface_predictive_posterior_and_batched_integrator():
         model.set_params(s.clone())
         probs.append(torch.softmax(model(x), 1)[0, int(y.argmax())].item())
     np.testing.assert_allclose(est.item(), np.mean(probs), rtol=1e-10)
+
+
+# --------------------------------------------------------------------------------------------- batched-GEMM path
+def _force_large(on):
+    from eeyore_amd import _lib as L
+    L.lib().ey_debug_set_variant(16 if on else 0)
+
+
+@pytest.mark.parametrize("dims,acts,bias,lik,N", [
+    ([4, 3, 3], [1, 0], [1, 1], 1, 150),
+    ([3, 5, 4, 2], [2, 3, 0], [1, 0, 1], 1, 77),
+    ([6, 70, 33, 2], [1, 2, 1], [1, 1, 1], 0, 130),
+])
+def test_bgemm_path_on_small_models_vs_oracle(dims, acts, bias, lik, N):
+    """The layerwise batched-GEMM kernels (ey_large.hip), forced onto models the other kernels also cover."""
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(sum(dims) + N)
+    x = rng.standard_normal((N, dims[0]))
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(float)
+    P = sum((dims[l] + bias[l]) * dims[l + 1] for l in range(len(dims) - 1))
+    mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+    co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=np.float32, bias=bias, nthreads=4)
+    _force_large(True)
+    try:
+        pl = Plan(dims, bias, acts, lik, torch.float32, DEV)
+        pl.set_data(_t(x, torch.float32), _t(y, torch.float32))
+        pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+        assert pl.kernel == "bgemm"
+        C = 7
+        th0 = (0.4 * rng.standard_normal((C, P))).astype(np.float32)
+        temps = torch.tensor([1.0, 0.5, 1.0, 0.25, 1.0, 1.0, 2.0])
+        t, g = pl.log_target_grad(_t(th0, torch.float32))
+        tt, gt = pl.log_target_grad(_t(th0, torch.float32), temp=temps)
+        lk, pr = pl.log_target(_t(th0, torch.float32))
+        for c in range(C):
+            to, go, lo, po = co.log_target_grad(th0[c])
+            np.testing.assert_allclose(t[c].item(), to, rtol=2e-4, atol=2e-3)
+            np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(go).max()))
+            np.testing.assert_allclose([lk[c].item(), pr[c].item()], [lo, po], rtol=2e-4, atol=2e-3)
+            np.testing.assert_allclose(tt[c].item(), temps[c].item() * to, rtol=2e-4, atol=2e-3)
+            np.testing.assert_allclose(gt[c].cpu().numpy(), temps[c].item() * go, rtol=2e-3,
+                                       atol=2e-4 * max(1.0, np.abs(go).max()))
+        p0 = rng.standard_normal((C, P)).astype(np.float32); u = rng.random(C).astype(np.float32)
+        for flags in (0, 1):
+            th, tv, gg = _t(th0, torch.float32).clone(), t.clone(), g.clone()
+            out = pl.hmc_step(th, tv, gg, 0.03, 6, p0=_t(p0, torch.float32), u=_t(u, torch.float32), flags=flags)
+            tho, tvo, go = th0.copy(), t.cpu().numpy().copy(), g.cpu().numpy().copy()
+            acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, 0.03, 6)
+            rate = np.minimum(np.exp(np.minimum(hc - hp, 0)), 1)
+            decided = np.abs(u - rate) > 5e-3
+            np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+            np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=2e-3, atol=2e-2)
+            same = out["accepted"].cpu().numpy() == acc
+            np.testing.assert_allclose(th.cpu().numpy()[same], tho[same], rtol=2e-3, atol=2e-4)
+        # Philox fused == streams passed in
+        a = [_t(th0, torch.float32).clone(), t.clone(), g.clone()]
+        b = [_t(th0, torch.float32).clone(), t.clone(), g.clone()]
+        oa = pl.hmc_step(*a, 0.03, 4, seed=5, it=2, chain_offset=10)
+        ob = pl.hmc_step(*b, 0.03, 4, p0=pl.philox_normal(C, 5, 2, 10), u=pl.philox_uniform(C, 5, 2, 10))
+        assert torch.equal(oa["accepted"], ob["accepted"]) and torch.equal(a[0], b[0])
+    finally:
+        _force_large(False)
+
+
+def test_config5_shape_mnist_like_model_runs_on_bgemm_path():
+    """BASELINE config 5's model shape: MLP(784-128-10), P = 101 770 (does not fit LDS) -> batched-GEMM path."""
+    from eeyore_amd.plan import Plan
+    dims, acts = [784, 128, 10], [1, 0]
+    rng = np.random.default_rng(0)
+    N = 96
+    x = rng.random((N, 784)) * (rng.random((N, 784)) < 0.19)
+    y = np.eye(10)[np.arange(N) % 10]
+    pl = Plan(dims, [1, 1], acts, 1, torch.float32, DEV)
+    assert pl.P == 101770 and pl.kernel == "bgemm"
+    pl.set_data(_t(x, torch.float32), _t(y, torch.float32))
+    pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
+    # with 1e5 parameters a sequential f32 sum (the C oracle in f32) is itself off by ~4e-4; the f64 oracle is the
+    # reference for values, the f32 one only drives the recorded-randomness HMC draw below
+    co64 = COracle(dims, acts, 1, x, y, 0.0, 1.0, dtype=np.float64, nthreads=8)
+    co = COracle(dims, acts, 1, x, y, 0.0, 1.0, dtype=np.float32, nthreads=8)
+    C = 3
+    th0 = (0.05 * rng.standard_normal((C, pl.P))).astype(np.float32)
+    t, g = pl.log_target_grad(_t(th0, torch.float32))
+    for c in range(C):
+        to, go, _, _ = co64.log_target_grad(th0[c].astype(np.float64))
+        np.testing.assert_allclose(t[c].item(), to, rtol=2e-6)
+        np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=2e-3, atol=2e-4 * np.abs(go).max())
+    p0 = rng.standard_normal((C, pl.P)).astype(np.float32); u = np.array([0.3, 0.6, 0.9], np.float32)
+    th, tv, gg = _t(th0, torch.float32).clone(), t.clone(), g.clone()
+    out = pl.hmc_step(th, tv, gg, 0.002, 3, p0=_t(p0, torch.float32), u=_t(u, torch.float32))
+    tho, tvo, go = th0.copy(), t.cpu().numpy().copy(), g.cpu().numpy().copy()
+    acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, 0.002, 3)
+    np.testing.assert_allclose(out["h_cur"].cpu().numpy(), hc, rtol=2e-4)
+    np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=1e-3)
+    np.testing.assert_allclose(th.cpu().numpy()[out["accepted"].cpu().numpy() == acc],
+                               tho[out["accepted"].cpu().numpy() == acc], rtol=2e-3, atol=2e-4)
