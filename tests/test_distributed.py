@@ -86,3 +86,57 @@ def test_world_size_2_gloo_equals_single_process():
     np.testing.assert_allclose(got["mean"], want["mean"].numpy(), rtol=1e-12)
     assert got["num_chains"] == x.shape[0] and got["num_samples"] == x.shape[1]
     assert abs(got["acceptance"] - want["acceptance"]) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ tempering exchange
+def _torch_decide(ell_i, ell_j, t_i, t_j, u, dlogq=None):
+    lr = (t_i - t_j) * (ell_j - ell_i)
+    return (torch.log(u) < lr).to(torch.uint8), lr
+
+
+def _pt_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from eeyore_amd.distributed import TemperingExchange
+    R = 50
+    temps = [(i / world) ** 4 for i in range(1, world + 1)]
+    ex = TemperingExchange(temps, R, rank, world, "cpu", seed=3, decide=_torch_decide)
+    hist = []
+    for it in range(6):
+        g = torch.Generator().manual_seed(100 * it + rank)
+        ell = -50.0 + 10.0 * torch.randn(R, generator=g, dtype=torch.float64)
+        ex.exchange(ell)
+        hist.append(ex.labels.clone())
+    q.put((rank, torch.stack(hist).numpy(), ex.num_swaps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tempering_exchange_keeps_a_permutation_and_agrees_across_ranks():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pt_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r, hist, swaps = q.get(timeout=120)
+        got[r] = (hist, swaps)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    labels = np.stack([got[r][0] for r in range(world)])  # [rank, attempt, replica]
+    # at every attempt, the ranks' labels of each replica are a permutation of the ladder positions
+    assert (np.sort(labels, axis=0) == np.arange(world)[:, None, None]).all()
+    assert len({got[r][1] for r in range(world)}) == 1 and got[0][1] > 0  # same swap count everywhere, some accepted
+    # positions move by at most one ladder step per attempt
+    assert np.abs(np.diff(labels, axis=1)).max() <= 1
+
+
+def test_tempering_exchange_single_process_matches_rule():
+    from eeyore_amd.distributed import TemperingExchange
+    ex = TemperingExchange([1.0], 4, 0, 1, "cpu", decide=_torch_decide)
+    assert ex.exchange(torch.zeros(4, dtype=torch.float64)) == 0 and ex.labels.tolist() == [0, 0, 0, 0]
+    assert ex.temperature_vector(torch.float32).tolist() == [1.0] * 4

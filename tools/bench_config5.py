@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: parallel-tempering HMC (L = 20) on MLP(784-128-10), MNIST-shaped synthetic data (N = 1024 rows,
+~19 % non-zero pixels, 10 balanced classes).  One ladder position per GPU, R chains (replicas) per GPU, ladder
+t_i = (i/K)^4, even/odd neighbour exchange of temperature labels every 10 iterations (one RCCL all-gather of [R] log-targets
+and labels; no state crosses xGMI).
+
+    python tools/bench_config5.py [chains] [iterations]                              # one GPU: one temperature
+    python -m torch.distributed.run --nproc-per-node 8 tools/bench_config5.py 4096 20  # the full configuration
+
+Reports leapfrog-steps/s x chains and TFLOP/s on the algorithmic flops of SURVEY.md 8(d) (4.097e8 per step per chain)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eeyore_amd.distributed import TemperingExchange, init_from_env  # noqa: E402
+from eeyore_amd.plan import Plan  # noqa: E402
+
+rank, world, local = init_from_env()
+local = local % max(1, torch.cuda.device_count())
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+N, L, eps, between = 1024, 20, 0.001, 10
+
+rng = np.random.default_rng(0)
+x = (rng.random((N, 784)) * (rng.random((N, 784)) < 0.19)).astype(np.float32)
+y = np.eye(10, dtype=np.float32)[np.arange(N) % 10]
+pl = Plan([784, 128, 10], [1, 1], [1, 0], 1, torch.float32, dev)
+pl.set_data(torch.tensor(x, device=dev), torch.tensor(y, device=dev))
+pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
+
+ladder = [(i / world) ** 4 for i in range(1, world + 1)]
+pt = TemperingExchange(ladder, C, rank, world, dev, seed=11)
+th = 0.05 * pl.philox_normal(C, seed=0, it=0)  # every rank starts its replicas from the same states
+temps = pt.temperature_vector(torch.float32)
+t, g = pl.log_target_grad(th, temp=temps)
+out = pl.hmc_step(th, t, g, eps, L, temp=temps, seed=1 + rank, it=1)
+torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
+t0 = time.perf_counter()
+accs, swaps = [], 0
+for it in range(iters):
+    out = pl.hmc_step(th, t, g, eps, L, temp=temps, seed=1 + rank, it=2 + it)
+    accs.append(out["accepted"].float().mean().item())
+    if world > 1 and (it + 1) % between == 0:
+        old = temps
+        swaps += pt.exchange(t / old)          # untempered log-target ell = T / t
+        temps = pt.temperature_vector(torch.float32)
+        ratio = temps / old                    # a relabelled chain keeps its state: rescale the cached tempered values
+        t *= ratio
+        g *= ratio[:, None]
+torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
+dt = (time.perf_counter() - t0) / iters
+f_step = 2 * N * (2 * (784 * 128 + 128 * 10) + 128 * 10) + 6 * pl.P
+if rank == 0:
+    tot = C * world
+    print(f"kernel {pl.kernel}: {world} temperature(s) x {C} chains, {dt * 1e3:.1f} ms per HMC iteration (L={L}) -> "
+          f"{tot * L / dt:.3e} leapfrog-steps/s x chains, {f_step * C * L / dt / 1e12:.1f} TFLOP/s per GPU "
+          f"({100 * f_step * C * L / dt / 157.3e12:.1f}% of f32 MFMA peak), acceptance {np.mean(accs):.2f}, "
+          f"label exchanges accepted {swaps}")
+if world > 1:
+    dist.destroy_process_group()
