@@ -9,17 +9,18 @@
 // with the same semantics as the other kernel families (MLP.forward eeyore/models/mlp.py:45-50, losses
 // eeyore/constants/constants.py:15-18, log_target eeyore/models/bayesian_model.py:30-56, gradient
 // eeyore/models/log_target_model.py:15-23, HMC eeyore/samplers/hmc.py:100-156).  One GEMM kernel serves the three
-// products through element strides; tiles are 64x64x16 through LDS, v_mfma_f32_32x32x2_f32 per 32x32 wave tile.
+// products through element strides; 128x128x16 tiles through double-buffered LDS, each wave a 64x64 quadrant of
+// v_mfma_f32_32x32x2_f32 tiles.
 #include <vector>
 
 #include "ey_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define BM 64
-#define BN 64
+#define BM 128
+#define BN 128
 #define BK 16
-#define LDT (BM + 1)
+#define LDT (BM + 4)  // [k][m] rows, 16-byte aligned, staggered over banks
 
 struct BG {
   const float* A; const float* B; float* C;
@@ -30,6 +31,7 @@ struct BG {
   int act;                            // activation applied to acc + bias
   const float* Hm; long sHm, sHn, bH; // if set: C = acc * act'(Hm[m][n]) with act_h
   int act_h;
+  float* rowsum; long bRow;           // if set: rowsum[m] = sum_k A[m][k] (the bias gradient of a dW product)
 };
 
 __device__ __forceinline__ float l_act(int code, float g) {
@@ -49,9 +51,61 @@ __device__ __forceinline__ float l_dact(int code, float h) {
   }
 }
 
+// One operand tile [BK][128] of a strided matrix: 8 elements per thread, fetched into registers (so the fetch of the
+// next k-tile overlaps the MFMAs of the current one) and then written to LDS as [k][row].
+struct Frag { float v[8]; };
+
+// element e of the tile (e in [0, 2048)) -> (row, k) such that consecutive threads walk the contiguous stride
+__device__ __forceinline__ void tile_coord(bool kfast, int e, int& row, int& kk) {
+  if (kfast) { row = e >> 4; kk = e & 15; } else { row = e & 127; kk = e >> 7; }
+}
+
+__device__ __forceinline__ Frag fetch(const float* P, long sRow, long sK, bool kfast, int row0, int k0, int rows, int K,
+                                      int tid) {
+  Frag f;
+  // fast path: 4 consecutive elements along the contiguous stride, all in bounds
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = (tid + 256 * i) * 4;
+    int row, kk;
+    tile_coord(kfast, e, row, kk);
+    const int gr = row0 + row, gk = k0 + kk;
+    const bool inside = kfast ? (gr < rows && gk + 3 < K) : (gr + 3 < rows && gk < K);
+    if (inside) {
+      const float* src = P + gr * sRow + gk * sK;  // the 4 elements are contiguous in memory
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.v[4 * i + j] = src[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r2 = kfast ? gr : gr + j, k2 = kfast ? gk + j : gk;
+        f.v[4 * i + j] = (r2 < rows && k2 < K) ? P[r2 * sRow + k2 * sK] : 0.0f;
+      }
+    }
+  }
+  return f;
+}
+
+__device__ __forceinline__ void stage(float* T, const Frag& f, bool kfast, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = (tid + 256 * i) * 4;
+    int row, kk;
+    tile_coord(kfast, e, row, kk);
+    if (kfast) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T[(kk + j) * LDT + row] = f.v[4 * i + j];
+    } else {
+      *reinterpret_cast<float4*>(T + kk * LDT + row) = make_float4(f.v[4 * i], f.v[4 * i + 1], f.v[4 * i + 2], f.v[4 * i + 3]);
+    }
+  }
+}
+
+// C[b] = epilogue(A[b] B[b]); 128x128x16 tiles, two LDS buffers, each of the 4 waves owns a 64x64 quadrant (2x2 MFMA
+// tiles of 32x32), so one operand register feeds two v_mfma_f32_32x32x2_f32
 __global__ void __launch_bounds__(256) k_bgemm(BG g) {
-  __shared__ float As[BK * LDT];
-  __shared__ float Bs[BK * LDT];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -59,44 +113,70 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
   const long b = blockIdx.z;
   const float* A = g.A + b * g.bA;
   const float* B = g.B + b * g.bB;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
-    // stage the two operand tiles as [k][m] / [k][n]; the element -> thread map follows the contiguous stride
+  f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + 256 * i;
-      int mm, kk;
-      if (a_kfast) { mm = e >> 4; kk = e & 15; } else { mm = e & 63; kk = e >> 6; }
-      const int gm = m0 + mm, gk = k0 + kk;
-      As[kk * LDT + mm] = (gm < g.M && gk < g.K) ? A[gm * g.sAm + gk * g.sAk] : 0.0f;
-      int nn, kb;
-      if (b_kfast) { nn = e >> 4; kb = e & 15; } else { nn = e & 63; kb = e >> 6; }
-      const int gn = n0 + nn, gkb = k0 + kb;
-      Bs[kb * LDT + nn] = (gn < g.N && gkb < g.K) ? B[gkb * g.sBk + gn * g.sBn] : 0.0f;
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int ktiles = (g.K + BK - 1) / BK;
+  const bool do_rowsum = g.rowsum != nullptr && blockIdx.x == 0 && tid < BM;
+  float rsum = 0.0f;
+  Frag fa = fetch(A, g.sAm, g.sAk, a_kfast, m0, 0, g.M, g.K, tid);
+  Frag fb = fetch(B, g.sBn, g.sBk, b_kfast, n0, 0, g.N, g.K, tid);
+  stage(As[0], fa, a_kfast, tid);
+  stage(Bs[0], fb, b_kfast, tid);
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < ktiles;
+    if (more) {
+      fa = fetch(A, g.sAm, g.sAk, a_kfast, m0, (kt + 1) * BK, g.M, g.K, tid);
+      fb = fetch(B, g.sBn, g.sBk, b_kfast, n0, (kt + 1) * BK, g.N, g.K, tid);
+    }
+    const float* Ac = As[cur] + wm * 64 + c;
+    const float* Bc = Bs[cur] + wn * 64 + c;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      const int row = (2 * s + h) * LDT;
+      const float a0 = Ac[row], a1 = Ac[row + 32], b0 = Bc[row], b1 = Bc[row + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (do_rowsum) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) rsum += As[cur][k * LDT + tid];
+    }
+    if (more) {
+      stage(As[cur ^ 1], fa, a_kfast, tid);
+      stage(Bs[cur ^ 1], fb, b_kfast, tid);
     }
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < BK / 2; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(2 * s + h) * LDT + wm * 32 + c], Bs[(2 * s + h) * LDT + wn * 32 + c],
-                                                 acc, 0, 0, 0);
-    __syncthreads();
   }
-  const int n = n0 + wn * 32 + c;
-  if (n >= g.N) return;
+  if (do_rowsum && m0 + tid < g.M) g.rowsum[b * g.bRow + m0 + tid] = rsum;
   float* C = g.C + b * g.bC;
-  const float bias = g.bias ? g.bias[b * g.bBias + n] : 0.0f;
   const float* Hm = g.Hm ? g.Hm + b * g.bH : nullptr;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-    if (m < g.M) {
-      float v = acc[r];
-      if (Hm) v *= l_dact(g.act_h, Hm[m * g.sHm + n * g.sHn]);
-      else v = l_act(g.act, v + bias);
-      C[m * g.sCm + n * g.sCn] = v;
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + 32 * j + c;
+    if (n >= g.N) continue;
+    const float bias = g.bias ? g.bias[b * g.bBias + n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (m < g.M) {
+          float v = acc[i][j][r];
+          if (Hm) v *= l_dact(g.act_h, Hm[m * g.sHm + n * g.sHn]);
+          else v = l_act(g.act, v + bias);
+          C[m * g.sCm + n * g.sCn] = v;
+        }
+      }
     }
   }
 }
@@ -152,6 +232,129 @@ __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ out, flo
   }
   lik = block_sum(lik, red);
   if (threadIdx.x == 0) lik_o[c] = lik;
+}
+
+// Narrow output layer, fused ("head"): for one chain, layer K-1 -> K forward, likelihood, output delta, the weight and
+// bias gradients of that layer, and delta_{K-1} = (delta_K W_{K-1}) * act'(H_{K-1}) -- the three skinny products a
+// 128-wide GEMM tile would waste itself on.  Rows are staged 64 at a time in LDS ([row][dH+1]); logits / softmax / dH
+// are row-parallel, the weight gradient is (output, input)-pair-parallel over the staged rows.
+#define HT 64
+__global__ void __launch_bounds__(256) k_head(const float* __restrict__ Hin, float* __restrict__ Dout,
+                                              const float* __restrict__ theta, float* __restrict__ grad, int P, int woff,
+                                              int boff, int N, int dH, int dK, const float* __restrict__ y,
+                                              const int* __restrict__ labels, int lik_code, int act_last, int act_prev,
+                                              int want_grad, float* __restrict__ lik_o) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float red[4];
+  const long c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int ld = dH + 1;
+  float* W = sm;                    // [dK][dH]
+  float* bsh = W + dK * dH;         // [dK]
+  float* tile = bsh + ((dK + 3) & ~3);  // [HT][ld]
+  float* dk = tile + HT * ld;       // [HT][dK] delta_K of the staged rows
+  const float* th = theta + c * P;
+  for (int i = tid; i < dK * dH; i += 256) W[i] = th[woff + i];
+  for (int i = tid; i < dK; i += 256) bsh[i] = boff >= 0 ? th[boff + i] : 0.0f;
+  const float* Hc = Hin + c * (long)N * dH;
+  float* Dc = Dout + c * (long)N * dH;
+  const int npairs = dK * dH;
+  float accw[8];  // pairs tid, tid+256, ... (npairs <= 2048)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) accw[q] = 0.0f;
+  float accb = 0.0f, lik = 0.0f;
+  for (int r0 = 0; r0 < N; r0 += HT) {
+    const int rows = min(HT, N - r0);
+    __syncthreads();
+    for (int i = tid; i < rows * dH; i += 256) {
+      const int r = i / dH, k = i - r * dH;
+      tile[r * ld + k] = Hc[(long)(r0 + r) * dH + k];
+    }
+    __syncthreads();
+    // logits, (row, output)-pair-parallel: lgt[r][o] = act(b[o] + sum_k H[r][k] W[o][k])
+    for (int pidx = tid; pidx < rows * dK; pidx += 256) {
+      const int r = pidx / dK, o = pidx - r * dK;
+      const float* hr = tile + r * ld;
+      const float* wr = W + o * dH;
+      float a = bsh[o];
+      for (int k = 0; k < dH; ++k) a += hr[k] * wr[k];
+      dk[pidx] = l_act(act_last, a);
+    }
+    __syncthreads();
+    if (tid < rows) {  // one row per thread: likelihood and delta_K (overwrites the logits in place)
+      float* lg = dk + tid * dK;
+      const int n = r0 + tid;
+      if (lik_code == EY_LIK_BCE_SUM) {
+        for (int o = 0; o < dK; ++o) {
+          const float pz = lg[o], yy = y[(long)n * dK + o];
+          lik += __logf(pz) * yy + __logf(1.0f - pz) * (1.0f - yy);
+          lg[o] = (yy / pz - (1.0f - yy) / (1.0f - pz)) * l_dact(act_last, pz);
+        }
+      } else {
+        const int lab = labels[n];
+        float mx = lg[0];
+        for (int o = 1; o < dK; ++o) mx = fmaxf(mx, lg[o]);
+        float ssum = 0.0f;
+        for (int o = 0; o < dK; ++o) ssum += __expf(lg[o] - mx);
+        const float llab = lg[lab];
+        const float rs = 1.0f / ssum;
+        for (int o = 0; o < dK; ++o)
+          lg[o] = ((o == lab ? 1.0f : 0.0f) - __expf(lg[o] - mx) * rs) * l_dact(act_last, lg[o]);
+        lik += llab - (mx + __logf(ssum));
+      }
+    }
+    __syncthreads();
+    if (want_grad) {
+      // dW[o][k] += sum_r delta_K[r][o] H[r][k]   (pair-parallel), db[o] += sum_r delta_K[r][o]
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int pidx = tid + 256 * q;
+        if (pidx < npairs) {
+          const int o = pidx / dH, k = pidx - o * dH;
+          float a = 0.0f;
+          for (int r = 0; r < rows; ++r) a += dk[r * dK + o] * tile[r * ld + k];
+          accw[q] += a;
+        }
+      }
+      if (tid < dK) {
+        float a = 0.0f;
+        for (int r = 0; r < rows; ++r) a += dk[r * dK + tid];
+        accb += a;
+      }
+      __syncthreads();
+      // delta_{K-1}[r][k] = (sum_o delta_K[r][o] W[o][k]) * act'(H[r][k]), (row, k)-parallel, in place; then to HBM
+      for (int i = tid; i < rows * dH; i += 256) {
+        const int r = i / dH, k = i - r * dH;
+        const float* dr = dk + r * dK;
+        float a = 0.0f;
+        for (int o = 0; o < dK; ++o) a += dr[o] * W[o * dH + k];
+        const float hv = tile[r * ld + k];
+        Dc[(long)(r0 + r) * dH + k] = a * l_dact(act_prev, hv);
+      }
+    }
+  }
+  if (want_grad) {
+    float* gc = grad + c * P;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int pidx = tid + 256 * q;
+      if (pidx < npairs) gc[woff + pidx] = accw[q];
+    }
+    if (tid < dK && boff >= 0) gc[boff + tid] = accb;
+  }
+  lik = block_sum(lik, red);
+  if (tid == 0) lik_o[c] = lik;
+}
+
+static bool head_ok(const EyModel& m) {
+  const int K = m.nl;
+  if (K < 2) return false;
+  const int dK = m.dims[K], dH = m.dims[K - 1];
+  return dK <= 16 && dK * dH <= 2048 && dH <= 512;
+}
+static size_t head_lds(const EyModel& m) {
+  const int dK = m.dims[m.nl], dH = m.dims[m.nl - 1];
+  return sizeof(float) * ((size_t)dK * dH + ((dK + 3) & ~3) + (size_t)HT * (dH + 1) + (size_t)HT * dK);
 }
 
 // db[c][j] = sum_n delta[c][n][j]
@@ -306,8 +509,9 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     }
   }
   int rc;
-  // forward
-  for (int l = 0; l < K; ++l) {
+  const bool head = head_ok(m);
+  const int Kf = head ? K - 1 : K;  // layers run as GEMMs in the forward pass
+  for (int l = 0; l < Kf; ++l) {
     BG g = {};
     g.A = l == 0 ? (const float*)m.x : H[l];
     g.B = theta + m.woff[l];
@@ -320,19 +524,32 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     g.act = m.act[l];
     if ((rc = bgemm(g, C, s))) return rc;
   }
-  hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
-                     m.dims[K], m.lik, m.act[K - 1], lik_tmp);
+  int ltop;  // first layer whose gradients still have to be produced by the GEMM loop below
+  if (head) {
+    static size_t attr_bytes = 48 * 1024;
+    if (head_lds(m) > attr_bytes) {
+      EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)head_lds(m)));
+      attr_bytes = head_lds(m);
+    }
+    hipLaunchKernelGGL(k_head, dim3(C), dim3(256), head_lds(m), s, (const float*)H[K - 1], D[K - 1], theta, grad, P,
+                       m.woff[K - 1], m.boff[K - 1], N, m.dims[K - 1], m.dims[K], (const float*)m.y, m.labels, m.lik,
+                       m.act[K - 1], m.act[K - 2], grad ? 1 : 0, lik_tmp);
+    ltop = K - 2;
+  } else {
+    hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
+                       m.dims[K], m.lik, m.act[K - 1], lik_tmp);
+    ltop = K - 1;
+  }
   if (grad) {
-    for (int l = K - 1; l >= 0; --l) {
-      BG g = {};  // dW_l = delta_{l+1}^T H_l
+    for (int l = ltop; l >= 0; --l) {
+      BG g = {};  // dW_l = delta_{l+1}^T H_l, db_l = row sums of delta_{l+1}^T
       g.A = D[l + 1]; g.sAm = 1; g.sAk = m.dims[l + 1]; g.bA = (long)N * m.dims[l + 1];
       g.B = l == 0 ? (const float*)m.x : H[l]; g.sBk = m.dims[l]; g.sBn = 1; g.bB = l == 0 ? 0 : (long)N * m.dims[l];
       g.C = grad + m.woff[l]; g.sCm = m.dims[l]; g.sCn = 1; g.bC = P;
       g.M = m.dims[l + 1]; g.N = m.dims[l]; g.K = N; g.act = EY_ACT_NONE;
+      if (m.boff[l] >= 0) { g.rowsum = grad + m.boff[l]; g.bRow = P; }
       if ((rc = bgemm(g, C, s))) return rc;
-      if (m.boff[l] >= 0)
-        hipLaunchKernelGGL(k_colsum, dim3((m.dims[l + 1] + 255) / 256, C), dim3(256), 0, s, (const float*)D[l + 1], N,
-                           m.dims[l + 1], grad + m.boff[l], (long)P);
       if (l > 0) {
         BG d = {};  // delta_l = (delta_{l+1} W_l) * act'(H_l)
         d.A = D[l + 1]; d.sAm = m.dims[l + 1]; d.sAk = 1; d.bA = (long)N * m.dims[l + 1];
