@@ -30,6 +30,9 @@ struct BG {
   const float* Hm; long sHm, sHn, bH; // if set: C = acc * act'(Hm[m][n]) with act_h
   int act_h;
   float* rowsum; long bRow;           // if set: rowsum[m] = sum_k A[m][k] (the bias gradient of a dW product)
+  // if pr_theta is set the product is a weight gradient: the output becomes (acc - (theta - mu) / sigma^2) * t, i.e.
+  // the prior gradient and the temperature are applied here (indexed like C; *_b like rowsum), batch stride bC / bRow
+  const float *pr_theta, *pr_mu, *pr_iv, *pr_theta_b, *pr_mu_b, *pr_iv_b, *pr_temp;
 };
 
 __device__ __forceinline__ float l_act(int code, float g) {
@@ -168,7 +171,12 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
     }
     __syncthreads();
   }
-  if (do_rowsum && m0 + tid < g.M) g.rowsum[b * g.bRow + m0 + tid] = rsum;
+  const float tscale = g.pr_temp ? g.pr_temp[b] : 1.0f;
+  if (do_rowsum && m0 + tid < g.M) {
+    const int mm = m0 + tid;
+    if (g.pr_theta_b) rsum = (rsum - (g.pr_theta_b[b * g.bRow + mm] - g.pr_mu_b[mm]) * g.pr_iv_b[mm]) * tscale;
+    g.rowsum[b * g.bRow + mm] = rsum;
+  }
   float* C = g.C + b * g.bC;
   const float* Hm = g.Hm ? g.Hm + b * g.bH : nullptr;
 #pragma unroll
@@ -185,7 +193,9 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
           float v = acc[i][j][r];
           if (Hm) v *= l_dact(g.act_h, Hm[m * g.sHm + n * g.sHn]);
           else v = l_act(g.act, v + bias);
-          C[m * g.sCm + n * g.sCn] = v;
+          const long ci = m * g.sCm + n * g.sCn;
+          if (g.pr_theta) v = (v - (g.pr_theta[b * g.bC + ci] - g.pr_mu[ci]) * g.pr_iv[ci]) * tscale;
+          C[ci] = v;
         }
       }
     }
@@ -388,18 +398,6 @@ __global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ delta,
   grad[c * gstride + j] = a;
 }
 
-// prior gradient and temperature: grad = (grad - (theta - mu) / sigma^2) * t, elementwise over [C, P]
-__global__ void __launch_bounds__(256) k_prior_grad(const float* __restrict__ theta, const float* __restrict__ mu,
-                                                    const float* __restrict__ iv, int P, const float* __restrict__ temp,
-                                                    float* __restrict__ grad) {
-  const long c = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const float t = temp ? temp[c] : 1.0f;
-  const long k = c * P + i;
-  grad[k] = (grad[k] - (theta[k] - mu[i]) * iv[i]) * t;
-}
-
 // prior value, temperature, log-target; one block per chain
 __global__ void __launch_bounds__(256) k_prior(const float* __restrict__ theta, const float* __restrict__ mu,
                                                const float* __restrict__ iv, float prior_const, int P,
@@ -443,16 +441,48 @@ __global__ void __launch_bounds__(256) k_hmc_begin(const float* theta, const flo
 }
 
 // p += wp * eps * g ; then theta += wt * eps * p   (either weight may be 0)
+// Also leaves, per block, the partial sum of (theta - mu)^2 / sigma^2 over the block's slice of the NEW position in
+// qpart[c][blockIdx.x]: the next evaluation's log-prior then needs no pass over theta (summed in a fixed order, so the
+// result is reproducible).
 __global__ void __launch_bounds__(256) k_leap(float* thp, float* p, const float* gp, int P, float step,
-                                              const float* step_vec, float wp, float wt) {
+                                              const float* step_vec, float wp, float wt, const float* __restrict__ mu,
+                                              const float* __restrict__ iv, float* __restrict__ qpart) {
+  __shared__ float red[4];
   const long c = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const float eps = step_vec ? step_vec[c] : step;
-  const long k = c * P + i;
-  float pv = p[k];
-  if (wp != 0.0f) { pv = pv + wp * eps * gp[k]; p[k] = pv; }
-  if (wt != 0.0f) thp[k] = thp[k] + wt * eps * pv;
+  float q = 0.0f;
+  if (i < P) {
+    const float eps = step_vec ? step_vec[c] : step;
+    const long k = c * P + i;
+    float pv = p[k];
+    if (wp != 0.0f) { pv = pv + wp * eps * gp[k]; p[k] = pv; }
+    float tv = thp[k];
+    if (wt != 0.0f) { tv = tv + wt * eps * pv; thp[k] = tv; }
+    const float d = tv - mu[i];
+    q = d * d * iv[i];
+  }
+  q = block_sum(q, red);
+  if (threadIdx.x == 0) qpart[c * gridDim.x + blockIdx.x] = q;
+}
+
+// log-target from the likelihood and the per-block partials of the prior quadratic form; one wave per chain, lanes
+// stride over the partials and combine with a fixed shuffle tree (reproducible)
+__global__ void __launch_bounds__(256) k_target(const float* __restrict__ qpart, int nblk, float prior_const,
+                                                const float* __restrict__ temp, const float* __restrict__ lik, int C,
+                                                float* lik_o, float* prior_o, float* target_o) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  float q = 0.0f;
+  for (int j = lane; j < nblk; j += 64) q += qpart[(long)c * nblk + j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  if (lane != 0) return;
+  const float t = temp ? temp[c] : 1.0f;
+  const float pr = (prior_const - 0.5f * q) * t, lk = lik[c] * t;
+  if (lik_o) lik_o[c] = lk;
+  if (prior_o) prior_o[c] = pr;
+  if (target_o) target_o[c] = lk + pr;
 }
 
 __global__ void __launch_bounds__(256) k_hmc_end(float* theta, float* grad, float* target, const float* thp,
@@ -523,7 +553,8 @@ static size_t act_floats_per_chain(const EyModel& m) {
 
 // value (+ gradient when grad != null) for chains [0, C) of theta, using `ws` (2 * C * act_floats floats) as scratch
 static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C, float* lik_o, float* prior_o,
-                      float* target_o, float* grad, float* ws, float* lik_tmp, hipStream_t s) {
+                      float* target_o, float* grad, float* ws, float* lik_tmp, hipStream_t s,
+                      const float* qpart = nullptr) {
   const EyModel& m = pl->m;
   const int K = m.nl, N = m.N, P = m.P;
   const size_t af = act_floats_per_chain(m);
@@ -579,6 +610,12 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
       g.C = grad + m.woff[l]; g.sCm = m.dims[l]; g.sCn = 1; g.bC = P;
       g.M = m.dims[l + 1]; g.N = m.dims[l]; g.K = N; g.act = EY_ACT_NONE;
       if (m.boff[l] >= 0) { g.rowsum = grad + m.boff[l]; g.bRow = P; }
+      g.pr_theta = theta + m.woff[l]; g.pr_mu = (const float*)m.mu + m.woff[l]; g.pr_iv = (const float*)m.inv_var + m.woff[l];
+      if (m.boff[l] >= 0) {
+        g.pr_theta_b = theta + m.boff[l]; g.pr_mu_b = (const float*)m.mu + m.boff[l];
+        g.pr_iv_b = (const float*)m.inv_var + m.boff[l];
+      }
+      g.pr_temp = temp;
       if ((rc = bgemm(g, C, s))) return rc;
       if (l > 0) {
         BG d = {};  // delta_l = (delta_{l+1} W_l) * act'(H_l)
@@ -591,11 +628,12 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
       }
     }
   }
-  if (grad)
-    hipLaunchKernelGGL(k_prior_grad, dim3((P + 255) / 256, C), dim3(256), 0, s, theta, (const float*)m.mu,
-                       (const float*)m.inv_var, P, temp, grad);
-  hipLaunchKernelGGL(k_prior, dim3(C), dim3(256), 0, s, theta, (const float*)m.mu, (const float*)m.inv_var,
-                     (float)m.prior_const, P, temp, (const float*)lik_tmp, lik_o, prior_o, target_o);
+  if (qpart)
+    hipLaunchKernelGGL(k_target, dim3((C + 3) / 4), dim3(256), 0, s, qpart, (P + 255) / 256, (float)m.prior_const,
+                       temp, (const float*)lik_tmp, C, lik_o, prior_o, target_o);
+  else
+    hipLaunchKernelGGL(k_prior, dim3(C), dim3(256), 0, s, theta, (const float*)m.mu, (const float*)m.inv_var,
+                       (float)m.prior_const, P, temp, (const float*)lik_tmp, lik_o, prior_o, target_o);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
@@ -637,7 +675,8 @@ int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void*
   const int cc = chunk_size(pl, C);
   const size_t af = act_floats_per_chain(m);
   // workspace: activations for a chunk + lik + [thp, p, gp] for the chunk + tprop, hcur
-  const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc;
+  const int nblk = (P + 255) / 256;
+  const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc + (size_t)cc * nblk;
   int rc = ensure_work(pl, ws_floats * sizeof(float));
   if (rc) return rc;
   float* ws = (float*)pl->d_work;
@@ -647,6 +686,9 @@ int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void*
   float* gp = p + (size_t)cc * P;
   float* tprop = gp + (size_t)cc * P;
   float* hc = tprop + cc;
+  float* qpart = hc + cc;
+  const float* mu = (const float*)m.mu;
+  const float* iv = (const float*)m.inv_var;
   const dim3 eg((P + 255) / 256, 1);
   for (int64_t c0 = 0; c0 < C; c0 += cc) {
     const int n = (int)((C - c0) < cc ? (C - c0) : cc);
@@ -663,12 +705,13 @@ int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void*
     }
     const dim3 grid(eg.x, n);
     // p += eps/2 g ; theta += eps p      (hmc.py:105,110)
-    hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, thp, p, (const float*)gp, P, (float)step, sv_c, 0.5f, 1.0f);
+    hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, thp, p, (const float*)gp, P, (float)step, sv_c, 0.5f, 1.0f, mu, iv,
+                       qpart);
     for (int k = 1; k <= L; ++k) {
-      if ((rc = eval_chunk(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s))) return rc;
+      if ((rc = eval_chunk(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s, qpart))) return rc;
       // full momentum step + position step, or the closing half momentum step (hmc.py:113-119)
       hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, thp, p, (const float*)gp, P, (float)step, sv_c,
-                         k < L ? 1.0f : 0.5f, k < L ? 1.0f : 0.0f);
+                         k < L ? 1.0f : 0.5f, k < L ? 1.0f : 0.0f, mu, iv, qpart);
     }
     hipLaunchKernelGGL(k_hmc_end, dim3(n), dim3(256), 0, s, th_c, g_c, t_c, (const float*)thp, (const float*)p,
                        (const float*)gp, (const float*)tprop, (const float*)hc, u ? (const float*)u + c0 : nullptr, P,
