@@ -227,6 +227,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     f32x16 H0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) H0[r] = sigmoid_from_scaled(acc[r]);
+    store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
     // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -243,6 +244,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     f32x16 H1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) H1[r] = sigmoid_from_scaled(acc[r]);
+    store_T(lw + O_TB0, H1, c, h);  // transposed copy for dW2; the logits and the softmax run while it lands
     // ---- F2: logits = W2 H1^T + b2 with the 16-block 4x4x1 product; each half sums its 16 features
     f32x4 lg0 = {0, 0, 0, 0}, lg1 = {0, 0, 0, 0};
 #pragma unroll
@@ -277,7 +279,6 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
       lw[O_D2BUF + 2 * 32 + a2] = d2[2];
       lw[O_D2BUF + 3 * 32 + a2] = 0.0f;
     }
-    store_T(lw + O_TB0, H1, c, h);
     wave_lds_fence();
     // ---- B2(2): dW2[o][k] += sum_n delta2[n][o] H1[n][k]                    (contracts over rows: transposed reads)
 #pragma unroll
@@ -303,7 +304,6 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     }
     wave_lds_fence();
     store_T(lw + O_TB0, D1, c, h);
-    store_T(lw + O_TB1, H0, c, h);
     wave_lds_fence();
     // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
     f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
