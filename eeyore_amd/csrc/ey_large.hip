@@ -264,140 +264,6 @@ __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ out, flo
   if (threadIdx.x == 0) lik_o[c] = lik;
 }
 
-// Narrow output layer, fused ("head"): for one chain, layer K-1 -> K forward, likelihood, output delta, the weight and
-// bias gradients of that layer, and delta_{K-1} = (delta_K W_{K-1}) * act'(H_{K-1}) -- the three skinny products a
-// 128-wide GEMM tile would waste itself on.  Rows are staged 64 at a time in LDS ([row][dH+1]); logits / softmax / dH
-// are row-parallel, the weight gradient is (output, input)-pair-parallel over the staged rows.
-#define HT 64
-__global__ void __launch_bounds__(256) k_head(const float* __restrict__ Hin, float* __restrict__ Dout,
-                                              const float* __restrict__ theta, float* __restrict__ grad, int P, int woff,
-                                              int boff, int N, int dH, int dK, const float* __restrict__ y,
-                                              const int* __restrict__ labels, int lik_code, int act_last, int act_prev,
-                                              int want_grad, float* __restrict__ lik_o) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  __shared__ float red[4];
-  const long c = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int ld = dH + 1;
-  float* W = sm;                    // [dK][dH]
-  float* bsh = W + dK * dH;         // [dK]
-  float* tile = bsh + ((dK + 3) & ~3);  // [HT][ld]
-  float* dk = tile + HT * ld;       // [HT][dK] delta_K of the staged rows
-  const float* th = theta + c * P;
-  for (int i = tid; i < dK * dH; i += 256) W[i] = th[woff + i];
-  for (int i = tid; i < dK; i += 256) bsh[i] = boff >= 0 ? th[boff + i] : 0.0f;
-  const float* Hc = Hin + c * (long)N * dH;
-  float* Dc = Dout + c * (long)N * dH;
-  const int npairs = dK * dH;
-  float accw[8];  // pairs tid, tid+256, ... (npairs <= 2048)
-#pragma unroll
-  for (int q = 0; q < 8; ++q) accw[q] = 0.0f;
-  float accb = 0.0f, lik = 0.0f;
-  for (int r0 = 0; r0 < N; r0 += HT) {
-    const int rows = min(HT, N - r0);
-    __syncthreads();
-    for (int i = tid; i < rows * dH; i += 256) {
-      const int r = i / dH, k = i - r * dH;
-      tile[r * ld + k] = Hc[(long)(r0 + r) * dH + k];
-    }
-    __syncthreads();
-    // logits, (row, output)-pair-parallel: lgt[r][o] = act(b[o] + sum_k H[r][k] W[o][k])
-    for (int pidx = tid; pidx < rows * dK; pidx += 256) {
-      const int r = pidx / dK, o = pidx - r * dK;
-      const float* hr = tile + r * ld;
-      const float* wr = W + o * dH;
-      float a = bsh[o];
-      for (int k = 0; k < dH; ++k) a += hr[k] * wr[k];
-      dk[pidx] = l_act(act_last, a);
-    }
-    __syncthreads();
-    if (tid < rows) {  // one row per thread: likelihood and delta_K (overwrites the logits in place)
-      float* lg = dk + tid * dK;
-      const int n = r0 + tid;
-      if (lik_code == EY_LIK_BCE_SUM) {
-        for (int o = 0; o < dK; ++o) {
-          const float pz = lg[o], yy = y[(long)n * dK + o];
-          lik += __logf(pz) * yy + __logf(1.0f - pz) * (1.0f - yy);
-          lg[o] = (yy / pz - (1.0f - yy) / (1.0f - pz)) * l_dact(act_last, pz);
-        }
-      } else {
-        const int lab = labels[n];
-        float mx = lg[0];
-        for (int o = 1; o < dK; ++o) mx = fmaxf(mx, lg[o]);
-        float ssum = 0.0f;
-        for (int o = 0; o < dK; ++o) ssum += __expf(lg[o] - mx);
-        const float llab = lg[lab];
-        const float rs = 1.0f / ssum;
-        for (int o = 0; o < dK; ++o)
-          lg[o] = ((o == lab ? 1.0f : 0.0f) - __expf(lg[o] - mx) * rs) * l_dact(act_last, lg[o]);
-        lik += llab - (mx + __logf(ssum));
-      }
-    }
-    __syncthreads();
-    if (want_grad) {
-      // dW[o][k] += sum_r delta_K[r][o] H[r][k]   (pair-parallel), db[o] += sum_r delta_K[r][o]
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int pidx = tid + 256 * q;
-        if (pidx < npairs) {
-          const int o = pidx / dH, k = pidx - o * dH;
-          float a = 0.0f;
-          for (int r = 0; r < rows; ++r) a += dk[r * dK + o] * tile[r * ld + k];
-          accw[q] += a;
-        }
-      }
-      if (tid < dK) {
-        float a = 0.0f;
-        for (int r = 0; r < rows; ++r) a += dk[r * dK + tid];
-        accb += a;
-      }
-      __syncthreads();
-      // delta_{K-1}[r][k] = (sum_o delta_K[r][o] W[o][k]) * act'(H[r][k]), (row, k)-parallel, in place; then to HBM
-      for (int i = tid; i < rows * dH; i += 256) {
-        const int r = i / dH, k = i - r * dH;
-        const float* dr = dk + r * dK;
-        float a = 0.0f;
-        for (int o = 0; o < dK; ++o) a += dr[o] * W[o * dH + k];
-        const float hv = tile[r * ld + k];
-        Dc[(long)(r0 + r) * dH + k] = a * l_dact(act_prev, hv);
-      }
-    }
-  }
-  if (want_grad) {
-    float* gc = grad + c * P;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int pidx = tid + 256 * q;
-      if (pidx < npairs) gc[woff + pidx] = accw[q];
-    }
-    if (tid < dK && boff >= 0) gc[boff + tid] = accb;
-  }
-  lik = block_sum(lik, red);
-  if (tid == 0) lik_o[c] = lik;
-}
-
-static bool head_ok(const EyModel& m) {
-  const int K = m.nl;
-  (void)K;
-  return false;  // measured slower than three narrow-tile GEMMs + k_loss (LDS-bound VALU); kept for reference
-}
-static size_t head_lds(const EyModel& m) {
-  const int dK = m.dims[m.nl], dH = m.dims[m.nl - 1];
-  return sizeof(float) * ((size_t)dK * dH + ((dK + 3) & ~3) + (size_t)HT * (dH + 1) + (size_t)HT * dK);
-}
-
-// db[c][j] = sum_n delta[c][n][j]
-__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ delta, int N, int d, float* __restrict__ grad,
-                                                long gstride) {
-  const long c = blockIdx.y;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= d) return;
-  const float* dl = delta + c * (long)N * d;
-  float a = 0.0f;
-  for (int n = 0; n < N; ++n) a += dl[n * d + j];
-  grad[c * gstride + j] = a;
-}
-
 // prior value, temperature, log-target; one block per chain
 __global__ void __launch_bounds__(256) k_prior(const float* __restrict__ theta, const float* __restrict__ mu,
                                                const float* __restrict__ iv, float prior_const, int P,
@@ -570,9 +436,7 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     }
   }
   int rc;
-  const bool head = head_ok(m);
-  const int Kf = head ? K - 1 : K;  // layers run as GEMMs in the forward pass
-  for (int l = 0; l < Kf; ++l) {
+  for (int l = 0; l < K; ++l) {
     BG g = {};
     g.A = l == 0 ? (const float*)m.x : H[l];
     g.B = theta + m.woff[l];
@@ -585,23 +449,9 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     g.act = m.act[l];
     if ((rc = bgemm(g, C, s))) return rc;
   }
-  int ltop;  // first layer whose gradients still have to be produced by the GEMM loop below
-  if (head) {
-    static size_t attr_bytes = 48 * 1024;
-    if (head_lds(m) > attr_bytes) {
-      EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_head), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)head_lds(m)));
-      attr_bytes = head_lds(m);
-    }
-    hipLaunchKernelGGL(k_head, dim3(C), dim3(256), head_lds(m), s, (const float*)H[K - 1], D[K - 1], theta, grad, P,
-                       m.woff[K - 1], m.boff[K - 1], N, m.dims[K - 1], m.dims[K], (const float*)m.y, m.labels, m.lik,
-                       m.act[K - 1], m.act[K - 2], grad ? 1 : 0, lik_tmp);
-    ltop = K - 2;
-  } else {
-    hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
-                       m.dims[K], m.lik, m.act[K - 1], lik_tmp);
-    ltop = K - 1;
-  }
+  hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
+                     m.dims[K], m.lik, m.act[K - 1], lik_tmp);
+  const int ltop = K - 1;
   if (grad) {
     for (int l = ltop; l >= 0; --l) {
       BG g = {};  // dW_l = delta_{l+1}^T H_l, db_l = row sums of delta_{l+1}^T
