@@ -1,7 +1,7 @@
 import torch
 
 from .base import SingleChainSerialSampler, default_counter
-from eeyore_amd.tuners import HMCDATuner
+from eeyore_amd.tuners import HMCDATuner, PerChainDATuner
 from eeyore_amd import _lib as L
 
 
@@ -36,6 +36,8 @@ class HMC(SingleChainSerialSampler):
             else:
                 self.step = tuner.e0
             self.num_steps = tuner.num_steps(self.step)
+        elif isinstance(tuner, PerChainDATuner):
+            self.step, self.num_steps = tuner.e0.clone(), tuner.num_steps()
         if theta0 is not None:
             self.set_current(theta0.clone().detach(), data=data0)
 
@@ -109,6 +111,9 @@ class HMC(SingleChainSerialSampler):
             last_burnin = self.counter.idx == self.counter.num_burnin_iters - 1
             self.step, self.num_steps = self.tuner.tune(out['rate'].mean().item(), self.counter.idx,
                                                         return_e=not last_burnin)
+        elif isinstance(self.tuner, PerChainDATuner) and self.counter.idx < self.counter.num_burnin_iters:
+            last_burnin = self.counter.idx == self.counter.num_burnin_iters - 1
+            self.step, _ = self.tuner.tune(out['rate'], self.counter.idx, return_e=not last_burnin)
         self._iter += 1
         self.last = out
         if savestate:

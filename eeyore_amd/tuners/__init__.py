@@ -1,1 +1,1 @@
-from .dual_averaging import HMCDATuner, Tuner
+from .dual_averaging import HMCDATuner, PerChainDATuner, Tuner

@@ -39,3 +39,39 @@ class HMCDATuner(Tuner):
         self.logbare += eta * (loge - self.logbare)
         e = math.exp(loge if return_e else self.logbare)
         return e, self.num_steps(e)
+
+
+class PerChainDATuner(Tuner):
+    """Dual averaging with one step size PER CHAIN: the recurrence of ``HMCDATuner`` applied
+    elementwise to a [C] tensor on the device, fed with the per-chain acceptance rates a fused HMC step returns.  The
+    number of leapfrog steps stays fixed (all chains share one launch), so only the step size adapts; the result goes
+    to the kernels as their per-chain ``step_vec``."""
+
+    gamma, t0, kappa = 0.05, 10, 0.75
+
+    def __init__(self, e0, num_steps, d=0.65, eub=None):
+        import torch
+        self._torch = torch
+        self.e0 = e0.clone()
+        self.fixed_num_steps = int(num_steps)
+        self.d = d
+        self.m = torch.log(10 * e0)
+        self.logeub = None if eub is None else math.log(eub)
+        self.logbare = torch.zeros_like(e0)
+        self.barh = torch.zeros_like(e0)
+
+    def num_steps(self, e=None):
+        return self.fixed_num_steps
+
+    def tune(self, rate, idx, return_e=True):
+        """``rate`` [C]: this iteration's acceptance rates.  Returns (step [C], num_steps)."""
+        torch = self._torch
+        it = idx + 1
+        w = 1.0 / (it + self.t0)
+        rate = torch.nan_to_num(rate.to(self.barh.dtype), nan=0.0)
+        self.barh += w * ((self.d - rate) - self.barh)
+        loge = self.m - math.sqrt(it) / self.gamma * self.barh
+        if self.logeub is not None:
+            loge = torch.clamp(loge, max=self.logeub)
+        self.logbare += it ** (-self.kappa) * (loge - self.logbare)
+        return torch.exp(loge if return_e else self.logbare), self.fixed_num_steps

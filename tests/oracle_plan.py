@@ -78,8 +78,17 @@ class OraclePlan:
         assert p0 is not None and u is not None, "the test double has no in-kernel RNG"
         co = self._oracle(temp)
         th, tv, g = theta.numpy(), target.numpy(), grad.numpy()  # share memory with the tensors: updated in place
-        acc, hc, hp = co.hmc_draw(th, tv, g, np.ascontiguousarray(p0.numpy()), np.ascontiguousarray(u.numpy()),
-                                  float(step), int(num_steps))
+        if step_vec is not None:  # per-chain step sizes: one oracle call per chain
+            C = th.shape[0]
+            acc, hc, hp = np.zeros(C, np.uint8), np.zeros(C, self.np_dtype), np.zeros(C, self.np_dtype)
+            for c in range(C):
+                tc, vc, gc = th[c:c + 1].copy(), tv[c:c + 1].copy(), g[c:c + 1].copy()
+                a, b, d = co.hmc_draw(tc, vc, gc, np.ascontiguousarray(p0.numpy()[c:c + 1]),
+                                      np.ascontiguousarray(u.numpy()[c:c + 1]), float(step_vec[c]), int(num_steps))
+                th[c], tv[c], g[c], acc[c], hc[c], hp[c] = tc[0], vc[0], gc[0], a[0], b[0], d[0]
+        else:
+            acc, hc, hp = co.hmc_draw(th, tv, g, np.ascontiguousarray(p0.numpy()), np.ascontiguousarray(u.numpy()),
+                                      float(step), int(num_steps))
         with np.errstate(over="ignore", invalid="ignore"):
             rate = np.minimum(np.exp(hc - hp), 1)
         return dict(accepted=torch.as_tensor(acc), rate=self._t(rate), h_cur=self._t(hc), h_prop=self._t(hp))

@@ -721,3 +721,29 @@ def test_config5_shape_mnist_like_model_runs_on_bgemm_path():
     np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=1e-3)
     np.testing.assert_allclose(th.cpu().numpy()[out["accepted"].cpu().numpy() == acc],
                                tho[out["accepted"].cpu().numpy() == acc], rtol=2e-3, atol=2e-4)
+
+
+def test_per_chain_dual_averaging_on_the_mfma_model():
+    """Per-chain step-size adaptation: chains started with very different steps all end near the
+    target acceptance of 0.65."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    from eeyore_amd.tuners import PerChainDATuner
+    data = synthetic.iris_shaped(dtype=torch.float32, device=DEV)
+    hp = mlp.Hyperparameters(dims=[4, 32, 32, 3], bias=3 * [True], activations=[torch.sigmoid, torch.sigmoid, None])
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'], hparams=hp, dtype=torch.float32, device=DEV)
+    P = model.num_params()
+    model.prior = Normal(torch.zeros(P, device=DEV), (3 * torch.ones(P, device=DEV)).sqrt())
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    C = 256
+    e0 = torch.logspace(-3, -1.2, C, device=DEV)
+    s = HMC(model, theta0=0.1 * torch.randn(C, P, device=DEV), dataloader=loader,
+            tuner=PerChainDATuner(e0, num_steps=10, eub=0.2), seed=3)
+    s.run(num_epochs=260, num_burnin_epochs=200)
+    acc = s.get_chain().acceptance_rate()
+    assert s.step.shape == (C,) and s.step.max() / s.step.min() < 5  # started a factor 63 apart
+    assert 0.45 < acc.mean().item() < 0.85

@@ -281,3 +281,36 @@ def test_hmc_with_dual_averaging_tuner_adapts_step():
     s.run(num_epochs=60, num_burnin_epochs=40)
     assert s.step != first and s.num_steps == max(1, round(2.0 / s.step))
     assert len(s.get_chain()) == 20 and 0.2 < s.get_chain().acceptance_rate() <= 1.0
+
+
+def test_per_chain_dual_averaging_matches_scalar_tuner_elementwise():
+    from eeyore_amd.tuners import HMCDATuner, PerChainDATuner
+    e0 = torch.tensor([0.05, 0.2, 0.7], dtype=torch.float64)
+    batched = PerChainDATuner(e0, num_steps=7, d=0.65, eub=1.0)
+    scalars = [HMCDATuner(l=1.0, e0=float(e), d=0.65, eub=1.0) for e in e0]
+    rng = np.random.default_rng(0)
+    for idx in range(12):
+        rates = rng.random(3)
+        last = idx == 11
+        got, L = batched.tune(torch.tensor(rates), idx, return_e=not last)
+        want = [s.tune(r, idx, return_e=not last)[0] for s, r in zip(scalars, rates)]
+        np.testing.assert_allclose(got.numpy(), want, rtol=1e-12)
+        assert L == 7
+
+
+def test_hmc_with_per_chain_tuner_adapts_each_chain():
+    from eeyore_amd.tuners import PerChainDATuner
+    rec = groups(load("g4_hmc_traces.npz"))["mlp2321"]
+    m = _model_from(rec)
+    ds = XYDataset(torch.tensor(rec["x"]), torch.tensor(rec["y"]))
+    loader = DataLoader(ds, batch_size=len(ds), shuffle=False)
+    torch.manual_seed(1)
+    C = 5
+    th0 = 0.3 * torch.randn(C, 20, dtype=torch.float64)
+    e0 = torch.tensor([0.05, 0.1, 0.3, 0.8, 2.0], dtype=torch.float64)
+    s = HMC(m, theta0=th0, dataloader=loader, tuner=PerChainDATuner(e0, num_steps=6), rng='torch')
+    assert torch.equal(s.step, e0) and s.num_steps == 6
+    s.run(num_epochs=50, num_burnin_epochs=40)
+    assert s.step.shape == (C,) and not torch.equal(s.step, e0)
+    assert s.step.max() / s.step.min() < e0.max() / e0.min()  # very different starts move towards each other
+    assert s.get_chain().get_samples().shape == (10, C, 20)
