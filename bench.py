@@ -31,6 +31,7 @@ L_STEPS = 20
 CHAINS_PER_GPU = 4096
 STEP_SIZE = 0.024  # ~70 % acceptance after burn-in on this target (tools/step_sweep.py: 0.02 -> 0.87, 0.03 -> 0.40)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+MEASURED_F32_MFMA_TFLOPS = 145.9  # tools/peak_probe.hip on the box (profiles/r01_peak_probe.txt): the sustained clock
 
 
 def flops_per_leapfrog_step(dims, n_rows):
@@ -184,6 +185,7 @@ def main():
                 "bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                 "kernel_ms": kern_ms, "flops_per_leapfrog_step_per_chain": f_step,
+                "peak_measured": MEASURED_F32_MFMA_TFLOPS, "frac_of_measured": achieved_tflops / MEASURED_F32_MFMA_TFLOPS,
             },
         }
         # HBM traffic of the dominant kernel from the committed PMC passes (tools/pmc_passes.sh; separate --pmc runs,
