@@ -2,6 +2,7 @@
 // families.  No torch types cross this boundary.
 #include <math.h>
 
+#include <cstring>
 #include <vector>
 
 #include "ey_common.h"
@@ -161,6 +162,8 @@ int ey_plan_set_prior(ey_plan* pl, const void* mu, const void* sigma, void* stre
   std::vector<unsigned char> hs(es * P);
   EY_HIP(hipMemcpyAsync(pl->d_mu, mu, es * P, hipMemcpyDeviceToDevice, s));
   EY_HIP(hipMemcpyAsync(hs.data(), sigma, es * P, hipMemcpyDeviceToHost, s));
+  std::vector<unsigned char> hm(es * P);
+  EY_HIP(hipMemcpyAsync(hm.data(), mu, es * P, hipMemcpyDeviceToHost, s));
   EY_HIP(hipStreamSynchronize(s));
   // Normal.log_prob = -(v-mu)^2/(2 sigma^2) - log(sigma) - log(sqrt(2 pi)); the theta-independent part is
   // summed once here (in double), the quadratic part is evaluated per call with 1/sigma^2.
@@ -174,6 +177,11 @@ int ey_plan_set_prior(ey_plan* pl, const void* mu, const void* sigma, void* stre
     else ((double*)hiv.data())[i] = 1.0 / (sg * sg);
   }
   EY_HIP(hipMemcpy(pl->d_inv_var, hiv.data(), es * P, hipMemcpyHostToDevice));
+  // one (mu, sigma) for every parameter (the usual N(0, s) prior): the fused kernel then needs no per-element loads
+  pl->prior_uniform = P > 0 && memcmp(hm.data(), hm.data() + es, es * (P - 1)) == 0 &&
+                      memcmp(hiv.data(), hiv.data() + es, es * (P - 1)) == 0;
+  pl->prior_mu0 = es == 4 ? (double)((const float*)hm.data())[0] : ((const double*)hm.data())[0];
+  pl->prior_iv0 = es == 4 ? (double)((const float*)hiv.data())[0] : ((const double*)hiv.data())[0];
   m.mu = pl->d_mu;
   m.inv_var = pl->d_inv_var;
   m.prior_const = c;

@@ -55,6 +55,8 @@ struct ey_plan {
   int device;
   bool has_data, has_prior;
   void *d_x, *d_y, *d_mu, *d_inv_var;
+  bool prior_uniform = false;  // every parameter has the same (mu, sigma)
+  double prior_mu0 = 0.0, prior_iv0 = 0.0;
   int* d_labels;
   // mfma32 path (4-32-32-3-like models, f32): padded/packed data image
   bool mfma32_ok;

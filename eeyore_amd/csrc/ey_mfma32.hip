@@ -23,6 +23,7 @@
 //   w1[4q+j] = W1[out = 8q+4h+j][in = c]   (the D layout of dW1 and the A operand of dH0 = W1^T delta1)
 //   w0[i]    = W0[out = 4(c>>2)+i][in = c&3]  (D layout of the 4x4x1 product; both halves hold the same values)
 //   w2[o]    = W2[o][k = c]                 (ditto)      b1 = b1[c], b0 = b0[c], b2[o] uniform
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -31,7 +32,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define MF_MAX_TILES 12
+#define MF_MAX_TILES 24  // 27 KB data image + 8 x 16.3 KB per-wave regions fit the 160 KB of a CU
 // per-wave LDS carve, in floats (all offsets multiples of 4 => 16-byte aligned b128 accesses)
 #define TS36 36
 #define O_W1IMG 0
@@ -61,6 +62,8 @@ struct MfArgs {
   const float* xpack;  // [ntiles][288]
   const float* mu;
   const float* inv_var;
+  int prior_uniform;   // all parameters share (mu0, iv0): no per-element prior loads
+  float mu0, iv0;
   float prior_const;
   int ntiles;
   int64_t C;
@@ -80,7 +83,11 @@ struct MfArgs {
   int recompute;
   unsigned char* accepted;
   float *rate, *hcur, *hprop;
+  int balance;         // 1: the two waves of a SIMD keep in step through s_setprio (see Pace)
 };
+
+// The arguments as the kernels read them: in place in the kernarg segment (constant address space, scalar loads).
+typedef const __attribute__((address_space(4))) MfArgs KArgs;
 
 struct Vec {
   float w1[16];
@@ -90,12 +97,28 @@ struct Vec {
   float b2[3];
 };
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Wave reductions without LDS traffic.  wsum: DPP adds inside each 16-lane row (quad swaps, half-mirror, mirror), then
+// row_bcast:15 / row_bcast:31 carry the row totals up so that lane 63 holds the wave total, which v_readlane returns
+// as a uniform value.  hsum(v) = v + (v of lane^32) in every lane: v_permlane32_swap_b32 on two copies of v leaves
+// (low half, low half) and (high half, high half).  (Inline asm: this compiler's builtin drops the second result.)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
 }
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float wsum(float v) {
+  v += dpp_get<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_get<0x140, 0xF>(v);  // row_mirror: every lane of a row holds the row total
+  v += dpp_get<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float hsum(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
 // The staged images of W0, b0, W1, b1 carry the factor -log2(e), so the accumulator holds -g*log2(e) and
 // sigmoid(g) = 1 / (1 + 2^acc): one v_exp_f32, one v_add_f32, one v_rcp_f32 per element.
 #define NEG_LOG2E (-1.4426950408889634f)
@@ -103,6 +126,21 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); 
 // 4 = no transcendental in the sigmoid, 8 = no dW1 product.  Results are wrong in such a build; only its timing is read.
 #ifndef EY_ABLATE
 #define EY_ABLATE 0
+#endif
+// EY_PHASE_TIMING (diagnostic builds only, tools/phase_timing.py): per-phase s_memtime sums of the tile loop.
+#ifndef EY_PHASE_TIMING
+#define EY_PHASE_TIMING 0
+#endif
+#if EY_PHASE_TIMING
+__device__ unsigned long long g_ey_phase[32];
+__device__ int g_ey_dbg[64];
+__device__ unsigned long long g_ey_wave_t[3 * 8192];  // per chain: kernel entry, wave start, wave end (s_memrealtime)
+// s_memtime is served by one global unit (~2 ns per call over the whole chip): only one wave in 256 reads it
+#define PH(i) do { if (ph_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += n_ - ph_t; ph_t = n_; } } while (0)
+#define KO(i) do { if (kt_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ko_acc[i] += n_ - ko_t; ko_t = n_; } } while (0)
+#else
+#define PH(i) do { } while (0)
+#define KO(i) do { } while (0)
 #endif
 __device__ __forceinline__ float sigmoid_from_scaled(float a) {
   if (EY_ABLATE & 4) return a * 0.01f + 0.5f;
@@ -199,9 +237,39 @@ __device__ __forceinline__ void store_T(float* tb, const f32x16& v, int c, int h
   for (int r = 0; r < 16; ++r) tb[(8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = v[r];
 }
 
+// Keeping the two waves of a SIMD in step.  The instruction arbiter serves the OLDER of two ready waves, so of two
+// chains sharing a SIMD one runs at nearly its stand-alone speed and the other on what is left (measured with
+// tools/wave_timeline.py: lifetimes 417 vs 632 us); at the end of the launch the late waves then run alone, and a wave
+// alone uses the ALU far less than two do.  Each wave therefore publishes in LDS how many row tiles it still has to
+// evaluate in this launch and, once per tile, compares with its SIMD partner: the wave with less left drops to
+// priority 0, the other takes priority 1, so the two waves of a SIMD finish the launch together whatever their
+// numbers of chains.  The partner's counter is read at the top of a tile and consumed in the middle of it, so the
+// LDS latency is never waited for.
+struct Pace {
+  int* prog;    // [waves] tiles left, per wave of this workgroup
+  int wave, partner;
+  int left;
+  bool on;
+};
+__device__ __forceinline__ int pace_post(Pace& pc, int lane) {
+  if (!pc.on) return 0;
+  pc.left = __builtin_amdgcn_readfirstlane(pc.left - 1);
+  if (lane == 0) __hip_atomic_store(&pc.prog[pc.wave], pc.left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __hip_atomic_load(&pc.prog[pc.partner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
+  if (!pc.on) return;
+  // (scalar comparison: a vector compare would be lowered to EXEC masking, under which both s_setprio would execute)
+  const int theirs = __builtin_amdgcn_readfirstlane(theirs_v);
+  if (pc.left < theirs) __builtin_amdgcn_s_setprio(0);
+  else __builtin_amdgcn_s_setprio(1);
+}
+
 // log-target and gradient of the position whose images are staged in lw.  Returns the (tempered) log-target.
-__device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec& g, bool has_temp, float temp, int c,
-                      int h, int lane) {
+// `need_value` (wave-uniform) = false skips the value-only work (row log-sum-exp terms, quadratic form of the prior
+// and their reductions): inside a trajectory only the gradient is consumed, hmc.py:108-121.
+__device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, bool has_temp, float temp, int c,
+                      int h, int lane, bool need_value, Pace& pc) {
   const int jj = lane & 3;
   f32x16 dW1;
 #pragma unroll
@@ -209,9 +277,15 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
   f32x4 dW0a = {0, 0, 0, 0}, dW0b = {0, 0, 0, 0}, dW2a = {0, 0, 0, 0}, dW2b = {0, 0, 0, 0};
   float db1 = 0.0f, db0 = 0.0f, db2[3] = {0.0f, 0.0f, 0.0f}, lik = 0.0f;
 
+#if EY_PHASE_TIMING
+  unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool ph_on = (blockIdx.x & 63) == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+  unsigned long long ph_t = ph_on ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
 #pragma unroll 1
   for (int t = 0; t < A.ntiles; ++t) {
     const float* xt = xs + t * XTILE_FLOATS;
+    const int pace_theirs = pace_post(pc, lane);
     // ---- F0: H0^T = sigmoid(W0 X^T + b0)                                  (mlp.py:45-50)
     f32x16 acc;
 #pragma unroll
@@ -228,6 +302,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
 #pragma unroll
     for (int r = 0; r < 16; ++r) H0[r] = sigmoid_from_scaled(acc[r]);
     store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
+    PH(0);
     // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -241,10 +316,12 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], H0[4 * q + j], acc, 0, 0, 0);
     }
+    pace_apply(pc, pace_theirs);  // while the F1 products run
     f32x16 H1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) H1[r] = sigmoid_from_scaled(acc[r]);
     store_T(lw + O_TB0, H1, c, h);  // transposed copy for dW2; the logits and the softmax run while it lands
+    PH(1);
     // ---- F2: logits = W2 H1^T + b2 with the 16-block 4x4x1 product; each half sums its 16 features
     f32x4 lg0 = {0, 0, 0, 0}, lg1 = {0, 0, 0, 0};
 #pragma unroll
@@ -256,15 +333,16 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
       lg1 = mfma4(wv[3], H1[4 * q + 3], lg1);
     }
     float l0 = lg0[0] + lg1[0], l1 = lg0[1] + lg1[1], l2 = lg0[2] + lg1[2];
-    l0 += xhalf(l0); l1 += xhalf(l1); l2 += xhalf(l2);
+    l0 = hsum(l0); l1 = hsum(l1); l2 = hsum(l2);
     l0 += th.b2[0]; l1 += th.b2[1]; l2 += th.b2[2];
+    PH(2);
     // ---- CE-sum log-likelihood and output delta = onehot - softmax           (constants.py:17)
     const bool valid = lab >= 0;
     const float mx = fmaxf(l0, fmaxf(l1, l2));
     const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx), e2 = __expf(l2 - mx);
     const float ssum = e0 + e1 + e2;
     const float llab = lab == 0 ? l0 : (lab == 1 ? l1 : l2);
-    if (valid && h == 0) lik += llab - (mx + __logf(ssum));
+    if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
     const float rs = __builtin_amdgcn_rcpf(ssum);
     float d2[3];
     d2[0] = valid ? ((lab == 0 ? 1.0f : 0.0f) - e0 * rs) : 0.0f;
@@ -280,6 +358,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
       lw[O_D2BUF + 3 * 32 + a2] = 0.0f;
     }
     wave_lds_fence();
+    PH(3);
     // ---- B2(2): dW2[o][k] += sum_n delta2[n][o] H1[n][k]                    (contracts over rows: transposed reads)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -290,6 +369,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
       dW2a = mfma4(du[2], hu[2], dW2a);
       dW2b = mfma4(du[3], hu[3], dW2b);
     }
+    PH(4);
     // ---- B1(2): dH1^T = W2^T delta2^T, delta1 = dH1 * H1 (1 - H1)
     f32x16 D1;
 #pragma unroll
@@ -302,9 +382,11 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
 #pragma unroll
       for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i] * __builtin_fmaf(-H1[4 * q + i], H1[4 * q + i], H1[4 * q + i]);
     }
+    PH(5);
     wave_lds_fence();
     store_T(lw + O_TB0, D1, c, h);
     wave_lds_fence();
+    PH(6);
     // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
     f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
 #pragma unroll
@@ -319,6 +401,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
       }
       db1 += (du[0] + du[1]) + (du[2] + du[3]);
     }
+    PH(7);
     // ---- B1(1): dH0 = delta1 W1 computed UNtransposed (A = delta1 tile with M = rows, B = theta's own W1
     // registers), so its accumulator is already lane <-> input feature, register <-> row: delta0 = dH0 * H0 (1 - H0)
     // comes out in the layout the dW0 product needs, with no LDS round trip (layer 0 is the last consumer).
@@ -329,6 +412,7 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
     f32x16 D0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) D0u[r] = acc[r] * __builtin_fmaf(-H0U[r], H0U[r], H0U[r]);
+    PH(8);
     // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
     const float* x2 = xt + 160 + (jj * 2 + h) * 16;
 #pragma unroll
@@ -342,58 +426,73 @@ __device__ float eval(const MfArgs& A, const float* xs, float* lw, Vec& th, Vec&
       db0 += (du[0] + du[1]) + (du[2] + du[3]);
     }
     wave_lds_fence();
+    PH(9);
   }
   // ---- combine the two row-parity halves and the lanes
 #pragma unroll
   for (int r = 0; r < 16; ++r) g.w1[r] = dW1[r];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float v = dW0a[i] + dW0b[i];
-    g.w0[i] = v + xhalf(v);
+    g.w0[i] = hsum(dW0a[i] + dW0b[i]);
   }
 #pragma unroll
   for (int o = 0; o < 3; ++o) {
-    const float v = dW2a[o] + dW2b[o];
-    g.w2[o] = v + xhalf(v);
+    g.w2[o] = hsum(dW2a[o] + dW2b[o]);
     g.b2[o] = wsum(db2[o]);
   }
-  g.b1 = db1 + xhalf(db1);
-  g.b0 = db0 + xhalf(db0);
-  lik = wsum(lik);
+  g.b1 = hsum(db1);
+  g.b0 = hsum(db0);
   // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
   float qsum = 0.0f;
-  for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int idx, bool counts) {
-    const float d = tv - A.mu[idx];
-    const float iv = A.inv_var[idx];
-    if (counts) qsum += d * d * iv;
-    float gn = gv - d * iv;
-    if (has_temp) gn *= temp;
-    gv = gn;
-  });
-  qsum = wsum(qsum);
-  float prior = A.prior_const - 0.5f * qsum;
+  if (A.prior_uniform) {
+    const float mu0 = A.mu0, iv0 = A.iv0;
+    for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int, bool counts) {
+      const float d = tv - mu0;
+      if (counts) qsum += d * d * iv0;
+      float gn = gv - d * iv0;
+      if (has_temp) gn *= temp;
+      gv = gn;
+    });
+  } else {
+    for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int idx, bool counts) {
+      const float d = tv - A.mu[idx];
+      const float iv = A.inv_var[idx];
+      if (counts) qsum += d * d * iv;
+      float gn = gv - d * iv;
+      if (has_temp) gn *= temp;
+      gv = gn;
+    });
+  }
+  float prior = 0.0f;
+  if (need_value) {
+    lik = wsum(lik);
+    prior = A.prior_const - 0.5f * wsum(qsum);
+  }
   if (has_temp) { lik *= temp; prior *= temp; }
+#if EY_PHASE_TIMING
+  if (ph_on) {
+    const float keep = lik + prior + g.w1[0] + g.b1;  // the epilogue's results must exist before the clock is read
+    if (keep == 1.2345e-30f) g.b0 += 1.0f;
+  }
+  PH(10);
+  if (ph_on && lane == 0) {
+    for (int i = 0; i < 11; ++i) atomicAdd(&g_ey_phase[i], ph_acc[i]);
+    atomicAdd(&g_ey_phase[15], 1ull);
+  }
+#endif
   return lik + prior;
 }
 
-// WAVES chains per workgroup (4: two workgroups per CU; 8: one).  Either way two waves share a SIMD: f32 MFMA runs
-// on the vector ALUs, so the partner wave hides latency (LDS round trips, MFMA result latency) rather than adding
-// throughput (tools/coexec_probe*.hip); raising one wave's priority with s_setprio changed nothing and was removed.
-template <int MODE, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
-  constexpr int MF_WAVES = WAVES, MF_THREADS = WAVES * 64;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 31, h = lane >> 5;
-  // shared, read-only data images
-  const int xfloats = A.ntiles * XTILE_FLOATS;
-  for (int i = tid; i < xfloats; i += MF_THREADS) smem[i] = A.xpack[i];
-  __syncthreads();
-  const float* xs = smem;
-  float* lw = smem + xfloats + wave * WAVE_FLOATS;
-  const int64_t chain = (int64_t)blockIdx.x * MF_WAVES + wave;
-  if (chain >= A.C) return;  // whole wave; no further block-level synchronisation below
+// One chain of one launch: everything between reading theta and writing the accepted state back.
+template <int MODE>
+__device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int c,
+                                          const int h, const int lane, Pace& pc) {
+#if EY_PHASE_TIMING
+  const bool kt_on = (blockIdx.x & 63) == 0 && pc.wave == 0;
+  if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain + 1] = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long kt0 = kt_on ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long ko_acc[6] = {0, 0, 0, 0, 0, 0}, ko_t = kt0;
+#endif
   float* thg = A.theta + chain * NPAR;
   float* grg = A.grad + chain * NPAR;
   const bool has_temp = A.temp != nullptr;
@@ -405,7 +504,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
 
   if (MODE == MODE_GRAD) {
     write_images(lw, th, c, h);
-    const float t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane);
+    const float t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
     for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
     if (lane == 0) A.target[chain] = t;
     return;
@@ -432,7 +531,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
       }
     });
     write_images(lw, p, c, h);
-    const float tv = eval(A, xs, lw, p, gp, has_temp, temp, c, h, lane);
+    const float tv = eval(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
     float log_rate = tv - A.target[chain];  // symmetric kernel: metropolis_hastings.py:50
     if (MODE == MODE_MALA) {
       float qb = 0.0f;
@@ -478,17 +577,22 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   float t = t_cur;
   if (MODE == MODE_LEAPFROG || A.recompute) {  // hmc.py:104
     write_images(lw, th, c, h);
-    t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane);
+    t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
   }
   // leapfrog, hmc.py:100-124 (grad_potential = -grad)
   for_each2(p, g, [&](float& pv, float& gv) { pv = pv + 0.5f * eps * gv; });
 #pragma unroll 1
+  KO(0);
   for (int k = 1; k <= A.L; ++k) {
     for_each2(th, p, [&](float& tv, float& pv) { tv = tv + eps * pv; });
+    KO(1);
     write_images(lw, th, c, h);
-    t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane);
+    KO(2);
+    t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc);
+    KO(3);
     const float w = (k < A.L) ? eps : 0.5f * eps;
     for_each2(p, g, [&](float& pv, float& gv) { pv = pv + w * gv; });
+    KO(4);
   }
 
   if (MODE == MODE_LEAPFROG) {
@@ -520,6 +624,84 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
     if (A.hcur) A.hcur[chain] = h_cur;
     if (A.hprop) A.hprop[chain] = h_prop;
   }
+#if EY_PHASE_TIMING
+  if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain + 2] = __builtin_amdgcn_s_memrealtime();
+  KO(5);
+  if (kt_on && lane == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_ey_phase[16 + i], ko_acc[i]);
+    atomicAdd(&g_ey_phase[11], __builtin_amdgcn_s_memtime() - kt0);
+    atomicAdd(&g_ey_phase[14], 1ull);
+  }
+#endif
+}
+
+// Persistent launch: one 8-wave workgroup per CU (two waves per SIMD), every wave walks over chains
+// blockIdx + gridDim*wave, + 8*gridDim, ...  so a wave starts its next chain the moment it finishes one (no workgroup
+// re-dispatch between rounds, the data image is staged once) and a partial last round spreads one wave per SIMD.
+// Two waves share a SIMD because f32 MFMA runs on the vector ALUs: the partner hides latency (LDS round trips, MFMA
+// result latency) rather than adding throughput (tools/coexec_probe*.hip).  WAVES = 4 is the former layout (two
+// 4-wave workgroups per CU, one chain per wave), kept for A/B runs (ey_debug_set_variant bit 0).
+template <int MODE, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
+  constexpr int MF_WAVES = WAVES, MF_THREADS = WAVES * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: chain index and addresses stay scalar
+  const int c = lane & 31, h = lane >> 5;
+#if EY_PHASE_TIMING
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+  // shared, read-only data images
+  const int xfloats = A.ntiles * XTILE_FLOATS;
+  for (int i = tid; i < xfloats; i += MF_THREADS) smem[i] = A.xpack[i];
+  const float* xs = smem;
+  float* lw = smem + xfloats + wave * WAVE_FLOATS;
+  int* ctl = reinterpret_cast<int*>(smem + xfloats + MF_WAVES * WAVE_FLOATS);  // [waves] counters, [waves] SIMD ids
+  // HW_REG_HW_ID (id 4), SIMD_ID = bits 5:4
+  const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+  if (lane == 0) {
+    ctl[wave] = 0;
+    ctl[MF_WAVES + wave] = simd;
+  }
+  __syncthreads();
+  Pace pc;
+  pc.prog = ctl;
+  pc.wave = wave;
+  pc.partner = wave;
+  pc.left = 0;
+  int mates = 0;
+  for (int w = 0; w < MF_WAVES; ++w)
+    if (w != wave && ctl[MF_WAVES + w] == simd) { pc.partner = w; ++mates; }
+  pc.on = A.balance != 0 && mates == 1;
+#if EY_PHASE_TIMING
+  if (blockIdx.x == 0 && lane == 0) {
+    g_ey_dbg[wave] = simd;
+    g_ey_dbg[8 + wave] = pc.partner;
+    g_ey_dbg[16 + wave] = mates;
+    g_ey_dbg[24 + wave] = (int)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+  }
+#endif
+  const int64_t first = (int64_t)blockIdx.x + (int64_t)gridDim.x * wave, stride = (int64_t)gridDim.x * MF_WAVES;
+  {  // row tiles this wave evaluates in the whole launch
+    const int64_t mine = first < A.C ? (A.C - first + stride - 1) / stride : 0;
+    const int evals = (MODE == MODE_HMC) ? A.L + (A.recompute ? 1 : 0) : (MODE == MODE_LEAPFROG ? A.L + 1 : 1);
+    pc.left = (int)std::min<int64_t>(mine * evals * A.ntiles, 0x3fffffff);
+    if (lane == 0) ctl[wave] = pc.left;
+  }
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(ctl[pc.partner]) == 0) pc.on = false;  // the partner has no chain at all
+  for (int64_t chain = first; chain < A.C; chain += stride) {  // whole waves; no workgroup synchronisation below
+    // Re-read the arguments from the kernarg segment in every round: hoisted out of this loop they would all stay
+    // live in scalar registers for the whole kernel (106 SGPRs, spilled into vector registers, which then spill too).
+    KArgs* Ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(Ap));
+#if EY_PHASE_TIMING
+    if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain] = rt_entry;
+#endif
+    run_chain<MODE>(*Ap, xs, lw, chain, c, h, lane, pc);
+  }
+  if (lane == 0) __hip_atomic_store(&ctl[wave], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // nothing left
 }
 
 // ----------------------------------------------------------------------------------------------- host side
@@ -532,10 +714,11 @@ bool ey_mfma32_supports(const ey_plan* pl) {
 }
 
 static size_t mf_lds_bytes(int ntiles, int waves) {
-  return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * WAVE_FLOATS);
+  return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * WAVE_FLOATS) + sizeof(int) * 2 * waves;
 }
 
-// kernel variant (tuning knob): 1 = 8 chains per workgroup instead of 4
+// kernel variant (A/B knob): bit 0 = former launch shape (4-wave workgroups, one chain per wave), bit 1 = no priority
+// balancing between the two waves of a SIMD
 static int g_variant = 0;
 extern int g_ey_force_large;
 extern "C" int ey_debug_set_variant(int v) {
@@ -549,7 +732,7 @@ extern "C" int ey_debug_set_variant(int v) {
 int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
   const EyModel& m = pl->m;
   const int ntiles = (m.N + 31) / 32;
-  if (ntiles > MF_MAX_TILES) {  // the shared data image would crowd out a second workgroup per CU
+  if (ntiles > MF_MAX_TILES) {  // the shared data image would no longer fit LDS beside the eight per-wave regions
     pl->mfma32_ok = false;
     return EY_OK;
   }
@@ -584,7 +767,7 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
 }
 
 template <int MODE, int WAVES>
-static int mf_launch_v(MfArgs& a, hipStream_t s) {
+static int mf_launch_v(MfArgs& a, int n_cu, hipStream_t s) {
   const size_t bytes = mf_lds_bytes(a.ntiles, WAVES);
   static bool attr_done = false;
   if (!attr_done) {
@@ -592,7 +775,10 @@ static int mf_launch_v(MfArgs& a, hipStream_t s) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_bytes(MF_MAX_TILES, WAVES)));
     attr_done = true;
   }
-  const unsigned grid = (unsigned)((a.C + WAVES - 1) / WAVES);
+  // 8 waves: one persistent workgroup per CU, or one per chain when there are fewer chains than CUs (then only wave
+  // 0 of a workgroup has work and every chain gets a CU to itself); 4 waves: a workgroup per 4 chains
+  const unsigned grid = WAVES == 8 ? (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256)
+                                   : (unsigned)((a.C + WAVES - 1) / WAVES);
   hipLaunchKernelGGL((k_mfma32<MODE, WAVES>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
   EY_HIP(hipGetLastError());
   return EY_OK;
@@ -604,12 +790,16 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.xpack = (const float*)pl->d_xpack;
   a.mu = (const float*)m.mu;
   a.inv_var = (const float*)m.inv_var;
+  a.prior_uniform = pl->prior_uniform ? 1 : 0;
+  a.mu0 = (float)pl->prior_mu0;
+  a.iv0 = (float)pl->prior_iv0;
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
+  a.balance = (g_variant & 2) ? 0 : 1;
   if constexpr (MODE == MODE_HMC) {
-    if (g_variant == 1) return mf_launch_v<MODE, 8>(a, s);
+    if (g_variant & 1) return mf_launch_v<MODE, 4>(a, pl->n_cu, s);
   }
-  return mf_launch_v<MODE, 4>(a, s);
+  return mf_launch_v<MODE, 8>(a, pl->n_cu, s);
 }
 
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
@@ -661,3 +851,20 @@ int ey_mfma32_leapfrog(ey_plan* pl, void* theta, void* p, double step, const voi
   a.step = (float)step; a.step_vec = (const float*)step_vec; a.L = L; a.temp = (const float*)temp;
   return mf_launch<MODE_LEAPFROG>(pl, a, s);
 }
+
+#if EY_PHASE_TIMING
+extern "C" int ey_debug_ints(int* out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ey_dbg), 64 * sizeof(int)) != hipSuccess;
+}
+extern "C" int ey_debug_wave_times(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ey_wave_t), (size_t)n * 3 * sizeof(unsigned long long)) != hipSuccess;
+}
+extern "C" int ey_debug_phase_read(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ey_phase), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ey_phase), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

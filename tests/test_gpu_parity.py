@@ -421,7 +421,7 @@ def test_mfma32_serves_config3_and_matches_generic_kernel():
     assert 0 < oa["accepted"].sum().item() < C
 
 
-@pytest.mark.parametrize("N", [1, 31, 32, 33, 150, 160, 384])
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 150, 160, 384, 768])
 def test_mfma32_row_counts_vs_oracle(N):
     rec, pl = _cfg3_plan(N)
     assert pl.kernel == "mfma32"
@@ -440,13 +440,65 @@ def test_mfma32_row_counts_vs_oracle(N):
 
 
 def test_mfma32_falls_back_to_generic_beyond_its_row_limit():
-    rec, pl = _cfg3_plan(400)
+    rec, pl = _cfg3_plan(800)
     assert pl.kernel == "generic"
     co = _oracle(rec, np.float32)
     th = 0.3 * pl.philox_normal(2, seed=9, it=0)
     t, g = pl.log_target_grad(th)
     to, go, _, _ = co.log_target_grad(th[0].cpu().numpy())
     np.testing.assert_allclose(t[0].item(), to, rtol=2e-4)
+
+
+def test_mfma32_elementwise_prior_vs_oracle():
+    """A prior with a different (mu, sigma) per parameter takes the kernel's per-element path (the N(m, s) prior shared
+    by all parameters is served from two scalars)."""
+    rec, _ = _cfg3_plan()
+    rng = np.random.default_rng(12)
+    P = 1315
+    rec["prior_mu"] = (0.2 * rng.standard_normal(P)).astype(np.float64)
+    rec["prior_sigma"] = (0.5 + rng.random(P)).astype(np.float64)
+    pl = _plan(rec, torch.float32)
+    assert pl.kernel == "mfma32"
+    co = _oracle(rec, np.float32)
+    C = 6
+    th = 0.3 * pl.philox_normal(C, seed=4, it=0)
+    t, g = pl.log_target_grad(th)
+    for c in range(C):
+        to, go, _, _ = co.log_target_grad(th[c].cpu().numpy())
+        np.testing.assert_allclose(t[c].item(), to, rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(go).max()))
+    p0 = pl.philox_normal(C, seed=4, it=1)
+    u = pl.philox_uniform(C, seed=4, it=1)
+    tho, tvo, go_ = th.cpu().numpy().copy(), t.cpu().numpy().copy(), g.cpu().numpy().copy()
+    out = pl.hmc_step(th, t, g, 0.02, 10, p0=p0, u=u)
+    acc, hc, hp = co.hmc_draw(tho, tvo, go_, p0.cpu().numpy(), u.cpu().numpy(), 0.02, 10)
+    np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=2e-3, atol=2e-2)
+    rate = np.minimum(np.exp(np.minimum(hc - hp, 0.0)), 1)
+    decided = np.abs(u.cpu().numpy() - rate) > 2e-3
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+
+
+def test_mfma32_more_chains_than_resident_waves():
+    """2048 chains are resident at once (8 per CU); 4500 chains take two full rounds and a partial third in which the
+    waves of a SIMD hold different numbers of chains.  Every chain must come out as the generic kernel computes it."""
+    from eeyore_amd import _lib as L
+    rec, pl = _cfg3_plan()
+    C = 4500
+    th = 0.2 * pl.philox_normal(C, seed=21, it=0)
+    t, g = pl.log_target_grad(th)
+    tg, gg = pl.log_target_grad(th[:64].clone())
+    assert torch.equal(t[:64], tg) and torch.equal(g[:64], gg)  # a chain's result does not depend on its slot
+    a = [th.clone(), t.clone(), g.clone()]
+    b = [th.clone(), t.clone(), g.clone()]
+    oa = pl.hmc_step(*a, 0.03, 4, seed=5, it=1)
+    ob = pl.hmc_step(*b, 0.03, 4, seed=5, it=1, flags=L.EY_FORCE_GENERIC)
+    decided = (pl.philox_uniform(C, seed=5, it=1) - oa["rate"]).abs() > 2e-3
+    assert torch.equal(oa["accepted"][decided], ob["accepted"][decided])
+    assert (~decided).sum().item() < 0.01 * C
+    np.testing.assert_allclose(oa["h_prop"].cpu().numpy(), ob["h_prop"].cpu().numpy(), rtol=2e-4, atol=2e-2)
+    same = (oa["accepted"] == ob["accepted"]).cpu().numpy()
+    np.testing.assert_allclose(a[0].cpu().numpy()[same], b[0].cpu().numpy()[same], rtol=2e-3, atol=2e-4)
+    assert 0.2 * C < oa["accepted"].sum().item() < C
 
 
 def test_mfma32_philox_and_per_chain_step():
