@@ -119,13 +119,15 @@ def main():
         plan.hmc_step(theta, target, grad, STEP_SIZE, L_STEPS, seed=seed, it=it, chain_offset=chain_offset, flags=flags,
                       out=out)
 
+    # the running chain moments behind the R-hat summary are accumulated by the step kernel itself (attached moments)
+    stats.attach(plan)
     it = 1
     for _ in range(args.warmup):
         step(it); it += 1
-        stats.update(theta, out["accepted"])  # also warms the torch elementwise kernels used in the timed region
     if args.warmup > 1:
-        stats.summary()
+        stats.summary()  # also warms the torch elementwise kernels used in the timed region
     stats = ChainStats(C, P, dev)
+    stats.attach(plan)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -133,7 +135,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(it); it += 1
-        stats.update(theta, out["accepted"])
     summ = stats.summary() if args.steps > 1 else None  # RCCL all-reduce of [3, P] partial sums when world > 1
     torch.cuda.synchronize()
     if world > 1:

@@ -189,6 +189,22 @@ int ey_plan_set_prior(ey_plan* pl, const void* mu, const void* sigma, void* stre
   return EY_OK;
 }
 
+extern "C" int ey_stats_update(const void* theta, const void* accepted, int64_t C, int64_t P, int dtype, void* s1,
+                               void* s2, void* acc, void* stream);
+static int moments_check(const ey_plan* pl, int64_t C, const char* who) {
+  if (pl && pl->mom_s1 && pl->mom_C != C) {
+    ey_set_error(std::string(who) + ": the attached moments were sized for " + std::to_string(pl->mom_C) +
+                 " chains, called with " + std::to_string(C));
+    return EY_ERR_INVALID;
+  }
+  return EY_OK;
+}
+// trailing pass for the kernel families that do not fuse the accumulation
+static int moments_trailing(ey_plan* pl, int rc, const void* theta, const void* accepted, int64_t C, void* stream) {
+  if (rc != EY_OK || !pl->mom_s1) return rc;
+  return ey_stats_update(theta, accepted, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2, pl->mom_acc, stream);
+}
+
 static int check_ready(const ey_plan* pl, int64_t C, const char* who) {
   if (!pl) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": null plan");
   if (!pl->has_data) EY_FAIL(EY_ERR_STATE, std::string(who) + ": ey_plan_set_data has not been called");
@@ -237,15 +253,18 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
   if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: null argument");
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: num_steps must be >= 1");
   if (C == 0) return EY_OK;
+  if ((rc = moments_check(pl, C, "ey_hmc_step"))) return rc;
   EY_HIP(hipSetDevice(pl->device));
-  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))  // accumulates attached moments itself
     return ey_mfma32_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                          accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
   if (use_large(pl))
-    return ey_large_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+    rc = ey_large_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+                      accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
+  else
+    rc = ey_generic_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                         accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
-  return ey_generic_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
-                        accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
+  return moments_trailing(pl, rc, theta, accepted, C, stream);
 }
 
 int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
@@ -268,12 +287,14 @@ int ey_mala_step(ey_plan* pl, void* theta, void* target, void* grad, const void*
   if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: null argument");
   if (!(step > 0.0) && !step_vec) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: step must be positive");
   if (C == 0) return EY_OK;
+  if ((rc = moments_check(pl, C, "ey_mala_step"))) return rc;
   EY_HIP(hipSetDevice(pl->device));
   if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
                           log_rate, (hipStream_t)stream);
-  return ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
-                         log_rate, (hipStream_t)stream);
+  rc = ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
+                       log_rate, (hipStream_t)stream);
+  return moments_trailing(pl, rc, theta, accepted, C, stream);
 }
 
 int ey_mh_step(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
@@ -283,12 +304,14 @@ int ey_mh_step(ey_plan* pl, void* theta, void* target, const void* z, const void
   if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !target || !scale || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mh_step: null argument");
   if (C == 0) return EY_OK;
+  if ((rc = moments_check(pl, C, "ey_mh_step"))) return rc;
   EY_HIP(hipSetDevice(pl->device));
   if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
                         (hipStream_t)stream);
-  return ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
-                       (hipStream_t)stream);
+  rc = ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
+                     (hipStream_t)stream);
+  return moments_trailing(pl, rc, theta, accepted, C, stream);
 }
 
 }  // extern "C"
@@ -429,5 +452,20 @@ extern "C" int ey_stats_update(const void* theta, const void* accepted, int64_t 
     hipLaunchKernelGGL(k_acc_update, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s,
                        (const unsigned char*)accepted, (double*)acc, C);
   EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+extern "C" int ey_plan_attach_moments(ey_plan* pl, void* s1, void* s2, void* acc, int64_t C) {
+  if (!pl) EY_FAIL(EY_ERR_INVALID, "ey_plan_attach_moments: null plan");
+  if (!s1) {
+    pl->mom_s1 = pl->mom_s2 = pl->mom_acc = nullptr;
+    pl->mom_C = 0;
+    return EY_OK;
+  }
+  if (!s2 || !acc || C <= 0) EY_FAIL(EY_ERR_INVALID, "ey_plan_attach_moments: s1, s2, acc and C > 0 are required");
+  pl->mom_s1 = (double*)s1;
+  pl->mom_s2 = (double*)s2;
+  pl->mom_acc = (double*)acc;
+  pl->mom_C = C;
   return EY_OK;
 }

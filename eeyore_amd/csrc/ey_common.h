@@ -57,6 +57,9 @@ struct ey_plan {
   void *d_x, *d_y, *d_mu, *d_inv_var;
   bool prior_uniform = false;  // every parameter has the same (mu, sigma)
   double prior_mu0 = 0.0, prior_iv0 = 0.0;
+  // running moments attached with ey_plan_attach_moments (caller-owned device memory)
+  double *mom_s1 = nullptr, *mom_s2 = nullptr, *mom_acc = nullptr;
+  int64_t mom_C = 0;
   int* d_labels;
   // mfma32 path (4-32-32-3-like models, f32): padded/packed data image
   bool mfma32_ok;

@@ -84,6 +84,7 @@ struct MfArgs {
   unsigned char* accepted;
   float *rate, *hcur, *hprop;
   int balance;         // 1: the two waves of a SIMD keep in step through s_setprio (see Pace)
+  double *mom_s1, *mom_s2, *mom_acc;  // attached running moments (ey_plan_attach_moments) or null
 };
 
 // The arguments as the kernels read them: in place in the kernarg segment (constant address space, scalar loads).
@@ -483,6 +484,40 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
   return lik + prior;
 }
 
+// Attached running moments: s1 += theta, s2 += theta^2, acc += accepted for the state this chain is left in, with the
+// arithmetic of ey_stats_update (the product of two floats is exact in double).  `now` holds the state where the lane
+// has it in registers; `from_memory` says to take it from theta in HBM instead (a rejected HMC proposal).
+__device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, const float* thg, bool from_memory,
+                                            bool accepted, int c, int h, int lane) {
+  double* m1 = A.mom_s1 + chain * NPAR;
+  double* m2 = A.mom_s2 + chain * NPAR;
+  // every load of the read-modify-write is issued before the first use (sched_barrier), so the wave waits for one
+  // memory round trip, not for one per group of loads
+  double a1[29], a2[29];
+  float x[29];
+  int k = 0;
+  for_each(now, c, h, lane, [&](float& v, int idx, bool counts) {
+    x[k] = v;
+    if (counts) {
+      a1[k] = m1[idx];
+      a2[k] = m2[idx];
+      if (from_memory) x[k] = thg[idx];
+    }
+    ++k;
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  k = 0;
+  for_each(now, c, h, lane, [&](float&, int idx, bool counts) {
+    if (counts) {
+      const double t = (double)x[k];
+      m1[idx] = a1[k] + t;
+      m2[idx] = a2[k] + t * t;
+    }
+    ++k;
+  });
+  if (lane == 0) A.mom_acc[chain] += accepted ? 1.0 : 0.0;
+}
+
 // One chain of one launch: everything between reading theta and writing the accepted state back.
 template <int MODE>
 __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int c,
@@ -555,6 +590,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
       A.accepted[chain] = acc ? 1 : 0;
       if (A.rate) A.rate[chain] = log_rate;
     }
+    if (A.mom_s1) add_moments(A, chain, acc ? p : th, thg, false, acc, c, h, lane);
     return;
   }
 
@@ -624,6 +660,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     if (A.hcur) A.hcur[chain] = h_cur;
     if (A.hprop) A.hprop[chain] = h_prop;
   }
+  if (A.mom_s1) add_moments(A, chain, th, thg, !acc, acc, c, h, lane);
 #if EY_PHASE_TIMING
   if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain + 2] = __builtin_amdgcn_s_memrealtime();
   KO(5);
@@ -796,6 +833,11 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
   a.balance = (g_variant & 2) ? 0 : 1;
+  if (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) {
+    a.mom_s1 = pl->mom_s1;
+    a.mom_s2 = pl->mom_s2;
+    a.mom_acc = pl->mom_acc;
+  }
   if constexpr (MODE == MODE_HMC) {
     if (g_variant & 1) return mf_launch_v<MODE, 4>(a, pl->n_cu, s);
   }

@@ -52,6 +52,14 @@ class ChainStats:
         self.s2 = torch.zeros(num_chains, num_params, dtype=torch.float64, device=device)
         self.acc = torch.zeros(num_chains, dtype=torch.float64, device=device)
 
+    def attach(self, plan):
+        """Let the plan's step kernels accumulate into this object (Plan.attach_moments): no separate pass over
+        [C, P] per iteration, and ``update`` must then not be called for those steps."""
+        plan.attach_moments(self.s1, self.s2, self.acc, on_step=self._count_step)
+
+    def _count_step(self):
+        self.n += 1
+
     def update(self, theta, accepted=None):
         if theta.is_cuda and theta.dtype in (torch.float32, torch.float64) and theta.is_contiguous():
             # one streaming HIP pass (ey_stats_update) instead of several elementwise torch kernels

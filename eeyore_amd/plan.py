@@ -39,6 +39,7 @@ class Plan:
         self.P = P.value
         self._data_key = None
         self._prior_key = None
+        self._moments = None
 
     def __del__(self):
         try:
@@ -118,6 +119,29 @@ class Plan:
                                            _stream(self.device)), "ey_log_target_grad")
         return target, grad
 
+    # ------------------------------------------------------------------ attached running moments
+    def attach_moments(self, s1, s2, acc, on_step=None):
+        """From now on every hmc_step / mala_step / mh_step also adds the state each chain is left in to the double
+        accumulators s1, s2 [C, P] and its accept flag to acc [C] (ey_plan_attach_moments): inside the fused kernel where
+        there is one.  ``on_step`` is called after each such step (e.g. to count iterations)."""
+        for t in (s1, s2, acc):
+            if t.dtype != torch.float64 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("moment accumulators must be contiguous float64 tensors on the plan's device")
+        C = s1.shape[0]
+        if tuple(s1.shape) != (C, self.P) or tuple(s2.shape) != (C, self.P) or tuple(acc.shape) != (C,):
+            raise ValueError(f"expected s1, s2 [C, {self.P}] and acc [C]")
+        L.check(L.lib().ey_plan_attach_moments(self.handle, L.ptr(s1), L.ptr(s2), L.ptr(acc), C),
+                "ey_plan_attach_moments")
+        self._moments = (s1, s2, acc, on_step)  # keeps the tensors alive
+
+    def detach_moments(self):
+        L.check(L.lib().ey_plan_attach_moments(self.handle, None, None, None, 0), "ey_plan_attach_moments")
+        self._moments = None
+
+    def _stepped(self):
+        if self._moments is not None and self._moments[3] is not None:
+            self._moments[3]()
+
     def hmc_step(self, theta, target, grad, step, num_steps, p0=None, u=None, step_vec=None, temp=None, seed=0, it=0,
                  chain_offset=0, flags=0, out=None):
         C = self._theta(theta)
@@ -129,6 +153,7 @@ class Plan:
                                     float(step), L.ptr(step_vec), int(num_steps), L.ptr(temp), C, int(seed), int(it),
                                     int(chain_offset), int(flags), L.ptr(out["accepted"]), L.ptr(out["rate"]),
                                     L.ptr(out["h_cur"]), L.ptr(out["h_prop"]), _stream(self.device)), "ey_hmc_step")
+        self._stepped()
         return out
 
     def leapfrog(self, theta, p, step, num_steps, step_vec=None, temp=None):
@@ -152,6 +177,7 @@ class Plan:
                                      float(step), L.ptr(step_vec), L.ptr(temp), C, int(seed), int(it),
                                      int(chain_offset), int(flags), L.ptr(out["accepted"]), L.ptr(out["log_rate"]),
                                      _stream(self.device)), "ey_mala_step")
+        self._stepped()
         return out
 
     def mh_step(self, theta, target, scale, z=None, u=None, temp=None, seed=0, it=0, chain_offset=0, flags=0, out=None):
@@ -163,6 +189,7 @@ class Plan:
         L.check(L.lib().ey_mh_step(self.handle, L.ptr(theta), L.ptr(target), L.ptr(z), L.ptr(u), L.ptr(scale),
                                    L.ptr(temp), C, int(seed), int(it), int(chain_offset), int(flags),
                                    L.ptr(out["accepted"]), L.ptr(out["log_rate"]), _stream(self.device)), "ey_mh_step")
+        self._stepped()
         return out
 
     def pt_swap_decide(self, ell_i, ell_j, t_i, t_j, u, dlogq=None):

@@ -131,6 +131,14 @@ int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64
 int ey_stats_update(const void* theta, const void* accepted, int64_t C, int64_t P, int dtype, void* s1, void* s2,
                     void* acc, void* stream);
 
+/* Attach running-moment accumulators to a plan: from now on every ey_hmc_step / ey_mala_step / ey_mh_step on it also
+ * performs, for the state each chain is left in, exactly what ey_stats_update does (s1 += theta, s2 += theta^2,
+ * acc += accepted) -- inside the fused kernel where there is one (no extra pass over [C,P]), as a trailing pass on
+ * the same stream otherwise.  s1, s2 [C,P] double, acc [C] double, all three required; steps must then be called with
+ * that same C.  s1 = NULL detaches.  (The reference keeps every sample and reduces afterwards,
+ * eeyore/chains/chain_list.py:64-67, chain_lists.py:65-66; with thousands of chains the moments are kept instead.) */
+int ey_plan_attach_moments(ey_plan* plan, void* s1, void* s2, void* acc, int64_t C);
+
 /* Tuning knob for the MFMA kernel family (not part of the drop-in surface): selects the workgroup shape /
  * issue-priority variant of the fused trajectory kernel; returns the previous value.  Results do not depend on it. */
 int ey_debug_set_variant(int variant);

@@ -501,6 +501,40 @@ def test_mfma32_more_chains_than_resident_waves():
     assert 0.2 * C < oa["accepted"].sum().item() < C
 
 
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_attached_moments_equal_a_separate_stats_pass(force_generic):
+    """ey_plan_attach_moments: the step kernels leave exactly the sums a following ey_stats_update would (fused in
+    the MFMA kernel, a trailing pass behind the generic one), for HMC, MALA and MH, accepted or not."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.distributed import ChainStats
+    rec, pl = _cfg3_plan()
+    flags = L.EY_FORCE_GENERIC if force_generic else 0
+    C = 300
+    th = 0.2 * pl.philox_normal(C, seed=8, it=0)
+    t, g = pl.log_target_grad(th)
+    ref, fused = ChainStats(C, pl.P, DEV), ChainStats(C, pl.P, DEV)
+    fused.attach(pl)
+    scale = torch.full((pl.P,), 0.01, dtype=torch.float32, device=DEV)
+    accepted_total = 0
+    for it in range(1, 7):
+        if it % 3 == 1:
+            out = pl.hmc_step(th, t, g, 0.05, 6, seed=8, it=it, flags=flags)
+        elif it % 3 == 2:
+            out = pl.mala_step(th, t, g, 0.002, seed=8, it=it, flags=flags)
+        else:
+            out = pl.mh_step(th, t, scale, seed=8, it=it, flags=flags)
+            t, g = pl.log_target_grad(th)  # MH leaves the gradient stale
+        ref.update(th, out["accepted"])
+        accepted_total += int(out["accepted"].sum().item())
+    assert 0 < accepted_total < 6 * C
+    assert fused.n == ref.n == 6
+    assert torch.equal(fused.s1, ref.s1) and torch.equal(fused.s2, ref.s2) and torch.equal(fused.acc, ref.acc)
+    with pytest.raises(ValueError, match="sized for"):
+        pl.hmc_step(th[:10].clone(), t[:10].clone(), g[:10].clone(), 0.05, 2, seed=1, it=1)
+    pl.detach_moments()
+    pl.hmc_step(th[:10].clone(), t[:10].clone(), g[:10].clone(), 0.05, 2, seed=1, it=1)
+
+
 def test_mfma32_philox_and_per_chain_step():
     rec, pl = _cfg3_plan()
     C = 256
