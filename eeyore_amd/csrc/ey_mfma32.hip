@@ -269,6 +269,12 @@ __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
 // log-target and gradient of the position whose images are staged in lw.  Returns the (tempered) log-target.
 // `need_value` (wave-uniform) = false skips the value-only work (row log-sum-exp terms, quadratic form of the prior
 // and their reductions): inside a trajectory only the gradient is consumed, hmc.py:108-121.
+//
+// PARK: the twelve elements of the position that the tile loop does not read from registers (W0, W2, b0, b1 are
+// staged as images; b2 is taken into scalar registers) wait in this wave's LDS region while the tile loop runs.  The
+// loop needs every vector register it can get, and what does not fit is spilled to scratch memory, whose reload
+// latency the end of every evaluation then waits for (four serial round trips per leapfrog step before this).
+template <int PARK, bool UPRIOR>
 __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, bool has_temp, float temp, int c,
                       int h, int lane, bool need_value, Pace& pc) {
   const int jj = lane & 3;
@@ -278,6 +284,20 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
   f32x4 dW0a = {0, 0, 0, 0}, dW0b = {0, 0, 0, 0}, dW2a = {0, 0, 0, 0}, dW2b = {0, 0, 0, 0};
   float db1 = 0.0f, db0 = 0.0f, db2[3] = {0.0f, 0.0f, 0.0f}, lik = 0.0f;
 
+  const float b2_0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[0])));
+  const float b2_1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[1])));
+  const float b2_2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[2])));
+  if (PARK) {
+    float* park = lw + WAVE_FLOATS + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) park[i * 64] = th.w0[i];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) park[(4 + o) * 64] = th.w2[o];
+    park[7 * 64] = th.b1;
+    park[8 * 64] = th.b0;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) park[(9 + o) * 64] = th.b2[o];
+  }
 #if EY_PHASE_TIMING
   unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const bool ph_on = (blockIdx.x & 63) == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
@@ -335,7 +355,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     }
     float l0 = lg0[0] + lg1[0], l1 = lg0[1] + lg1[1], l2 = lg0[2] + lg1[2];
     l0 = hsum(l0); l1 = hsum(l1); l2 = hsum(l2);
-    l0 += th.b2[0]; l1 += th.b2[1]; l2 += th.b2[2];
+    l0 += b2_0; l1 += b2_1; l2 += b2_2;
     PH(2);
     // ---- CE-sum log-likelihood and output delta = onehot - softmax           (constants.py:17)
     const bool valid = lab >= 0;
@@ -429,6 +449,18 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     wave_lds_fence();
     PH(9);
   }
+  if (PARK) {
+    int at = WAVE_FLOATS + lane;
+    asm volatile("" : "+v"(at));  // an offset the compiler cannot match with the stores above: no forwarding
+#pragma unroll
+    for (int i = 0; i < 4; ++i) th.w0[i] = lw[at + i * 64];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) th.w2[o] = lw[at + (4 + o) * 64];
+    th.b1 = lw[at + 7 * 64];
+    th.b0 = lw[at + 8 * 64];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) th.b2[o] = lw[at + (9 + o) * 64];
+  }
   // ---- combine the two row-parity halves and the lanes
 #pragma unroll
   for (int r = 0; r < 16; ++r) g.w1[r] = dW1[r];
@@ -445,7 +477,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
   g.b0 = hsum(db0);
   // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
   float qsum = 0.0f;
-  if (A.prior_uniform) {
+  if (UPRIOR || A.prior_uniform) {  // UPRIOR: the kernel variant launched only for such priors has no other path
     const float mu0 = A.mu0, iv0 = A.iv0;
     for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int, bool counts) {
       const float d = tv - mu0;
@@ -491,6 +523,9 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
                                             bool accepted, int c, int h, int lane) {
   double* m1 = A.mom_s1 + chain * NPAR;
   double* m2 = A.mom_s2 + chain * NPAR;
+  // (a pointer the compiler cannot identify with the one theta was first read through: otherwise it keeps those 29
+  // values in registers through the whole trajectory instead of reading them again here)
+  asm volatile("" : "+s"(thg));
   // every load of the read-modify-write is issued before the first use (sched_barrier), so the wave waits for one
   // memory round trip, not for one per group of loads
   double a1[29], a2[29];
@@ -519,7 +554,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
 }
 
 // One chain of one launch: everything between reading theta and writing the accepted state back.
-template <int MODE>
+template <int MODE, int PARK, bool UPRIOR>
 __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int c,
                                           const int h, const int lane, Pace& pc) {
 #if EY_PHASE_TIMING
@@ -539,7 +574,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
 
   if (MODE == MODE_GRAD) {
     write_images(lw, th, c, h);
-    const float t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
+    const float t = eval<PARK, UPRIOR>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
     for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
     if (lane == 0) A.target[chain] = t;
     return;
@@ -566,7 +601,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
       }
     });
     write_images(lw, p, c, h);
-    const float tv = eval(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
+    const float tv = eval<PARK, UPRIOR>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
     float log_rate = tv - A.target[chain];  // symmetric kernel: metropolis_hastings.py:50
     if (MODE == MODE_MALA) {
       float qb = 0.0f;
@@ -613,7 +648,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   float t = t_cur;
   if (MODE == MODE_LEAPFROG || A.recompute) {  // hmc.py:104
     write_images(lw, th, c, h);
-    t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
+    t = eval<PARK, UPRIOR>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
   }
   // leapfrog, hmc.py:100-124 (grad_potential = -grad)
   for_each2(p, g, [&](float& pv, float& gv) { pv = pv + 0.5f * eps * gv; });
@@ -624,7 +659,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     KO(1);
     write_images(lw, th, c, h);
     KO(2);
-    t = eval(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc);
+    t = eval<PARK, UPRIOR>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc);
     KO(3);
     const float w = (k < A.L) ? eps : 0.5f * eps;
     for_each2(p, g, [&](float& pv, float& gv) { pv = pv + w * gv; });
@@ -678,7 +713,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
 // Two waves share a SIMD because f32 MFMA runs on the vector ALUs: the partner hides latency (LDS round trips, MFMA
 // result latency) rather than adding throughput (tools/coexec_probe*.hip).  WAVES = 4 is the former layout (two
 // 4-wave workgroups per CU, one chain per wave), kept for A/B runs (ey_debug_set_variant bit 0).
-template <int MODE, int WAVES>
+template <int MODE, int WAVES, int PARK, bool UPRIOR>
 __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   constexpr int MF_WAVES = WAVES, MF_THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -693,8 +728,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   const int xfloats = A.ntiles * XTILE_FLOATS;
   for (int i = tid; i < xfloats; i += MF_THREADS) smem[i] = A.xpack[i];
   const float* xs = smem;
-  float* lw = smem + xfloats + wave * WAVE_FLOATS;
-  int* ctl = reinterpret_cast<int*>(smem + xfloats + MF_WAVES * WAVE_FLOATS);  // [waves] counters, [waves] SIMD ids
+  constexpr int REGION = WAVE_FLOATS + 64 * PARK;
+  float* lw = smem + xfloats + wave * REGION;
+  int* ctl = reinterpret_cast<int*>(smem + xfloats + MF_WAVES * REGION);  // [waves] counters, [waves] SIMD ids
   // HW_REG_HW_ID (id 4), SIMD_ID = bits 5:4
   const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
   if (lane == 0) {
@@ -736,7 +772,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
 #if EY_PHASE_TIMING
     if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain] = rt_entry;
 #endif
-    run_chain<MODE>(*Ap, xs, lw, chain, c, h, lane, pc);
+    run_chain<MODE, PARK, UPRIOR>(*Ap, xs, lw, chain, c, h, lane, pc);
   }
   if (lane == 0) __hip_atomic_store(&ctl[wave], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // nothing left
 }
@@ -750,12 +786,15 @@ bool ey_mfma32_supports(const ey_plan* pl) {
   return m.act[0] == EY_ACT_SIGMOID && m.act[1] == EY_ACT_SIGMOID && m.act[2] == EY_ACT_NONE;
 }
 
-static size_t mf_lds_bytes(int ntiles, int waves) {
-  return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * WAVE_FLOATS) + sizeof(int) * 2 * waves;
+static size_t mf_lds_bytes(int ntiles, int waves, int park) {
+  return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * (WAVE_FLOATS + 64 * park)) +
+         sizeof(int) * 2 * waves;
 }
+#define MF_PARK 12        // position elements parked in LDS during the tile loop ...
+#define MF_PARK_TILES 7   // ... when the data image leaves room for it (N <= 224 rows)
 
 // kernel variant (A/B knob): bit 0 = former launch shape (4-wave workgroups, one chain per wave), bit 1 = no priority
-// balancing between the two waves of a SIMD
+// balancing between the two waves of a SIMD, bit 2 = no momentum parking
 static int g_variant = 0;
 extern int g_ey_force_large;
 extern "C" int ey_debug_set_variant(int v) {
@@ -803,20 +842,21 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
   return EY_OK;
 }
 
-template <int MODE, int WAVES>
+template <int MODE, int WAVES, int PARK, bool UPRIOR = false>
 static int mf_launch_v(MfArgs& a, int n_cu, hipStream_t s) {
-  const size_t bytes = mf_lds_bytes(a.ntiles, WAVES);
+  const size_t bytes = mf_lds_bytes(a.ntiles, WAVES, PARK);
   static bool attr_done = false;
   if (!attr_done) {
-    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_lds_bytes(MF_MAX_TILES, WAVES)));
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PARK, UPRIOR>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)mf_lds_bytes(PARK ? MF_PARK_TILES : MF_MAX_TILES, WAVES, PARK)));
     attr_done = true;
   }
   // 8 waves: one persistent workgroup per CU, or one per chain when there are fewer chains than CUs (then only wave
   // 0 of a workgroup has work and every chain gets a CU to itself); 4 waves: a workgroup per 4 chains
   const unsigned grid = WAVES == 8 ? (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256)
                                    : (unsigned)((a.C + WAVES - 1) / WAVES);
-  hipLaunchKernelGGL((k_mfma32<MODE, WAVES>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+  hipLaunchKernelGGL((k_mfma32<MODE, WAVES, PARK, UPRIOR>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
@@ -839,9 +879,12 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
     a.mom_acc = pl->mom_acc;
   }
   if constexpr (MODE == MODE_HMC) {
-    if (g_variant & 1) return mf_launch_v<MODE, 4>(a, pl->n_cu, s);
+    if (g_variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);
+    // the headline shape (few row tiles, one Normal(m, s) prior for all parameters) has its own, leaner instantiation
+    if (a.ntiles <= MF_PARK_TILES && a.prior_uniform && !(g_variant & 4))
+      return mf_launch_v<MODE, 8, MF_PARK, true>(a, pl->n_cu, s);
   }
-  return mf_launch_v<MODE, 8>(a, pl->n_cu, s);
+  return mf_launch_v<MODE, 8, 0>(a, pl->n_cu, s);
 }
 
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
