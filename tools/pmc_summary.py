@@ -23,7 +23,7 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
     print(f"matrix-pipe busy fraction    {mean['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (mean['GRBM_GUI_ACTIVE'] / 8):18.3f}")
 if len(sys.argv) > 3 and "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
-    json.dump({"kernel": "k_mfma32<0,4> (HMC trajectory)", "FETCH_SIZE_KB": mean["FETCH_SIZE"],
+    json.dump({"kernel": "k_mfma32<0,8,12,true> (HMC trajectory)", "FETCH_SIZE_KB": mean["FETCH_SIZE"],
                "WRITE_SIZE_KB": mean["WRITE_SIZE"], "dispatches": n,
                "source": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes), 4096 chains x L=20 per dispatch"},
               open(sys.argv[3], "w"), indent=1)
