@@ -73,6 +73,16 @@ class ChainBuffer(Chain):
         """Per-chain Monte Carlo means [C, P]."""
         return self.get_samples().mean(0)
 
+    def ess(self):
+        """Effective sample size of every (chain, parameter) series, [C, P] (one device pass, stats.batched.ess)."""
+        from eeyore_amd.stats import batched
+        return batched.ess(self.get_samples())
+
+    def mc_se(self):
+        """Monte Carlo standard error (the reference's mc_se, p = 1) of every (chain, parameter) series, [C, P]."""
+        from eeyore_amd.stats import batched
+        return batched.mc_se(self.get_samples())
+
     def acceptance_rate(self):
         """Per-chain acceptance [C] = sum(accepted) / num_samples (chain_list.py:94-96)."""
         return self.get_accepted().to(torch.float64).mean(0)

@@ -103,6 +103,27 @@ class ChainStats:
                     acceptance=extra[1].item() / (m * n))
 
 
+def reduce_ess(ess, group=None):
+    """Combine per-rank effective sample sizes ess [C_local, P] (ChainBuffer.ess()) into job-wide figures per
+    parameter: the minimum over all chains, the mean over all chains and the total (chains are independent, so their
+    effective sizes add).  Series for which the estimator had not enough samples (NaN) are left out and counted.
+    Two small all-reduces of [P] (+1) doubles over RCCL; nothing per chain crosses the wire."""
+    e = ess.to(torch.float64)
+    ok = torch.isfinite(e)
+    big = torch.full_like(e, float("inf"))
+    emin = torch.where(ok, e, big).amin(0)
+    esum = torch.where(ok, e, torch.zeros_like(e)).sum(0)
+    cnt = torch.cat([ok.sum(0).to(torch.float64), torch.tensor([float(e.shape[0])], dtype=torch.float64, device=e.device)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(emin, op=dist.ReduceOp.MIN, group=group)
+        packed = torch.cat([esum, cnt])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        esum, cnt = packed[:esum.numel()], packed[esum.numel():]
+    used, chains = cnt[:-1], cnt[-1]
+    return dict(min=emin, mean=esum / used.clamp(min=1), total=esum, num_chains=int(chains.item()),
+                not_enough=int((chains * used.numel() - used.sum()).item()))
+
+
 class TemperingExchange:
     """Parallel tempering across ranks by exchanging temperature LABELS, never states (collective 2).
 

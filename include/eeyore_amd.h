@@ -131,6 +131,15 @@ int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64
 int ey_stats_update(const void* theta, const void* accepted, int64_t C, int64_t P, int dtype, void* s1, void* s2,
                     void* acc, void* stream);
 
+/* Initial-sequence estimate of the asymptotic variance (eeyore/stats/inse_mc_cov.py:9-83) of every column of
+ * x [n, S] at once, each column on its own (p = 1): S = chains * parameters of a stored run, n iterations, row-major as a
+ * chain buffer [iterations, C, P] is laid out.  sig2 [S] double: the estimate (NaN where the reference raises 'Not
+ * enough samples', :45-46); var [S] double: the unbiased sample variance (eeyore/stats/cov.py:5-15), so that multi_ess'
+ * n * (det cov / det mc_cov)^(1/p) (eeyore/stats/multi_ess.py:6-14) is n * var / sig2; num_pairs [S] int32 or NULL: lag
+ * pairs that entered the sum (-1 where not enough).  The reference's adjust=True changes nothing for p = 1. */
+int ey_inse_univariate(const void* x, int64_t n, int64_t S, int dtype, void* sig2, void* var, void* num_pairs,
+                       void* stream);
+
 /* Attach running-moment accumulators to a plan: from now on every ey_hmc_step / ey_mala_step / ey_mh_step on it also
  * performs, for the state each chain is left in, exactly what ey_stats_update does (s1 += theta, s2 += theta^2,
  * acc += accepted) -- inside the fused kernel where there is one (no extra pass over [C,P]), as a trailing pass on

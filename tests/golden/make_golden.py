@@ -372,8 +372,36 @@ def g7_stats():
     print("g7 rhat", out["multi_rhat"], "ess", out["multi_ess"])
 
 
+# ----------------------------------------------------------------------------- G8: univariate INSE / ESS (one parameter at a time)
+def g8_univariate_stats():
+    """inse_mc_cov / multi_ess of the reference applied to single columns (p = 1): the statistic the batched device
+    kernel ey_inse_univariate computes for every (chain, parameter) series."""
+    chains = [np.loadtxt(os.path.join(REF, "examples", "stats", f"chain0{i}.csv"), delimiter=",", skiprows=1)
+              for i in range(1, 5)]
+    x = torch.tensor(np.array(chains), dtype=torch.float64)
+    m, n, p = x.shape
+    # (multi_ess itself cannot take p = 1: its torch.det needs a matrix, multi_ess.py:9; its formula n * (det cov /
+    # det mc_cov)^(1/p) is recorded here through its two ingredients, inse_mc_cov and cov)
+    inse = np.zeros((m, p)); var = np.zeros((m, p)); inse_short = np.zeros((m, p)); var_short = np.zeros((m, p))
+    for i in range(m):
+        for j in range(p):
+            col = x[i][:, j:j + 1].clone()
+            inse[i, j] = st.inse_mc_cov(col).item()
+            var[i, j] = st.cov(col, rowvar=False).item()
+            short = col[:200].clone()
+            inse_short[i, j] = st.inse_mc_cov(short).item()
+            var_short[i, j] = st.cov(short, rowvar=False).item()
+    np.savez_compressed(os.path.join(HERE, "g8_univariate_stats.npz"), chains=x.numpy(), inse=inse, var=var,
+                        inse_first200=inse_short, var_first200=var_short)
+    print("g8 inse", inse, "var", var)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if len(sys.argv) > 1:  # regenerate selected groups only, e.g. `make_golden.py g8_univariate_stats`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_kats()
     g2_grads()
     g3_leapfrog()
@@ -381,6 +409,7 @@ if __name__ == "__main__":
     g5_mala_mh_traces()
     g6_power_posterior()
     g7_stats()
+    g8_univariate_stats()
     # bundled datasets re-exported as data fixtures (inputs only)
     d = datasets(torch.float64)
     np.savez_compressed(os.path.join(HERE, "datasets.npz"), xor_x=d["xor"].x.numpy(), xor_y=d["xor"].y.numpy(),

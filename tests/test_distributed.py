@@ -41,10 +41,19 @@ def _worker(rank, world, port, q):
     x, acc = _chains()
     off, cnt = shard(x.shape[0], rank, world)
     s = _summary(x[off:off + cnt], acc[off:off + cnt])
+    from eeyore_amd.distributed import reduce_ess
+    e = reduce_ess(_fake_ess()[off:off + cnt])
+    s.update({"ess_" + k: v for k, v in e.items()})
     if rank == 0:
         q.put({k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in s.items()})
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _fake_ess(C=10, P=7):
+    e = torch.tensor(np.random.default_rng(4).uniform(5.0, 300.0, (C, P)))
+    e[3, 2] = float("nan")  # a series without enough samples
+    return e
 
 
 def test_shard_is_a_partition():
@@ -86,6 +95,14 @@ def test_world_size_2_gloo_equals_single_process():
     np.testing.assert_allclose(got["mean"], want["mean"].numpy(), rtol=1e-12)
     assert got["num_chains"] == x.shape[0] and got["num_samples"] == x.shape[1]
     assert abs(got["acceptance"] - want["acceptance"]) < 1e-12
+    from eeyore_amd.distributed import reduce_ess
+    e = reduce_ess(_fake_ess())
+    for k in ("min", "mean", "total"):
+        np.testing.assert_allclose(got["ess_" + k], e[k].numpy(), rtol=1e-12)
+    assert got["ess_num_chains"] == 10 and got["ess_not_enough"] == e["not_enough"] == 1
+    full = _fake_ess()
+    np.testing.assert_allclose(e["min"].numpy()[2], np.nanmin(full.numpy()[:, 2]))
+    np.testing.assert_allclose(e["mean"].numpy()[2], np.nanmean(full.numpy()[:, 2]))
 
 
 # ------------------------------------------------------------------------------------------------ tempering exchange

@@ -833,3 +833,84 @@ def test_per_chain_dual_averaging_on_the_mfma_model():
     acc = s.get_chain().acceptance_rate()
     assert s.step.shape == (C,) and s.step.max() / s.step.min() < 5  # started a factor 63 apart
     assert 0.45 < acc.mean().item() < 0.85
+
+
+def _ar1(rng, n, S, rho, dtype):
+    e = rng.standard_normal((n, S))
+    x = np.zeros((n, S))
+    x[0] = e[0]
+    for i in range(1, n):
+        x[i] = rho * x[i - 1] + e[i]
+    return (x * (1.0 + np.arange(S) % 3) + 5.0).astype(dtype)
+
+
+def test_inse_univariate_kernel_on_the_reference_chains():
+    """ey_inse_univariate against the reference's own numbers (G8) and the numpy oracle: examples/stats/chain0[1-4].csv,
+    every column as one series."""
+    from eeyore_amd.stats import batched
+    from oracle import diagnostics_oracle as do
+    z = load("g8_univariate_stats.npz")
+    x = z["chains"]                                    # [4, 999, 3]
+    stacked = np.ascontiguousarray(np.transpose(x, (1, 0, 2)))  # [n, C, P] as a chain buffer stores it
+    r = batched.inse_univariate(_t(stacked))
+    np.testing.assert_allclose(r["sig2"].cpu().numpy(), z["inse"], rtol=1e-10)
+    np.testing.assert_allclose(r["var"].cpu().numpy(), z["var"], rtol=1e-12)
+    r2 = batched.inse_univariate(_t(stacked[:200]))
+    np.testing.assert_allclose(r2["sig2"].cpu().numpy(), z["inse_first200"], rtol=1e-10)
+    ess = batched.ess(_t(stacked)).cpu().numpy()
+    np.testing.assert_allclose(ess, 999 * z["var"] / z["inse"], rtol=1e-10)
+    for i in range(4):
+        for j in range(3):
+            assert r["pairs"][i, j].item() == do.inse_univariate(x[i, :, j])[1]
+
+
+@pytest.mark.parametrize("n,S,tag", [(2, 5, "f64"), (3, 33, "f64"), (64, 100, "f32"), (257, 1000, "f64"),
+                                     (1000, 4 * 1315, "f32"), (2500, 37, "f64"), (5000, 19, "f32"), (20000, 3, "f32")])
+def test_inse_univariate_kernel_vs_oracle(n, S, tag):
+    """Series lengths that take each staging shape (16, 4 and 1 series per workgroup), ragged series counts, constant
+    series (the reference raises 'Not enough samples': NaN here) and strongly correlated ones."""
+    from eeyore_amd.stats import batched
+    from oracle import diagnostics_oracle as do
+    npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    rng = np.random.default_rng(n + S)
+    x = _ar1(rng, n, S, 0.9 if n > 100 else 0.3, npdt)
+    x[:, S // 2] = 1.25                                  # a constant series
+    r = batched.inse_univariate(_t(x, dt))
+    sig2, var, pairs = (r[k].cpu().numpy() for k in ("sig2", "var", "pairs"))
+    check = range(S) if S <= 64 else list(range(0, S, max(1, S // 48))) + [S // 2, S - 1]
+    tol = 1e-10 if tag == "f64" else 2e-4
+    for j in check:
+        col = x[:, j].astype(np.float64) if tag == "f64" else x[:, j]
+        try:
+            so, used = do.inse_univariate(col.astype(npdt))
+        except RuntimeError:
+            assert np.isnan(sig2[j]) and pairs[j] == -1
+            continue
+        if tag == "f32":  # the kernel centres in float and sums in double; compare with the oracle run in double on the same data
+            so, used_d = do.inse_univariate(col.astype(np.float64))
+            np.testing.assert_allclose(sig2[j], so, rtol=tol)
+            assert abs(int(pairs[j]) - used_d) <= 1
+        else:
+            np.testing.assert_allclose(sig2[j], so, rtol=tol)
+            assert pairs[j] == used
+        np.testing.assert_allclose(var[j], do.sample_var(col.astype(np.float64)), rtol=tol)
+    assert np.isnan(sig2[S // 2])
+
+
+def test_chain_buffer_ess_after_a_short_run():
+    """ChainBuffer.ess(): [C, P] effective sample sizes of a sampled run, positive and below a few n."""
+    rec, pl = _cfg3_plan()
+    from eeyore_amd.chains.chain_buffer import ChainBuffer
+    C, n = 32, 60
+    th = 0.2 * pl.philox_normal(C, seed=2, it=0)
+    t, g = pl.log_target_grad(th)
+    buf = ChainBuffer()
+    for it in range(n):
+        out = pl.hmc_step(th, t, g, 0.03, 8, seed=2, it=1 + it)
+        buf.update(dict(sample=th, target_val=t, accepted=out["accepted"]))
+    ess = buf.ess()
+    assert tuple(ess.shape) == (C, pl.P)
+    ok = torch.isfinite(ess)
+    assert ok.float().mean().item() > 0.99
+    assert (ess[ok] > 1.0).all() and (ess[ok] < 20 * n).all()
+    assert tuple(buf.mc_se().shape) == (C, pl.P)

@@ -127,3 +127,21 @@ def test_g6_power_posterior():
     for (i, j), lr, lq in zip(z["pairs"], z["log_rate"], z["log_q"]):
         got = orc.pt_swap_log_rate(lq[0], lq[1], ell[i], ell[j], z["ladder"][i], z["ladder"][j])
         np.testing.assert_allclose(got, lr, rtol=1e-9, atol=1e-10)
+
+
+def test_g8_univariate_inse_oracle_matches_reference():
+    """oracle/diagnostics_oracle.py against the reference's inse_mc_cov / cov run on single columns (G8)."""
+    from oracle import diagnostics_oracle as do
+    z = load("g8_univariate_stats.npz")
+    x = z["chains"]
+    for i in range(x.shape[0]):
+        for j in range(x.shape[2]):
+            sig, used = do.inse_univariate(x[i, :, j])
+            np.testing.assert_allclose(sig, z["inse"][i, j], rtol=1e-11)
+            np.testing.assert_allclose(do.sample_var(x[i, :, j]), z["var"][i, j], rtol=1e-12)
+            assert used >= 1
+            sig, _ = do.inse_univariate(x[i, :200, j])
+            np.testing.assert_allclose(sig, z["inse_first200"][i, j], rtol=1e-11)
+            np.testing.assert_allclose(do.sample_var(x[i, :200, j]), z["var_first200"][i, j], rtol=1e-12)
+    with np.testing.assert_raises(RuntimeError):
+        do.inse_univariate(np.ones(10))  # a constant series never gives a positive Sig

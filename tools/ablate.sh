@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/abl
 for a in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -DEY_ABLATE=$a -shared \
-    -o tools/abl/lib_$a.so eeyore_amd/csrc/ey_api.hip eeyore_amd/csrc/ey_generic.hip eeyore_amd/csrc/ey_mfma32.hip 2> /dev/null &
+    -o tools/abl/lib_$a.so eeyore_amd/csrc/*.hip 2> /dev/null &
 done
 wait
 ls -la tools/abl
