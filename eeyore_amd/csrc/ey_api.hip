@@ -232,6 +232,17 @@ int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, v
   return ey_generic_log_target(pl, theta, temp, C, log_lik, log_prior, nullptr, nullptr, (hipStream_t)stream);
 }
 
+int ey_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, void* stream) {
+  int rc = check_ready(pl, C, "ey_log_lik_rows");
+  if (rc) return rc < 0 ? rc : EY_OK;
+  if (!theta || !rows) EY_FAIL(EY_ERR_INVALID, "ey_log_lik_rows: null argument");
+  if (C == 0) return EY_OK;
+  if (use_large(pl))
+    EY_FAIL(EY_ERR_UNSUPPORTED, "ey_log_lik_rows: not built for models whose parameters do not fit LDS");
+  EY_HIP(hipSetDevice(pl->device));
+  return ey_generic_log_lik_rows(pl, theta, temp, C, rows, (hipStream_t)stream);
+}
+
 int ey_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,
                        void* stream) {
   int rc = check_ready(pl, C, "ey_log_target_grad");

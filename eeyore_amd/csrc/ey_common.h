@@ -73,6 +73,7 @@ struct ey_plan {
 // generic kernels (ey_generic.hip)
 int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                           void* target, void* grad, hipStream_t s);
+int ey_generic_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, hipStream_t s);
 int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                    const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                    uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,

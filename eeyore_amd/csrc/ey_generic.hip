@@ -96,7 +96,7 @@ static size_t lds_bytes(const EyModel& m, int nvec, size_t esz) {
 // gr receives the gradient of the (tempered) log-target.  lik/prior are the tempered parts.
 template <typename T, bool GRAD>
 __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, bool has_temp, T temp, T* lik_out,
-                         T* prior_out) {
+                         T* prior_out, T* row_out = nullptr) {
   const int lane = threadIdx.x;
   const T* x = static_cast<const T*>(m.x);
   const T* y = static_cast<const T*>(m.y);
@@ -129,6 +129,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
     const T* out = l.act + m.hoff[nl] * TS + lane;
     T* dcur = l.dl;
     T* dnext = l.dl + m.dmax * TS;
+    T row_lik = T(0);  // this row's term of the log-likelihood sum (ey_log_lik_rows)
     if (m.lik == EY_LIK_BCE_SUM) {
       for (int j = 0; j < dK; ++j) {
         const T o = out[j * TS];
@@ -136,6 +137,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
         // naive logs exactly as eeyore/stats/loss.py:2 (NaN once a sigmoid saturates)
         const T term = Num<T>::log(o) * yy + Num<T>::log(T(1) - o) * (T(1) - yy);
         if (valid) lik += term;
+        row_lik += term;
         if (GRAD) {
           const T d = (yy / o - (T(1) - yy) / (T(1) - o)) * dact_fn<T>(m.act[nl - 1], o);
           dcur[j * TS + lane] = valid ? d : T(0);
@@ -147,7 +149,8 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
       for (int j = 1; j < dK; ++j) mx = fmax(mx, out[j * TS]);
       T ssum = T(0);
       for (int j = 0; j < dK; ++j) ssum += Num<T>::exp(out[j * TS] - mx);
-      if (valid) lik += out[lab * TS] - (mx + Num<T>::log(ssum));
+      row_lik = out[lab * TS] - (mx + Num<T>::log(ssum));
+      if (valid) lik += row_lik;
       if (GRAD) {
         for (int j = 0; j < dK; ++j) {
           const T o = out[j * TS];
@@ -156,6 +159,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
         }
       }
     }
+    if (row_out && valid) row_out[n] = has_temp ? row_lik * temp : row_lik;
     if (GRAD) {
       // ---- backward
       for (int k = nl - 1; k >= 0; --k) {
@@ -219,7 +223,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
 // ----------------------------------------------------------------------------------------------- kernels
 template <typename T, bool GRAD>
 __global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, const T* temp, T* lik_o, T* prior_o,
-                                                     T* target_o, T* grad_o) {
+                                                     T* target_o, T* grad_o, T* rows_o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds<T> l = carve<T>(m, smem, 2);
   const int64_t c = blockIdx.x;
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, 
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
   T lik, prior;
-  const T t = eval_target<T, GRAD>(m, l, l.th, l.gr, ht, tc, &lik, &prior);
+  const T t = eval_target<T, GRAD>(m, l, l.th, l.gr, ht, tc, &lik, &prior, rows_o ? rows_o + c * m.N : nullptr);
   if (lane == 0) {
     if (lik_o) lik_o[c] = lik;
     if (prior_o) prior_o[c] = prior;
@@ -437,17 +441,17 @@ static int prep(K kernel, size_t bytes) {
 
 template <typename T>
 static int launch_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
-                             void* target, void* grad, hipStream_t s) {
+                             void* target, void* grad, hipStream_t s, void* rows = nullptr) {
   const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
   int rc;
   if (grad) {
     if ((rc = prep(k_log_target<T, true>, bytes))) return rc;
     hipLaunchKernelGGL((k_log_target<T, true>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
-                       (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)grad);
+                       (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)grad, (T*)nullptr);
   } else {
     if ((rc = prep(k_log_target<T, false>, bytes))) return rc;
     hipLaunchKernelGGL((k_log_target<T, false>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
-                       (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)nullptr);
+                       (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)nullptr, (T*)rows);
   }
   EY_HIP(hipGetLastError());
   return EY_OK;
@@ -457,6 +461,12 @@ int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int6
                           void* target, void* grad, hipStream_t s) {
   return pl->dtype == EY_F32 ? launch_log_target<float>(pl, theta, temp, C, lik, prior, target, grad, s)
                              : launch_log_target<double>(pl, theta, temp, C, lik, prior, target, grad, s);
+}
+
+int ey_generic_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, hipStream_t s) {
+  return pl->dtype == EY_F32
+             ? launch_log_target<float>(pl, theta, temp, C, nullptr, nullptr, nullptr, nullptr, s, rows)
+             : launch_log_target<double>(pl, theta, temp, C, nullptr, nullptr, nullptr, nullptr, s, rows);
 }
 
 template <typename T>

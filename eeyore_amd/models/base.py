@@ -151,6 +151,39 @@ class BayesianModel(LogTargetModel):
     def predictive_posterior(self, theta, x, y):
         return self._predictive_integrator(theta).integrate(x, y)
 
+    def _stack_samples(self, theta):
+        stack = theta if torch.is_tensor(theta) else torch.stack(list(theta))
+        return self._chains(stack if stack.dim() == 2 else stack.unsqueeze(0))[0]
+
+    def predictive_posterior_batched(self, theta, x, y):
+        """The reference's predictive_posterior (bayesian_model.py:58-62) for K points at once: x [K, d_0], y [K, d_K],
+        theta the stored samples ([S, P] tensor or a list of [P]).  Returns (estimates [K], dropped [K]): per point the
+        mean over samples of the likelihood of that ONE point, NaN integrands dropped and counted
+        (eeyore/integrators/mcintegrator.py:24-28).  One pass of the row log-likelihood kernel over S x K."""
+        th = self._stack_samples(theta)
+        rows = self._plan(x, y).log_lik_rows(th, temp=self.temperature)  # [S, K]
+        lik = torch.exp(rows)
+        ok = ~torch.isnan(lik)
+        kept = ok.sum(0)
+        est = torch.where(ok, lik, torch.zeros_like(lik)).sum(0) / kept.clamp(min=1)
+        est = torch.where(kept > 0, est, torch.full_like(est, float('nan')))
+        return est, (~ok).sum(0)
+
     def predictive_posterior_from_dataset(self, theta, dataset, num_points, shuffle=True, verbose=False, verbose_step=1):
-        return self._predictive_integrator(theta).integrate_from_dataset(
-            dataset, num_points, shuffle=shuffle, verbose=verbose, verbose_step=verbose_step)
+        """(integrals, indices, numbers of dropped samples) as bayesian_model.py:64-67 /
+        mcintegrator.py:38-63: points are drawn one at a time from a DataLoader(dataset, batch_size=1, shuffle) exactly
+        as there (same draws from the torch generator), then all of them are integrated in one device pass."""
+        from torch.utils.data import DataLoader
+        xs, ys, idxs = [], [], []
+        while len(xs) < num_points:
+            for item in DataLoader(dataset, batch_size=1, shuffle=shuffle):
+                if len(xs) == num_points:
+                    break
+                xs.append(item[0].reshape(1, -1))
+                ys.append(item[1].reshape(1, -1))
+                idxs.append(int(item[2]) if len(item) > 2 else -1)
+                if verbose and len(xs) % verbose_step == 0:
+                    print(f"Iteration {len(xs)} out of {num_points}")
+        est, dropped = self.predictive_posterior_batched(theta, torch.cat(xs), torch.cat(ys))
+        return (est.to(self.dtype), torch.tensor(idxs, dtype=torch.int64, device=est.device),
+                dropped.to(torch.int64))

@@ -111,6 +111,15 @@ class Plan:
                                       _stream(self.device)), "ey_log_target")
         return lik, prior
 
+    def log_lik_rows(self, theta, temp=None):
+        """[C, N]: the log-likelihood term of every data row under every chain's parameters (ey_log_lik_rows)."""
+        C = self._theta(theta)
+        rows = self.empty(C, self.N)
+        temp = self._opt(temp, C)
+        L.check(L.lib().ey_log_lik_rows(self.handle, L.ptr(theta), L.ptr(temp), C, L.ptr(rows), _stream(self.device)),
+                "ey_log_lik_rows")
+        return rows
+
     def log_target_grad(self, theta, temp=None):
         C = self._theta(theta)
         target, grad = self.empty(C), self.empty(C, self.P)

@@ -75,6 +75,12 @@ int ey_plan_set_prior(ey_plan* plan, const void* mu, const void* sigma, void* st
  * log_lik, log_prior: [C] outputs (either may be NULL). */
 int ey_log_target(ey_plan* plan, const void* theta, const void* temp, int64_t C, void* log_lik, void* log_prior,
                   void* stream);
+/* The N terms of BayesianModel.log_lik's sum, one per data row (the loss of eeyore/constants/constants.py:15-18 is a
+ * sum over rows): rows [C, N], rows[c, n] = log-likelihood of row n under theta[c] (times temp[c] if given).  This is
+ * the integrand of BayesianModel.predictive_posterior for N points and C posterior samples at once
+ * (eeyore/models/bayesian_model.py:58-67: exp of the log-likelihood of ONE point, averaged over samples by MCIntegrator,
+ * eeyore/integrators/mcintegrator.py:16-36). */
+int ey_log_lik_rows(ey_plan* plan, const void* theta, const void* temp, int64_t C, void* rows, void* stream);
 /* LogTargetModel.upto_grad_log_target (eeyore/models/log_target_model.py:15-23): target [C], grad [C,P]. */
 int ey_log_target_grad(ey_plan* plan, const void* theta, const void* temp, int64_t C, void* target, void* grad,
                        void* stream);

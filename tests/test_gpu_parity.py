@@ -713,6 +713,72 @@ def test_model_surface_predictive_posterior_and_batched_integrator():
     np.testing.assert_allclose(est.item(), np.mean(probs), rtol=1e-10)
 
 
+@pytest.mark.parametrize("dims,acts,lik,tag", [
+    ([4, 32, 32, 3], [1, 1, 0], 1, "f32"), ([4, 3, 3], [1, 0], 1, "f64"), ([2, 3, 2, 1], [1, 1, 1], 0, "f64"),
+    ([3, 5, 2], [2, 1], 0, "f32"),
+])
+def test_log_lik_rows_vs_oracle(dims, acts, lik, tag):
+    """ey_log_lik_rows: every row's term of the log-likelihood sum, against the numpy oracle run on one row at a time,
+    and their sum against ey_log_target."""
+    from eeyore_amd.plan import Plan
+    from oracle import mlp_oracle as mo
+    npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    rng = np.random.default_rng(sum(dims))
+    N, C = 70, 5  # more than one 64-row tile
+    x = rng.standard_normal((N, dims[0])).astype(npdt)
+    if lik == 1:
+        y = np.eye(dims[-1], dtype=npdt)[rng.integers(0, dims[-1], N)]
+    else:
+        y = (rng.random((N, dims[-1])) < 0.5).astype(npdt)
+    pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV)
+    pl.set_data(_t(x, dt), _t(y, dt))
+    pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
+    th = (0.5 * rng.standard_normal((C, pl.P))).astype(npdt)
+    temps = np.array([1.0, 0.5, 2.0, 1.0, 0.25], dtype=npdt)
+    rows = pl.log_lik_rows(_t(th, dt)).cpu().numpy()
+    rows_t = pl.log_lik_rows(_t(th, dt), temp=_t(temps, dt)).cpu().numpy()
+    lik_sum = pl.log_target(_t(th, dt))[0].cpu().numpy()
+    tol = 1e-10 if tag == "f64" else 2e-4
+    np.testing.assert_allclose(rows.sum(1), lik_sum, rtol=tol * 10, atol=tol * 10)
+    np.testing.assert_allclose(rows_t, rows * temps[:, None], rtol=tol)
+    for c in range(C):
+        for n in (0, 1, 63, 64, N - 1):
+            spec = mo.Spec(dims, acts, lik)
+            want = mo.log_lik(spec, th[c].astype(np.float64), x[n:n + 1].astype(np.float64),
+                              y[n:n + 1].astype(np.float64))
+            np.testing.assert_allclose(rows[c, n], want, rtol=tol, atol=tol)
+
+
+def test_predictive_posterior_batched_equals_the_point_by_point_form():
+    """predictive_posterior_batched / predictive_posterior_from_dataset (one device pass over samples x points)
+    against the reference-shaped loop (bayesian_model.py:58-67 with MCIntegrator.integrate, one point at a time),
+    including a sample whose likelihood is NaN (dropped and counted, mcintegrator.py:24-28)."""
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import XYDataset
+    from eeyore_amd.models import mlp
+    xor = XYDataset.from_eeyore('xor', dtype=torch.float64, device=DEV)
+    model = mlp.MLP(loss=loss_functions['binary_classification'],
+                    hparams=mlp.Hyperparameters(dims=[2, 2, 1], activations=[torch.sigmoid, torch.sigmoid]), device=DEV)
+    P = model.num_params()
+    torch.manual_seed(3)
+    samples = torch.randn(12, P, dtype=torch.float64, device=DEV)
+    samples[5] = 400.0  # saturates the output sigmoid: log(1 - 1) * 0 is NaN for the naive BCE (loss.py:2)
+    x, y = xor.x, xor.y
+    est, dropped = model.predictive_posterior_batched(samples, x, y)
+    for k in range(x.shape[0]):
+        e1, d1 = model.predictive_posterior(list(samples.unbind(0)), x[k:k + 1], y[k:k + 1])
+        np.testing.assert_allclose(est[k].item(), float(e1), rtol=1e-12)
+        assert int(dropped[k].item()) == d1
+    assert int(dropped.max().item()) >= 1
+    torch.manual_seed(11)
+    a = model.predictive_posterior_from_dataset(samples, xor, 6, shuffle=True)
+    torch.manual_seed(11)
+    integ = model._predictive_integrator(list(samples.unbind(0)))
+    b = integ.integrate_from_dataset(xor, 6, shuffle=True, dtype=torch.float64, device=DEV)
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=1e-12)
+    assert torch.equal(a[1].cpu(), b[1].cpu()) and torch.equal(a[2].cpu(), b[2].cpu())
+
+
 # --------------------------------------------------------------------------------------------- batched-GEMM path
 def _force_large(on):
     from eeyore_amd import _lib as L
