@@ -143,6 +143,38 @@ __device__ unsigned long long g_ey_wave_t[3 * 8192];  // per chain: kernel entry
 #define PH(i) do { } while (0)
 #define KO(i) do { } while (0)
 #endif
+// Packed f32 math (two elements per instruction at the rate of one): written on two-element vectors so that the
+// instruction selector sees v2f32 operations (it scalarises the same operations on a whole 16-element tile).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_add1(f32x2 a) { return a + 1.0f; }
+__device__ __forceinline__ f32x2 pk_h_one_minus_h(f32x2 h) { return __builtin_elementwise_fma(-h, h, h); }
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
+// sigmoid of a whole accumulator tile: exp2, packed "+1", rcp
+__device__ __forceinline__ f32x16 sigmoid_tile(const f32x16& a) {
+  f32x16 h;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    f32x2 e;
+    e[0] = (EY_ABLATE & 4) ? a[r] * 0.01f - 0.5f : __builtin_amdgcn_exp2f(a[r]);
+    e[1] = (EY_ABLATE & 4) ? a[r + 1] * 0.01f - 0.5f : __builtin_amdgcn_exp2f(a[r + 1]);
+    e = pk_add1(e);
+    h[r] = (EY_ABLATE & 4) ? e[0] : __builtin_amdgcn_rcpf(e[0]);
+    h[r + 1] = (EY_ABLATE & 4) ? e[1] : __builtin_amdgcn_rcpf(e[1]);
+  }
+  return h;
+}
+// d * h (1 - h) for a tile
+__device__ __forceinline__ f32x16 times_dsigmoid(const f32x16& d, const f32x16& h) {
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 h2 = {h[r], h[r + 1]}, d2 = {d[r], d[r + 1]};
+    const f32x2 v = pk_mul(d2, pk_h_one_minus_h(h2));
+    o[r] = v[0];
+    o[r + 1] = v[1];
+  }
+  return o;
+}
 __device__ __forceinline__ float sigmoid_from_scaled(float a) {
   if (EY_ABLATE & 4) return a * 0.01f + 0.5f;
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
@@ -319,9 +351,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     for (int s = 0; s < 2; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw[O_W0IMG + c * 5 + 2 * s + h], xt[c * 5 + 2 * s + h], acc, 0, 0, 0);
     const int lab = __float_as_int(xt[c * 5 + 4]);
-    f32x16 H0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) H0[r] = sigmoid_from_scaled(acc[r]);
+    const f32x16 H0 = sigmoid_tile(acc);
     store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
     PH(0);
     // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
@@ -338,9 +368,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], H0[4 * q + j], acc, 0, 0, 0);
     }
     pace_apply(pc, pace_theirs);  // while the F1 products run
-    f32x16 H1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) H1[r] = sigmoid_from_scaled(acc[r]);
+    const f32x16 H1 = sigmoid_tile(acc);
     store_T(lw + O_TB0, H1, c, h);  // transposed copy for dW2; the logits and the softmax run while it lands
     PH(1);
     // ---- F2: logits = W2 H1^T + b2 with the 16-block 4x4x1 product; each half sums its 16 features
@@ -401,9 +429,10 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
       d = mfma4(wt[1], d2[1], d);
       d = mfma4(wt[2], d2[2], d);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i] * __builtin_fmaf(-H1[4 * q + i], H1[4 * q + i], H1[4 * q + i]);
+      for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i];
     }
     PH(5);
+    D1 = times_dsigmoid(D1, H1);
     wave_lds_fence();
     store_T(lw + O_TB0, D1, c, h);
     wave_lds_fence();
@@ -430,9 +459,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
-    f32x16 D0u;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) D0u[r] = acc[r] * __builtin_fmaf(-H0U[r], H0U[r], H0U[r]);
+    const f32x16 D0u = times_dsigmoid(acc, H0U);
     PH(8);
     // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
     const float* x2 = xt + 160 + (jj * 2 + h) * 16;
