@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
+    ap.add_argument("--iters-per-launch", type=int, default=10,
+                    help="HMC iterations (bench steps) per kernel launch: ey_hmc_run, as HMC.run issues them; 1 = ey_hmc_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true", help="time the generic VALU kernel instead of the MFMA one")
     args = ap.parse_args()
@@ -115,15 +117,28 @@ def main():
     flags = L.EY_FORCE_GENERIC if args.force_generic else 0
     seed = 2024
 
-    def step(it):
-        plan.hmc_step(theta, target, grad, STEP_SIZE, L_STEPS, seed=seed, it=it, chain_offset=chain_offset, flags=flags,
-                      out=out)
+    ipl = max(1, args.iters_per_launch)
+    if args.force_generic:
+        ipl = 1  # the generic family replays attached moments from recorded samples; keep its one-step form
+
+    def steps(it, n):
+        """n bench steps = n HMC iterations of every chain, starting at iteration number `it`: whole launches of `ipl`
+        iterations (what HMC.run does after burn-in), then the remainder."""
+        done = 0
+        while done < n:
+            k = min(ipl, n - done)
+            if k == 1:
+                plan.hmc_step(theta, target, grad, STEP_SIZE, L_STEPS, seed=seed, it=it + done,
+                              chain_offset=chain_offset, flags=flags, out=out)
+            else:
+                plan.hmc_run(theta, target, grad, STEP_SIZE, L_STEPS, k, seed=seed, it=it + done,
+                             chain_offset=chain_offset, flags=flags, out=out)
+            done += k
 
     # the running chain moments behind the R-hat summary are accumulated by the step kernel itself (attached moments)
     stats.attach(plan)
     it = 1
-    for _ in range(args.warmup):
-        step(it); it += 1
+    steps(it, args.warmup); it += args.warmup
     if args.warmup > 1:
         stats.summary()  # also warms the torch elementwise kernels used in the timed region
     stats = ChainStats(C, P, dev)
@@ -133,8 +148,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(it); it += 1
+    steps(it, args.steps); it += args.steps
     summ = stats.summary() if args.steps > 1 else None  # RCCL all-reduce of [3, P] partial sums when world > 1
     torch.cuda.synchronize()
     if world > 1:
@@ -150,15 +164,15 @@ def main():
     n_ev = 10
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     for a, b in evs:
-        a.record(); step(it); b.record(); it += 1
+        a.record(); steps(it, ipl); b.record(); it += ipl
     torch.cuda.synchronize()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # one launch of ipl iterations
 
     if rank == 0:
         f_step = flops_per_leapfrog_step(DIMS, N_ROWS)
         total_chains = C * world
         value = total_chains * L_STEPS * args.steps / elapsed
-        achieved_tflops = f_step * L_STEPS * C / (kern_ms * 1e-3) / 1e12
+        achieved_tflops = f_step * L_STEPS * C * ipl / (kern_ms * 1e-3) / 1e12
         line = {
             "metric": "leapfrog-steps/sec x chains, HMC MLP(4-32-32-3)",
             "value": value,
@@ -178,14 +192,15 @@ def main():
                             f"{'; configs[3] sharding' if world > 1 else ''})",
                 "chains_per_gpu": C, "num_steps": L_STEPS, "step_size": STEP_SIZE, "rng": "in-kernel Philox4x32-10",
                 "kernel": "generic" if args.force_generic else plan.kernel,
-                "gradient_evaluations_per_iteration": L_STEPS,
+                "gradient_evaluations_per_iteration": L_STEPS, "iterations_per_launch": ipl,
                 "acceptance": None if summ is None else round(summ["acceptance"], 4),
                 "max_rhat": None if summ is None else round(float(summ["rhat"].max().item()), 4),
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "kernel_ms": kern_ms, "flops_per_leapfrog_step_per_chain": f_step,
+                "kernel_ms": kern_ms, "leapfrog_steps_per_launch": C * L_STEPS * ipl,
+                "flops_per_leapfrog_step_per_chain": f_step,
                 "peak_measured": MEASURED_F32_MFMA_TFLOPS, "frac_of_measured": achieved_tflops / MEASURED_F32_MFMA_TFLOPS,
             },
         }
@@ -196,7 +211,9 @@ def main():
             with open(pmc) as f:
                 pm = json.load(f)
             if pm.get("kernel", "").startswith("k_mfma32"):
-                line["roofline"]["traffic"] = (2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024.0
+                # per launch of `ipl` iterations (the PMC run's dispatches held pm["iterations_per_launch"] each)
+                line["roofline"]["traffic"] = ((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024.0 * ipl
+                                               / pm.get("iterations_per_launch", 1))
                 line["roofline"]["traffic_source"] = pm.get("source", "profiles/pmc_latest.json")
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(xs, ys, sigma)

@@ -49,6 +49,18 @@ class ChainBuffer(Chain):
             self.bufs[k][self.n].copy_(state[k])
         self.n += 1
 
+    def block(self, k, state):
+        """Writable views of the next k iterations of every stored key (after reserving room), for a kernel that
+        records k iterations in one launch; ``commit(k)`` makes them part of the chain."""
+        any_buf = next(iter(self.bufs.values()), None)
+        need = self.n + k
+        if any_buf is None or any_buf.shape[0] < need:
+            self.reserve(max(need, self.capacity, 2 * (0 if any_buf is None else any_buf.shape[0])), state)
+        return {key: self.bufs[key][self.n:self.n + k] for key in self.keys}
+
+    def commit(self, k):
+        self.n += k
+
     def detach_and_update(self, state):
         self.update(state)  # update() copies into the buffer, so no clone is needed
 

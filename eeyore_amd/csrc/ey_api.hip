@@ -278,6 +278,67 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
   return moments_trailing(pl, rc, theta, accepted, C, stream);
 }
 
+__global__ void k_count_accepts(const unsigned char* __restrict__ accepted, int* __restrict__ count, int64_t C) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C && accepted[c]) count[c] += 1;
+}
+
+int ey_hmc_run(ey_plan* pl, void* theta, void* target, void* grad, double step, const void* step_vec, int L,
+               const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
+               int n_iters, void* samples, void* targets, void* accepted_rec, void* accept_count, void* accepted,
+               void* stream) {
+  int rc = check_ready(pl, C, "ey_hmc_run");
+  if (rc) return rc < 0 ? rc : EY_OK;
+  if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_hmc_run: null argument");
+  if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_run: num_steps must be >= 1");
+  if (n_iters < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_run: n_iters must be >= 1");
+  if (C == 0) return EY_OK;
+  if ((rc = moments_check(pl, C, "ey_hmc_run"))) return rc;
+  EY_HIP(hipSetDevice(pl->device));
+  hipStream_t s = (hipStream_t)stream;
+  EyRun run = {n_iters, samples, targets, accepted_rec, (int*)accept_count};
+  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+    return ey_mfma32_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
+                         flags, accepted, nullptr, nullptr, nullptr, s, &run);
+  if (!use_large(pl)) {
+    rc = ey_generic_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
+                        flags, accepted, nullptr, nullptr, nullptr, s, &run);
+    if (rc != EY_OK || !pl->mom_s1) return rc;
+    // the generic kernels do not fuse the moments: replay them from the recorded samples when there are any
+    if (n_iters > 1 && (!samples || !accepted_rec))
+      EY_FAIL(EY_ERR_UNSUPPORTED, "ey_hmc_run: attached moments with n_iters > 1 need the samples and accepted records "
+                                  "on this kernel family");
+    const size_t es = esize(pl);
+    for (int it = 0; it < n_iters; ++it) {
+      const void* th_it = n_iters > 1 ? (const void*)((const char*)samples + (size_t)it * C * pl->m.P * es) : theta;
+      const void* ac_it = accepted_rec ? (const void*)((const char*)accepted_rec + (size_t)it * C) : accepted;
+      rc = ey_stats_update(th_it, ac_it, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2, pl->mom_acc, stream);
+      if (rc) return rc;
+    }
+    return EY_OK;
+  }
+  // models beyond LDS: the layerwise path has no in-kernel iteration loop; the launches are queued back to back
+  const size_t es = esize(pl);
+  for (int it = 0; it < n_iters; ++it) {
+    rc = ey_large_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter + it,
+                      chain_offset, flags, accepted, nullptr, nullptr, nullptr, s);
+    if (rc) return rc;
+    if (samples)
+      EY_HIP(hipMemcpyAsync((char*)samples + (size_t)it * C * pl->m.P * es, theta, (size_t)C * pl->m.P * es,
+                            hipMemcpyDeviceToDevice, s));
+    if (targets)
+      EY_HIP(hipMemcpyAsync((char*)targets + (size_t)it * C * es, target, (size_t)C * es, hipMemcpyDeviceToDevice, s));
+    if (accepted_rec)
+      EY_HIP(hipMemcpyAsync((char*)accepted_rec + (size_t)it * C, accepted, (size_t)C, hipMemcpyDeviceToDevice, s));
+    if (accept_count)
+      hipLaunchKernelGGL(k_count_accepts, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s,
+                         (const unsigned char*)accepted, (int*)accept_count, C);
+    if ((rc = moments_trailing(pl, EY_OK, theta, accepted, C, stream))) return rc;
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
 int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                     int64_t C, void* target, void* grad, void* stream) {
   int rc = check_ready(pl, C, "ey_hmc_leapfrog");

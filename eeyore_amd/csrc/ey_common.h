@@ -70,6 +70,15 @@ struct ey_plan {
   size_t work_bytes;
 };
 
+// ey_hmc_run: n_iters consecutive draws inside one launch, with optional per-iteration records
+struct EyRun {
+  int n_iters;
+  void* samples;    // [n_iters, C, P] of the plan's dtype, or null
+  void* targets;    // [n_iters, C], or null
+  void* accepted;   // [n_iters, C] uint8, or null
+  int* accept_count;  // [C] int32 (+=), or null
+};
+
 // generic kernels (ey_generic.hip)
 int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                           void* target, void* grad, hipStream_t s);
@@ -77,7 +86,7 @@ int ey_generic_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, in
 int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                    const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                    uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                   hipStream_t s);
+                   hipStream_t s, const EyRun* run = nullptr);
 int ey_generic_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                         int64_t C, void* target, void* grad, hipStream_t s);
 int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
@@ -103,7 +112,7 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s);
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                  hipStream_t s);
+                  hipStream_t s, const EyRun* run = nullptr);
 int ey_mfma32_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,
                               hipStream_t s);
 int ey_mfma32_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,

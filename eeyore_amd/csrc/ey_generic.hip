@@ -246,8 +246,10 @@ __global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, 
 template <typename T>
 __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T* grad, const T* p0, const T* u_in,
                                               T step, const T* step_vec, int L, const T* temp, uint64_t seed,
-                                              uint64_t iter, uint64_t chain_offset, int recompute,
-                                              unsigned char* accepted, T* rate_o, T* hcur_o, T* hprop_o) {
+                                              uint64_t iter0, uint64_t chain_offset, int recompute,
+                                              unsigned char* accepted, T* rate_o, T* hcur_o, T* hprop_o, int n_iters,
+                                              T* rec_samples, T* rec_targets, unsigned char* rec_accepted,
+                                              int* accept_count, int64_t C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds<T> l = carve<T>(m, smem, 3);
   const int64_t c = blockIdx.x;
@@ -257,6 +259,11 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
   const T tc = ht ? temp[c] : T(1);
   const T eps = step_vec ? step_vec[c] : step;
   T* p = l.a;
+  T t_state = target[c];
+  // ey_hmc_run: n_iters draws in one launch; every lane re-reads only what it wrote itself (theta, grad), the
+  // log-target is carried in a register
+  for (int it = 0; it < n_iters; ++it) {
+  const uint64_t iter = iter0 + (uint64_t)it;
   // momentum ~ N(0, I)  (hmc.py:134)
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   T kin = T(0);
@@ -268,7 +275,7 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
     kin += pi * pi;
   }
   kin = wave_sum(kin);
-  const T t_cur = target[c];
+  const T t_cur = t_state;
   const T h_cur = -t_cur + T(0.5) * kin;  // hmc.py:91-98,137
   __syncthreads();
   T t = t_cur;
@@ -296,12 +303,22 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
       grad[c * P + i] = l.gr[i];
     }
   }
+  if (acc) t_state = t;
+  if (rec_samples) {  // the state the chain is left in (what ChainList.update stores, chain_list.py:64-67)
+    T* so = rec_samples + ((int64_t)it * C + c) * P;
+    for (int i = lane; i < P; i += WAVE) so[i] = acc ? l.th[i] : theta[c * P + i];
+  }
   if (lane == 0) {
     if (acc) target[c] = t;
     accepted[c] = acc ? 1 : 0;
     if (rate_o) rate_o[c] = rate;
     if (hcur_o) hcur_o[c] = h_cur;
     if (hprop_o) hprop_o[c] = h_prop;
+    if (rec_targets) rec_targets[(int64_t)it * C + c] = t_state;
+    if (rec_accepted) rec_accepted[(int64_t)it * C + c] = acc ? 1 : 0;
+    if (accept_count && acc) accept_count[c] += 1;
+  }
+  __syncthreads();
   }
 }
 
@@ -473,14 +490,16 @@ template <typename T>
 static int launch_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                       const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                       uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                      hipStream_t s) {
+                      hipStream_t s, const EyRun* run) {
   const size_t bytes = lds_bytes(pl->m, 3, sizeof(T));
   int rc;
   if ((rc = prep(k_hmc<T>, bytes))) return rc;
   hipLaunchKernelGGL((k_hmc<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
                      (const T*)p0, (const T*)u, (T)step, (const T*)step_vec, L, (const T*)temp, seed, iter,
                      chain_offset, (int)((flags & EY_RECOMPUTE_INITIAL_GRAD) != 0), (unsigned char*)accepted, (T*)rate,
-                     (T*)hcur, (T*)hprop);
+                     (T*)hcur, (T*)hprop, run ? run->n_iters : 1, run ? (T*)run->samples : nullptr,
+                     run ? (T*)run->targets : nullptr, run ? (unsigned char*)run->accepted : nullptr,
+                     run ? run->accept_count : nullptr, C);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
@@ -488,12 +507,12 @@ static int launch_hmc(ey_plan* pl, void* theta, void* target, void* grad, const 
 int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                    const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                    uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                   hipStream_t s) {
+                   hipStream_t s, const EyRun* run) {
   return pl->dtype == EY_F32
              ? launch_hmc<float>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset,
-                                 flags, accepted, rate, hcur, hprop, s)
+                                 flags, accepted, rate, hcur, hprop, s, run)
              : launch_hmc<double>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset,
-                                  flags, accepted, rate, hcur, hprop, s);
+                                  flags, accepted, rate, hcur, hprop, s, run);
 }
 
 template <typename T>

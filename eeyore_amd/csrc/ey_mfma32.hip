@@ -85,6 +85,12 @@ struct MfArgs {
   float *rate, *hcur, *hprop;
   int balance;         // 1: the two waves of a SIMD keep in step through s_setprio (see Pace)
   double *mom_s1, *mom_s2, *mom_acc;  // attached running moments (ey_plan_attach_moments) or null
+  // ey_hmc_run: n_iters consecutive draws per launch and the per-iteration records (each nullable)
+  int n_iters;
+  float* rec_samples;          // [n_iters, C, P]
+  float* rec_targets;          // [n_iters, C]
+  unsigned char* rec_accepted; // [n_iters, C]
+  int* accept_count;           // [C], +=
 };
 
 // The arguments as the kernels read them: in place in the kernarg segment (constant address space, scalar loads).
@@ -582,8 +588,13 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
 
 // One chain of one launch: everything between reading theta and writing the accepted state back.
 template <int MODE, int PARK, bool UPRIOR>
-__device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int c,
-                                          const int h, const int lane, Pace& pc) {
+__device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int it,
+                                          const int c, const int h, const int lane, Pace& pc) {
+  // Later iterations of one launch read what this wave's lanes wrote at the end of the previous one.  Workgroup scope
+  // is enough (and only costs a wait for the outstanding stores): all accesses go through this CU's vector cache in
+  // order; an agent-scope release would write the whole L2 of the XCD back every iteration.
+  if (it > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const uint64_t iter = A.iter + (uint64_t)it;
 #if EY_PHASE_TIMING
   const bool kt_on = (blockIdx.x & 63) == 0 && pc.wave == 0;
   if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain + 1] = __builtin_amdgcn_s_memrealtime();
@@ -610,7 +621,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   if (MODE == MODE_MALA || MODE == MODE_MH) {
     // MALA.draw (eeyore/samplers/mala.py:46-82) / MetropolisHastings.draw (metropolis_hastings.py:41-73): one
     // evaluation at the proposal; p holds the proposal, gp its gradient
-    const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_NORMAL);
+    const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_NORMAL);
     const float* zin = A.p0 ? A.p0 + chain * NPAR : nullptr;
     const float sc = A.step_vec ? sqrtf(eps) : A.sqrt_step;  // scale = sqrt(step), mala.py:39
     float qf = 0.0f;
@@ -639,7 +650,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
       const float inv2v = 1.0f / (2.0f * sc * sc);
       log_rate += (wsum(qf) - wsum(qb)) * inv2v;  // the -P log s - P/2 log 2pi terms cancel (mala.py:58-64)
     }
-    const EyRng ru = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_UNIFORM);
+    const EyRng ru = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_UNIFORM);
     const float u = A.u ? A.u[chain] : ey_rng_uniform<float>(ru);
     const bool acc = __logf(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
     if (acc) {
@@ -658,7 +669,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
 
   float t_cur = 0.0f, kin = 0.0f;
   if (MODE == MODE_HMC) {
-    const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_NORMAL);
+    const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_NORMAL);
     const float* p0 = A.p0 ? A.p0 + chain * NPAR : nullptr;
     for_each(p, c, h, lane, [&](float& v, int idx, bool counts) {
       v = p0 ? p0[idx] : ey_rng_normal<float>(rn, (uint32_t)idx);   // hmc.py:134
@@ -708,7 +719,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   const float h_prop = -t + 0.5f * kin;
   float rate = __expf(h_cur - h_prop);  // hmc.py:143-146
   if (rate > 1.0f) rate = 1.0f;
-  const EyRng ru = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, A.iter, EY_STREAM_UNIFORM);
+  const EyRng ru = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_UNIFORM);
   const float u = A.u ? A.u[chain] : ey_rng_uniform<float>(ru);
   const bool acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
   if (acc) {
@@ -723,6 +734,18 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     if (A.hprop) A.hprop[chain] = h_prop;
   }
   if (A.mom_s1) add_moments(A, chain, th, thg, !acc, acc, c, h, lane);
+  if (A.rec_samples) {  // the state this chain is left in (what ChainList.update stores, chain_list.py:64-67)
+    float* so = A.rec_samples + ((int64_t)it * A.C + chain) * NPAR;
+    const float* old = thg;
+    asm volatile("" : "+s"(old));  // see add_moments
+    for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) so[idx] = acc ? v : old[idx]; });
+  }
+  if (lane == 0) {
+    if (A.rec_targets) A.rec_targets[(int64_t)it * A.C + chain] = acc ? t : t_cur;
+    if (A.rec_accepted) A.rec_accepted[(int64_t)it * A.C + chain] = acc ? 1 : 0;
+    if (A.accept_count && acc) A.accept_count[chain] += 1;
+  }
+  if (A.n_iters > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #if EY_PHASE_TIMING
   if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain + 2] = __builtin_amdgcn_s_memrealtime();
   KO(5);
@@ -786,20 +809,24 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   {  // row tiles this wave evaluates in the whole launch
     const int64_t mine = first < A.C ? (A.C - first + stride - 1) / stride : 0;
     const int evals = (MODE == MODE_HMC) ? A.L + (A.recompute ? 1 : 0) : (MODE == MODE_LEAPFROG ? A.L + 1 : 1);
-    pc.left = (int)std::min<int64_t>(mine * evals * A.ntiles, 0x3fffffff);
+    const int iters = (MODE == MODE_HMC) ? A.n_iters : 1;
+    pc.left = (int)std::min<int64_t>(mine * evals * A.ntiles * iters, 0x3fffffff);
     if (lane == 0) ctl[wave] = pc.left;
   }
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(ctl[pc.partner]) == 0) pc.on = false;  // the partner has no chain at all
-  for (int64_t chain = first; chain < A.C; chain += stride) {  // whole waves; no workgroup synchronisation below
-    // Re-read the arguments from the kernarg segment in every round: hoisted out of this loop they would all stay
-    // live in scalar registers for the whole kernel (106 SGPRs, spilled into vector registers, which then spill too).
-    KArgs* Ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(Ap));
+  const int n_iters = (MODE == MODE_HMC) ? A.n_iters : 1;
+  for (int it = 0; it < n_iters; ++it) {
+    for (int64_t chain = first; chain < A.C; chain += stride) {  // whole waves; no workgroup synchronisation below
+      // Re-read the arguments from the kernarg segment in every round: hoisted out of this loop they would all stay
+      // live in scalar registers for the whole kernel (106 SGPRs, spilled into vector registers, which then spill too).
+      KArgs* Ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(Ap));
 #if EY_PHASE_TIMING
-    if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain] = rt_entry;
+      if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain] = rt_entry;
 #endif
-    run_chain<MODE, PARK, UPRIOR>(*Ap, xs, lw, chain, c, h, lane, pc);
+      run_chain<MODE, PARK, UPRIOR>(*Ap, xs, lw, chain, it, c, h, lane, pc);
+    }
   }
   if (lane == 0) __hip_atomic_store(&ctl[wave], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // nothing left
 }
@@ -917,13 +944,21 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                  hipStream_t s) {
+                  hipStream_t s, const EyRun* run) {
   MfArgs a = {};
   a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)grad;
   a.p0 = (const float*)p0; a.u = (const float*)u; a.step = (float)step; a.step_vec = (const float*)step_vec;
   a.L = L; a.temp = (const float*)temp; a.seed = seed; a.iter = iter; a.chain_offset = chain_offset;
   a.recompute = (flags & EY_RECOMPUTE_INITIAL_GRAD) ? 1 : 0;
   a.accepted = (unsigned char*)accepted; a.rate = (float*)rate; a.hcur = (float*)hcur; a.hprop = (float*)hprop;
+  a.n_iters = 1;
+  if (run) {
+    a.n_iters = run->n_iters;
+    a.rec_samples = (float*)run->samples;
+    a.rec_targets = (float*)run->targets;
+    a.rec_accepted = (unsigned char*)run->accepted;
+    a.accept_count = run->accept_count;
+  }
   return mf_launch<MODE_HMC>(pl, a, s);
 }
 

@@ -147,9 +147,10 @@ class Plan:
         L.check(L.lib().ey_plan_attach_moments(self.handle, None, None, None, 0), "ey_plan_attach_moments")
         self._moments = None
 
-    def _stepped(self):
+    def _stepped(self, times=1):
         if self._moments is not None and self._moments[3] is not None:
-            self._moments[3]()
+            for _ in range(times):
+                self._moments[3]()
 
     def hmc_step(self, theta, target, grad, step, num_steps, p0=None, u=None, step_vec=None, temp=None, seed=0, it=0,
                  chain_offset=0, flags=0, out=None):
@@ -163,6 +164,31 @@ class Plan:
                                     int(chain_offset), int(flags), L.ptr(out["accepted"]), L.ptr(out["rate"]),
                                     L.ptr(out["h_cur"]), L.ptr(out["h_prop"]), _stream(self.device)), "ey_hmc_step")
         self._stepped()
+        return out
+
+    def hmc_run(self, theta, target, grad, step, num_steps, n_iters, step_vec=None, temp=None, seed=0, it=0,
+                chain_offset=0, flags=0, samples=None, targets=None, accepted_rec=None, accept_count=None, out=None):
+        """``n_iters`` HMC iterations (it, it + 1, ...) of every chain in ONE launch (ey_hmc_run): the in-kernel Philox
+        streams only, bit-identical to ``n_iters`` calls of ``hmc_step`` without ``p0`` / ``u``.  Optional records of the
+        state after each iteration: ``samples`` [n_iters, C, P], ``targets`` [n_iters, C], ``accepted_rec`` [n_iters, C]
+        uint8 (contiguous views, e.g. slices of a ChainBuffer's storage); ``accept_count`` [C] int32 is incremented."""
+        C = self._theta(theta)
+        if out is None:
+            out = dict(accepted=self.empty(C, dtype=torch.uint8))
+        temp, step_vec = self._opt(temp, C), self._opt(step_vec, C)
+        n_iters = int(n_iters)
+        for name, t, shape, dt in (("samples", samples, (n_iters, C, self.P), self.dtype),
+                                   ("targets", targets, (n_iters, C), self.dtype),
+                                   ("accepted_rec", accepted_rec, (n_iters, C), torch.uint8),
+                                   ("accept_count", accept_count, (C,), torch.int32)):
+            if t is not None and (tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous()
+                                  or t.device != self.device):
+                raise ValueError(f"{name} must be a contiguous {dt} tensor of shape {shape} on the plan's device")
+        L.check(L.lib().ey_hmc_run(self.handle, L.ptr(theta), L.ptr(target), L.ptr(grad), float(step), L.ptr(step_vec),
+                                   int(num_steps), L.ptr(temp), C, int(seed), int(it), int(chain_offset), int(flags),
+                                   n_iters, L.ptr(samples), L.ptr(targets), L.ptr(accepted_rec), L.ptr(accept_count),
+                                   L.ptr(out["accepted"]), _stream(self.device)), "ey_hmc_run")
+        self._stepped(n_iters)
         return out
 
     def leapfrog(self, theta, p, step, num_steps, step_vec=None, temp=None):

@@ -97,6 +97,19 @@ int ey_hmc_step(ey_plan* plan, void* theta, void* target, void* grad, const void
                 uint64_t chain_offset, uint32_t flags, void* accepted, void* accept_rate, void* H_cur, void* H_prop,
                 void* stream);
 
+/* n_iters consecutive iterations (iter, iter + 1, ...) of HMC.draw for every chain inside ONE launch: exactly what
+ * n_iters calls of ey_hmc_step with p0 = u = NULL do (same Philox streams, bit-identical states), without the launches
+ * in between and with every chain looping on its own.  This is SerialSampler.run's inner loop
+ * (eeyore/samplers/serial_sampler.py:41-52) for the iterations in which nothing on the host looks at the state
+ * (no tuner step, no minibatch change).  Records, each nullable: samples [n_iters, C, P], targets [n_iters, C] and
+ * accepted_rec [n_iters, C] uint8 = the state of every chain after each iteration, i.e. what ChainList.update stores
+ * (eeyore/chains/chain_list.py:64-67); accept_count [C] int32 is incremented per accepted iteration.
+ * accepted [C] uint8 receives the last iteration's flags.  Attached moments are accumulated every iteration. */
+int ey_hmc_run(ey_plan* plan, void* theta, void* target, void* grad, double step, const void* step_vec, int L,
+               const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
+               int n_iters, void* samples, void* targets, void* accepted_rec, void* accept_count, void* accepted,
+               void* stream);
+
 /* HMC.leapfrog(position0, momentum0, x, y) (eeyore/samplers/hmc.py:100-124) for C chains, exactly as the
  * reference runs it: L steps, L+1 gradient evaluations, final momentum negated.  theta [C,P] and p [C,P] are
  * in/out (position_L, momentum_L); target [C] and grad [C,P] receive the log-target and its gradient at

@@ -389,6 +389,42 @@ def test_sampler_surface_batched_philox():
         assert torch.isfinite(ch.get_target_vals()).all()
 
 
+def test_hmc_fused_run_loop_gives_the_same_chains():
+    """HMC.run with blocks of iterations per launch (ey_hmc_run, records written straight into the chain buffer)
+    against the same run with one launch per iteration: identical chains, targets and accept flags; with a per-chain
+    tuner the burn-in still goes iteration by iteration."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    from eeyore_amd.tuners import PerChainDATuner
+    data = synthetic.iris_shaped(dtype=torch.float32, device=DEV)
+    hp = mlp.Hyperparameters(dims=[4, 32, 32, 3], bias=3 * [True], activations=[torch.sigmoid, torch.sigmoid, None])
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'], hparams=hp, dtype=torch.float32, device=DEV)
+    P = model.num_params()
+    model.prior = Normal(torch.zeros(P, device=DEV), (3 * torch.ones(P, device=DEV)).sqrt())
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    C = 96
+    th0 = 0.1 * torch.randn(C, P, device=DEV)
+    for with_tuner in (False, True):
+        runs = []
+        for block in (0, 4, 256):
+            tuner = PerChainDATuner(torch.full((C,), 0.02, device=DEV), num_steps=6) if with_tuner else None
+            s = HMC(model, theta0=th0, dataloader=loader, seed=7, step=0.02, num_steps=6, tuner=tuner)
+            s.fused_block = block
+            s.run(num_epochs=17, num_burnin_epochs=6)
+            ch = s.get_chain()
+            assert ch.get_samples().shape == (11, C, P) and s.counter.idx == 17
+            runs.append((ch.get_samples().clone(), ch.get_target_vals().clone(), ch.get_accepted().clone(),
+                         s.current['sample'].clone()))
+        for other in runs[1:]:
+            for a, b in zip(runs[0], other):
+                assert torch.equal(a, b)
+        assert 0.05 < runs[0][2].float().mean().item() <= 1.0
+
+
 # --------------------------------------------------------------------------------------------- MFMA kernel family
 def _cfg3_plan(N=None, seed=0):
     from eeyore_amd.datasets import synthetic
@@ -980,3 +1016,52 @@ def test_chain_buffer_ess_after_a_short_run():
     assert ok.float().mean().item() > 0.99
     assert (ess[ok] > 1.0).all() and (ess[ok] < 20 * n).all()
     assert tuple(buf.mc_se().shape) == (C, pl.P)
+
+
+@pytest.mark.parametrize("kind", ["mfma32", "generic_f32", "generic_f64", "bgemm"])
+def test_hmc_run_equals_consecutive_steps(kind):
+    """ey_hmc_run: n iterations inside one launch leave every chain exactly where n calls of ey_hmc_step (in-kernel
+    Philox streams) leave it, and the per-iteration records are the states in between."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.distributed import ChainStats
+    if kind == "bgemm":
+        _force_large(True)
+    try:
+        if kind == "generic_f64":
+            rec = groups(load("g4_hmc_traces.npz"))["mlp2321"]
+            pl, step, nl = _plan(rec, torch.float64), 0.3, 6
+        else:
+            rec, pl = _cfg3_plan()
+            step, nl = 0.03, 5
+        flags = L.EY_FORCE_GENERIC if kind.startswith("generic") else 0
+        C, n = (2300 if kind == "mfma32" else 40), 7  # mfma32: more chains than resident waves
+        th = 0.2 * pl.philox_normal(C, seed=31, it=0)
+        t, g = pl.log_target_grad(th)
+        a = [th.clone(), t.clone(), g.clone()]
+        b = [th.clone(), t.clone(), g.clone()]
+        want_s, want_t, want_a = [], [], []
+        st_a = ChainStats(C, pl.P, DEV)
+        for it in range(n):
+            out = pl.hmc_step(*a, step, nl, seed=31, it=10 + it, flags=flags)
+            want_s.append(a[0].clone()); want_t.append(a[1].clone()); want_a.append(out["accepted"].clone())
+            st_a.update(a[0], out["accepted"])
+        samples = pl.empty(n, C, pl.P)
+        targets = pl.empty(n, C)
+        acc_rec = pl.empty(n, C, dtype=torch.uint8)
+        count = torch.zeros(C, dtype=torch.int32, device=DEV)
+        st_b = ChainStats(C, pl.P, DEV)
+        st_b.attach(pl)
+        out = pl.hmc_run(*b, step, nl, n, seed=31, it=10, flags=flags, samples=samples, targets=targets,
+                         accepted_rec=acc_rec, accept_count=count)
+        pl.detach_moments()
+        assert torch.equal(b[0], a[0]) and torch.equal(b[1], a[1]) and torch.equal(b[2], a[2])
+        assert torch.equal(samples, torch.stack(want_s)) and torch.equal(targets, torch.stack(want_t))
+        assert torch.equal(acc_rec, torch.stack(want_a)) and torch.equal(out["accepted"], want_a[-1])
+        assert torch.equal(count.long(), torch.stack(want_a).long().sum(0))
+        assert 0 < count.sum().item() < n * C
+        assert st_b.n == n and torch.equal(st_b.s1, st_a.s1) and torch.equal(st_b.s2, st_a.s2)
+        assert torch.equal(st_b.acc, st_a.acc)
+        with pytest.raises(ValueError):
+            pl.hmc_run(*b, step, nl, 0, seed=1, it=1)
+    finally:
+        _force_large(False)

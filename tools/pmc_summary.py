@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSV output: mean counter value per dispatch of the dominant kernel.
-usage: pmc_summary.py <dir> [kernel-substring] [json-out]"""
+usage: pmc_summary.py <dir> [kernel-substring] [json-out] [HMC iterations per dispatch]"""
 import csv
 import glob
 import json
@@ -23,7 +23,9 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
     print(f"matrix-pipe busy fraction    {mean['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (mean['GRBM_GUI_ACTIVE'] / 8):18.3f}")
 if len(sys.argv) > 3 and "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+    ipl = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     json.dump({"kernel": "k_mfma32<0,8,12,true> (HMC trajectory)", "FETCH_SIZE_KB": mean["FETCH_SIZE"],
-               "WRITE_SIZE_KB": mean["WRITE_SIZE"], "dispatches": n,
-               "source": "tools/pmc_passes.sh (rocprofv3 --pmc, separate passes), 4096 chains x L=20 per dispatch"},
+               "WRITE_SIZE_KB": mean["WRITE_SIZE"], "dispatches": n, "iterations_per_launch": ipl,
+               "source": f"tools/pmc_passes.sh (rocprofv3 --pmc, separate passes), 4096 chains x L=20 x {ipl} "
+                         f"iterations per dispatch"},
               open(sys.argv[3], "w"), indent=1)
