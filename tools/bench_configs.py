@@ -41,6 +41,16 @@ dt = timed(f1, 200)
 print(f"cfg1 HMC 1 chain MLP(2-2-1) XOR f64 L=10: {dt * 1e6:.1f} us/draw -> {10 / dt:.3e} leapfrog-steps/s x chains "
       f"(launch-latency bound)")
 
+th = torch.tensor([[1.1, -2.9, -0.4, 0.8, 4.3, 9.2, 4.44, -3.4, 7.2]], dtype=torch.float64, device=dev)
+t, g = pl.log_target_grad(th)
+K = 1000
+def f1run():
+    it[0] += K
+    pl.hmc_run(th, t, g, 0.1, 10, K, seed=1, it=it[0])
+dt = timed(f1run, 10) / K
+print(f"cfg1 as above, 1000 iterations per launch (ey_hmc_run): {dt * 1e6:.2f} us/draw -> {10 / dt:.3e} "
+      f"leapfrog-steps/s x chains")
+
 # cfg2
 for dtype in (torch.float32, torch.float64):
     data = synthetic.binary_xor_like(256, dtype=dtype, device=dev)
