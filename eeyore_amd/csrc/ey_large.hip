@@ -18,6 +18,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 16
+#ifndef BG_ABL
+#define BG_ABL 0  // timing-only ablations (tools/scratch): 1 = no LDS fragment reads, 2 = no global fetch / staging
+#endif
 #define LDT(R) ((R) + 4)  // [k][row] image of an R-row operand tile: 16-byte aligned rows, staggered over banks
 
 struct BG {
@@ -63,51 +66,89 @@ __device__ __forceinline__ void tile_coord(bool kfast, int e, int& row, int& kk)
   if (kfast) { row = e >> 4; kk = e & 15; } else { row = e & (RT - 1); kk = e / RT; }
 }
 
+// Per-thread fetch state of one operand: everything that does not change from one k-tile to the next (tile
+// coordinates, the 64-bit address of the first k-tile, whether the rows are inside the matrix) is worked out once; a
+// k-tile then costs one pointer offset and one bound check per group.  (f32 MFMA shares the vector ALUs with this
+// arithmetic: recomputing strides with 64-bit multiplies in every k-tile cost 22 % of the whole iteration.)
 template <int RT>
-__device__ __forceinline__ Frag fetch(const float* P, long sRow, long sK, bool kfast, int row0, int k0, int rows, int K,
-                                      int tid) {
-  Frag f;
-  // fast path: 4 consecutive elements along the contiguous stride, all in bounds
+struct Fetcher {
+  static constexpr int NG = (RT * BK + 1023) / 1024;
+  const float* base[NG];  // address of this thread's group in k-tile 0 (may be out of bounds: see ok/edge)
+  int kk[NG];             // k offset of the group inside a k-tile
+  int row[NG];            // global row of the group's first element
+  bool live[NG];          // the thread has this group (a 32-row tile occupies only half of the threads)
+  int lds[NG];            // where the group goes in the [k][row] LDS image
+  long sRow, sK, step;    // element strides; address step per k-tile
+  int rows, K;
+  bool kfast;
+  bool rows_inside;       // the whole tile lies inside the matrix (wave-uniform)
+
+  __device__ __forceinline__ void init(const float* P, long sRow_, long sK_, bool kfast_, int row0, int rows_, int K_,
+                                       int tid) {
+    sRow = sRow_; sK = sK_; kfast = kfast_; rows = rows_; K = K_;
+    step = (long)BK * sK;
+    rows_inside = row0 + RT <= rows_;
 #pragma unroll
-  for (int i = 0; i < (RT * BK + 1023) / 1024; ++i) {
-    const int e = (tid + 256 * i) * 4;
-    if (e >= RT * BK) break;
-    int row, kk;
-    tile_coord<RT>(kfast, e, row, kk);
-    const int gr = row0 + row, gk = k0 + kk;
-    const bool inside = kfast ? (gr < rows && gk + 3 < K) : (gr + 3 < rows && gk < K);
-    if (inside) {
-      const float* src = P + gr * sRow + gk * sK;  // the 4 elements are contiguous in memory
+    for (int i = 0; i < NG; ++i) {
+      const int e = (tid + 256 * i) * 4;
+      live[i] = e < RT * BK;
+      int r, k;
+      tile_coord<RT>(kfast, e, r, k);
+      row[i] = row0 + r;
+      kk[i] = k;
+      lds[i] = k * LDT(RT) + r;
+      base[i] = P + (long)row[i] * sRow + (long)k * sK;
+    }
+  }
+
+  // registers -> LDS image [k][row]: a k-fast group is 4 k's of one row (4 scalar stores LDT apart), a row-fast group 4
+  // rows of one k (one 16-byte store)
+  __device__ __forceinline__ void store(float* T, const Frag& f) const {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f.v[4 * i + j] = src[j];
-    } else {
+    for (int i = 0; i < NG; ++i) {
+      if (RT * BK < 1024 && !live[i]) break;
+      if (kfast) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r2 = kfast ? gr : gr + j, k2 = kfast ? gk + j : gk;
-        f.v[4 * i + j] = (r2 < rows && k2 < K) ? P[r2 * sRow + k2 * sK] : 0.0f;
+        for (int j = 0; j < 4; ++j) T[lds[i] + j * LDT(RT)] = f.v[4 * i + j];
+      } else {
+        *reinterpret_cast<float4*>(T + lds[i]) = make_float4(f.v[4 * i], f.v[4 * i + 1], f.v[4 * i + 2], f.v[4 * i + 3]);
       }
     }
   }
-  return f;
-}
 
-template <int RT>
-__device__ __forceinline__ void stage(float* T, const Frag& f, bool kfast, int tid) {
+  __device__ __forceinline__ Frag load(int kt) const {
+    Frag f;
+    const int k0 = kt * BK;
+    if (RT * BK >= 1024 && rows_inside && k0 + BK <= K) {
+      // interior k-tile of an interior block (a scalar branch): every thread loads its groups with no per-thread test
 #pragma unroll
-  for (int i = 0; i < (RT * BK + 1023) / 1024; ++i) {
-    const int e = (tid + 256 * i) * 4;
-    if (e >= RT * BK) break;
-    int row, kk;
-    tile_coord<RT>(kfast, e, row, kk);
-    if (kfast) {
+      for (int i = 0; i < NG; ++i) {
+        const float* src = base[i] + (long)kt * step;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) T[(kk + j) * LDT(RT) + row] = f.v[4 * i + j];
-    } else {
-      *reinterpret_cast<float4*>(T + kk * LDT(RT) + row) =
-          make_float4(f.v[4 * i], f.v[4 * i + 1], f.v[4 * i + 2], f.v[4 * i + 3]);
+        for (int j = 0; j < 4; ++j) f.v[4 * i + j] = src[j];
+      }
+      return f;
     }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      if (!live[i]) break;
+      const int gr = row[i], gk = k0 + kk[i];
+      const float* src = base[i] + (long)kt * step;
+      const bool inside = kfast ? (gr < rows && gk + 3 < K) : (gr + 3 < rows && gk < K);
+      if (inside) {  // 4 consecutive elements along the contiguous stride, all in bounds
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.v[4 * i + j] = src[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r2 = kfast ? gr : gr + j, k2 = kfast ? gk + j : gk;
+          f.v[4 * i + j] = (r2 < rows && k2 < K) ? src[kfast ? (long)j * sK : (long)j * sRow] : 0.0f;
+        }
+      }
+    }
+    return f;
   }
-}
+};
 
 // C[b] = epilogue(A[b] B[b]).  Block tile BMT x BNT x 16 with two LDS buffers; the 4 waves form a WGM x WGN grid and
 // each owns TM x TN MFMA tiles of 32x32 (v_mfma_f32_32x32x2_f32), so one operand register feeds TN (or TM) MFMAs.
@@ -135,17 +176,21 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
   const int ktiles = (g.K + BK - 1) / BK;
   const bool do_rowsum = g.rowsum != nullptr && blockIdx.x == 0 && tid < BMT;
   float rsum = 0.0f;
-  Frag fa = fetch<BMT>(A, g.sAm, g.sAk, a_kfast, m0, 0, g.M, g.K, tid);
-  Frag fb = fetch<BNT>(B, g.sBn, g.sBk, b_kfast, n0, 0, g.N, g.K, tid);
-  stage<BMT>(As[0], fa, a_kfast, tid);
-  stage<BNT>(Bs[0], fb, b_kfast, tid);
+  Fetcher<BMT> FA;
+  Fetcher<BNT> FB;
+  FA.init(A, g.sAm, g.sAk, a_kfast, m0, g.M, g.K, tid);
+  FB.init(B, g.sBn, g.sBk, b_kfast, n0, g.N, g.K, tid);
+  Frag fa = FA.load(0);
+  Frag fb = FB.load(0);
+  FA.store(As[0], fa);
+  FB.store(Bs[0], fb);
   __syncthreads();
   for (int kt = 0; kt < ktiles; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < ktiles;
-    if (more) {
-      fa = fetch<BMT>(A, g.sAm, g.sAk, a_kfast, m0, (kt + 1) * BK, g.M, g.K, tid);
-      fb = fetch<BNT>(B, g.sBn, g.sBk, b_kfast, n0, (kt + 1) * BK, g.N, g.K, tid);
+    if (more && !(BG_ABL & 2)) {
+      fa = FA.load(kt + 1);
+      fb = FB.load(kt + 1);
     }
     const float* Ac = As[cur] + wm * (32 * TM) + c;
     const float* Bc = Bs[cur] + wn * (32 * TN) + c;
@@ -153,9 +198,9 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
     for (int s = 0; s < BK / 2; ++s) {
       float av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = Ac[(2 * s + h) * LDT(BMT) + 32 * i];
+      for (int i = 0; i < TM; ++i) av[i] = (BG_ABL & 1) ? (float)(s + i) : Ac[(2 * s + h) * LDT(BMT) + 32 * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bc[(2 * s + h) * LDT(BNT) + 32 * j];
+      for (int j = 0; j < TN; ++j) bv[j] = (BG_ABL & 1) ? (float)(s - j) : Bc[(2 * s + h) * LDT(BNT) + 32 * j];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -165,9 +210,9 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) rsum += As[cur][k * LDT(BMT) + tid];
     }
-    if (more) {
-      stage<BMT>(As[cur ^ 1], fa, a_kfast, tid);
-      stage<BNT>(Bs[cur ^ 1], fb, b_kfast, tid);
+    if (more && !(BG_ABL & 2)) {
+      FA.store(As[cur ^ 1], fa);
+      FB.store(Bs[cur ^ 1], fb);
     }
     __syncthreads();
   }
