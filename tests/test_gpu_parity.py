@@ -1065,3 +1065,47 @@ def test_hmc_run_equals_consecutive_steps(kind):
             pl.hmc_run(*b, step, nl, 0, seed=1, it=1)
     finally:
         _force_large(False)
+
+
+def test_three_samplers_agree_on_the_posterior():
+    """End-to-end statistical check: HMC, MALA and random-walk MH on the same target (MLP(2-3-2-1), binary data,
+    N(0, sqrt 3) prior, 256 chains from over-dispersed starts) must give the same posterior means within 5 standard
+    errors of the chain ensemble, and a potential scale reduction close to 1."""
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.distributed import ChainStats
+    from eeyore_amd.plan import Plan
+    dt = torch.float64
+    data = synthetic.binary_xor_like(64, dtype=dt, device=DEV)
+    pl = Plan([2, 3, 2, 1], [1, 1, 1], [1, 1, 1], 0, dt, DEV)
+    pl.set_data(data.x, data.y)
+    pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), float(np.sqrt(3.0))))
+    C, burn, keep = 256, 400, 2000
+    scale = torch.full((pl.P,), 0.25, dtype=dt, device=DEV)
+    results = {}
+    for name in ("hmc", "mala", "mh"):
+        th = 2.0 * pl.philox_normal(C, seed=77, it=0)
+        t, g = pl.log_target_grad(th)
+        st = ChainStats(C, pl.P, DEV)
+        for it in range(burn + keep):
+            if it == burn:
+                st.attach(pl)
+            if name == "hmc":
+                pl.hmc_step(th, t, g, 0.25, 6, seed=78, it=1 + it)
+            elif name == "mala":
+                pl.mala_step(th, t, g, 0.08, seed=79, it=1 + it)
+            else:
+                pl.mh_step(th, t, scale, seed=80, it=1 + it)
+        pl.detach_moments()
+        s = st.summary()
+        chain_means = (st.s1 / st.n)                       # [C, P]
+        results[name] = (chain_means.mean(0).cpu().numpy(), (chain_means.std(0) / np.sqrt(C)).cpu().numpy(),
+                         float(s["rhat"].max().item()), s["acceptance"])
+    for name, (m, se, rhat, acc) in results.items():
+        assert 0.15 < acc < 0.98, (name, acc)
+        # 2000 kept iterations: HMC has mixed; MALA and random-walk MH mix more slowly (the z-test below decides)
+        assert rhat < {"hmc": 1.1, "mala": 1.3, "mh": 1.6}[name], (name, rhat)
+    for a, b in (("hmc", "mala"), ("hmc", "mh"), ("mala", "mh")):
+        ma, sa, _, _ = results[a]
+        mb, sb, _, _ = results[b]
+        z = np.abs(ma - mb) / np.sqrt(sa ** 2 + sb ** 2)
+        assert z.max() < 5.0, (a, b, z.max())
