@@ -405,10 +405,15 @@ __global__ void k_pt_swap(const T* ell_i, const T* ell_j, const T* t_i, const T*
 template <typename T>
 __global__ void k_philox_normal(T* out, int64_t C, int64_t P, uint64_t seed, uint64_t iter, uint64_t chain_offset) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < C * P; k += stride) {
-    const int64_t c = k / P, i = k - c * P;
+  const int64_t nb = (P + 3) / 4;  // blocks of four stream elements per chain
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < C * nb; k += stride) {
+    const int64_t c = k / nb, b = k - c * nb;
     const EyRng r = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
-    out[k] = ey_rng_normal<T>(r, (uint32_t)i);
+    T o[4];
+    ey_rng_normal4<T>(r, (uint32_t)b, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * b + j < P) out[c * P + 4 * b + j] = o[j];
   }
 }
 

@@ -162,31 +162,52 @@ __host__ __device__ inline EyRng ey_rng_make(uint64_t seed, uint64_t chain, uint
   return r;
 }
 
-// N(0,1) for element idx.  Box-Muller on two 24-bit (f32) / 32+21-bit (f64) uniforms.  Contraction is off so
-// the fused kernels and ey_philox_normal produce bit-identical values.
+// N(0,1) for the four elements 4b .. 4b+3 of a chain's stream ("block" b): element idx is component idx & 3 of block
+// idx >> 2, whoever computes it, so every kernel layout reproduces the same stream.  f32: ONE Philox call per block,
+// two Box-Muller pairs on 24-bit uniforms (o0,o1 -> elements 0,1 as r cos, r sin; o2,o3 -> elements 2,3).  f64: two
+// calls (counters 2b and 2b+1), one Box-Muller pair on 32+21-bit uniforms each.  The 32-bit integer multiplies of
+// Philox are quarter rate and the generator is a visible share of a draw (all of a MALA / MH draw's prologue), so
+// producers generate whole blocks.  Contraction is off so that the fused kernels and ey_philox_normal produce
+// bit-identical values.
 template <typename T>
-__device__ inline T ey_rng_normal(const EyRng& r, uint32_t idx);
+__device__ inline void ey_rng_normal4(const EyRng& r, uint32_t block, T out[4]);
 
 template <>
-__device__ inline float ey_rng_normal<float>(const EyRng& r, uint32_t idx) {
+__device__ inline void ey_rng_normal4<float>(const EyRng& r, uint32_t block, float out[4]) {
 #pragma clang fp contract(off)
   uint32_t o[4];
-  ey_philox4x32_10(idx, r.c1, r.c2, r.c3, r.k0, r.k1, o);
-  const float u1 = ((float)(o[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
-  const float u2 = (float)(o[1] >> 8) * 5.9604644775390625e-08f;           // [0,1)
-  const float rad = sqrtf(-2.0f * logf(u1));
-  return rad * cospif(2.0f * u2);
+  ey_philox4x32_10(block, r.c1, r.c2, r.c3, r.k0, r.k1, o);
+#pragma unroll
+  for (int pair = 0; pair < 2; ++pair) {
+    const float u1 = ((float)(o[2 * pair] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
+    const float u2 = (float)(o[2 * pair + 1] >> 8) * 5.9604644775390625e-08f;       // [0,1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    out[2 * pair] = rad * cospif(2.0f * u2);
+    out[2 * pair + 1] = rad * sinpif(2.0f * u2);
+  }
 }
 
 template <>
-__device__ inline double ey_rng_normal<double>(const EyRng& r, uint32_t idx) {
+__device__ inline void ey_rng_normal4<double>(const EyRng& r, uint32_t block, double out[4]) {
 #pragma clang fp contract(off)
-  uint32_t o[4];
-  ey_philox4x32_10(idx, r.c1, r.c2, r.c3, r.k0, r.k1, o);
-  const double u1 = ((double)(((uint64_t)o[0] << 21) | (o[2] >> 11)) + 0.5) * 1.1102230246251565e-16;  // 2^-53
-  const double u2 = (double)(((uint64_t)o[1] << 21) | (o[3] >> 11)) * 1.1102230246251565e-16;
-  const double rad = sqrt(-2.0 * log(u1));
-  return rad * cospi(2.0 * u2);
+#pragma unroll
+  for (int pair = 0; pair < 2; ++pair) {
+    uint32_t o[4];
+    ey_philox4x32_10(2u * block + (uint32_t)pair, r.c1, r.c2, r.c3, r.k0, r.k1, o);
+    const double u1 = ((double)(((uint64_t)o[0] << 21) | (o[2] >> 11)) + 0.5) * 1.1102230246251565e-16;  // 2^-53
+    const double u2 = (double)(((uint64_t)o[1] << 21) | (o[3] >> 11)) * 1.1102230246251565e-16;
+    const double rad = sqrt(-2.0 * log(u1));
+    out[2 * pair] = rad * cospi(2.0 * u2);
+    out[2 * pair + 1] = rad * sinpi(2.0 * u2);
+  }
+}
+
+// one element (for consumers that are handed single indices): the same arithmetic, the other components discarded
+template <typename T>
+__device__ inline T ey_rng_normal(const EyRng& r, uint32_t idx) {
+  T o[4];
+  ey_rng_normal4<T>(r, idx >> 2, o);
+  return o[idx & 3u];
 }
 
 template <typename T>

@@ -94,6 +94,19 @@ static size_t lds_bytes(const EyModel& m, int nvec, size_t esz) {
 
 // log-target (and gradient when GRAD) of the position in `th`; result broadcast to every lane.
 // gr receives the gradient of the (tempered) log-target.  lik/prior are the tempered parts.
+// the chain's N(0,1) stream for elements 0..P-1 into an LDS array, one block of four per lane and round
+template <typename T>
+__device__ inline void fill_normals(T* dst, const EyRng& rn, int P) {
+  for (int b = threadIdx.x; 4 * b < P; b += WAVE) {
+    T o[4];
+    ey_rng_normal4<T>(rn, (uint32_t)b, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * b + j < P) dst[4 * b + j] = o[j];
+  }
+  __syncthreads();
+}
+
 template <typename T, bool GRAD>
 __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, bool has_temp, T temp, T* lik_out,
                          T* prior_out, T* row_out = nullptr) {
@@ -267,10 +280,11 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
   // momentum ~ N(0, I)  (hmc.py:134)
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   T kin = T(0);
+  if (!p0) fill_normals<T>(p, rn, P);
   for (int i = lane; i < P; i += WAVE) {
     l.th[i] = theta[c * P + i];
     l.gr[i] = grad[c * P + i];
-    const T pi = p0 ? p0[c * P + i] : ey_rng_normal<T>(rn, (uint32_t)i);
+    const T pi = p0 ? p0[c * P + i] : p[i];
     p[i] = pi;
     kin += pi * pi;
   }
@@ -375,11 +389,12 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
   T* gp = l.b;
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   T qf = T(0);
+  if (!z_in) fill_normals<T>(prop, rn, P);
   for (int i = lane; i < P; i += WAVE) {
     const T th = theta[c * P + i], g = grad[c * P + i];
     l.th[i] = th;
     l.gr[i] = g;
-    const T zi = z_in ? z_in[c * P + i] : ey_rng_normal<T>(rn, (uint32_t)i);
+    const T zi = z_in ? z_in[c * P + i] : prop[i];
     const T loc = th + T(0.5) * eps * g;  // kernel_mean (mala.py:35-36)
     const T pr = loc + sc * zi;           // Normal(loc, scale).sample()
     prop[i] = pr;
@@ -426,8 +441,9 @@ __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, con
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
+  if (!z_in) fill_normals<T>(l.th, rn, P);
   for (int i = lane; i < P; i += WAVE) {
-    const T zi = z_in ? z_in[c * P + i] : ey_rng_normal<T>(rn, (uint32_t)i);
+    const T zi = z_in ? z_in[c * P + i] : l.th[i];
     l.th[i] = theta[c * P + i] + scale[i] * zi;  // NormalKernel(theta, scale).sample()
   }
   __syncthreads();

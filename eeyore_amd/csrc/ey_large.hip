@@ -339,13 +339,21 @@ __global__ void __launch_bounds__(256) k_hmc_begin(const float* theta, const flo
   const long c = blockIdx.x;
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   float kin = 0.0f;
-  for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    const long k = c * P + i;
-    const float pv = p0 ? p0[k] : ey_rng_normal<float>(rn, (uint32_t)i);  // hmc.py:134
-    p[k] = pv;
-    kin += pv * pv;
-    thp[k] = theta[k];
-    gp[k] = grad[k];
+  // momentum (hmc.py:134): one block of four stream elements per thread and round (one Philox call each)
+  for (int b = threadIdx.x; 4 * b < P; b += blockDim.x) {
+    float o[4];
+    if (!p0) ey_rng_normal4<float>(rn, (uint32_t)b, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * b + j;
+      if (i >= P) break;
+      const long k = c * P + i;
+      const float pv = p0 ? p0[k] : o[j];
+      p[k] = pv;
+      kin += pv * pv;
+      thp[k] = theta[k];
+      gp[k] = grad[k];
+    }
   }
   kin = block_sum(kin, red);
   if (threadIdx.x == 0) hcur[c] = -target[c] + 0.5f * kin;  // hmc.py:91-98,137

@@ -312,7 +312,9 @@ __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
 // staged as images; b2 is taken into scalar registers) wait in this wave's LDS region while the tile loop runs.  The
 // loop needs every vector register it can get, and what does not fit is spilled to scratch memory, whose reload
 // latency the end of every evaluation then waits for (four serial round trips per leapfrog step before this).
-template <int PARK, bool UPRIOR>
+// GRAD = false: the value only (random-walk MH needs no gradient, metropolis_hastings.py:41-73): the forward products
+// and the row log-sum-exp, about a third of the work.
+template <int PARK, bool UPRIOR, bool GRAD = true>
 __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, bool has_temp, float temp, int c,
                       int h, int lane, bool need_value, Pace& pc) {
   const int jj = lane & 3;
@@ -358,7 +360,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw[O_W0IMG + c * 5 + 2 * s + h], xt[c * 5 + 2 * s + h], acc, 0, 0, 0);
     const int lab = __float_as_int(xt[c * 5 + 4]);
     const f32x16 H0 = sigmoid_tile(acc);
-    store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
+    if (GRAD) store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
     PH(0);
     // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
 #pragma unroll
@@ -375,7 +377,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     }
     pace_apply(pc, pace_theirs);  // while the F1 products run
     const f32x16 H1 = sigmoid_tile(acc);
-    store_T(lw + O_TB0, H1, c, h);  // transposed copy for dW2; the logits and the softmax run while it lands
+    if (GRAD) store_T(lw + O_TB0, H1, c, h);  // transposed copy for dW2; the logits and the softmax run while it lands
     PH(1);
     // ---- F2: logits = W2 H1^T + b2 with the 16-block 4x4x1 product; each half sums its 16 features
     f32x4 lg0 = {0, 0, 0, 0}, lg1 = {0, 0, 0, 0};
@@ -398,6 +400,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     const float ssum = e0 + e1 + e2;
     const float llab = lab == 0 ? l0 : (lab == 1 ? l1 : l2);
     if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
+    if (!GRAD) continue;  // nothing was written to LDS in this tile
     const float rs = __builtin_amdgcn_rcpf(ssum);
     float d2[3];
     d2[0] = valid ? ((lab == 0 ? 1.0f : 0.0f) - e0 * rs) : 0.0f;
@@ -495,19 +498,21 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     for (int o = 0; o < 3; ++o) th.b2[o] = lw[at + (9 + o) * 64];
   }
   // ---- combine the two row-parity halves and the lanes
+  if (GRAD) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) g.w1[r] = dW1[r];
+    for (int r = 0; r < 16; ++r) g.w1[r] = dW1[r];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    g.w0[i] = hsum(dW0a[i] + dW0b[i]);
+    for (int i = 0; i < 4; ++i) {
+      g.w0[i] = hsum(dW0a[i] + dW0b[i]);
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      g.w2[o] = hsum(dW2a[o] + dW2b[o]);
+      g.b2[o] = wsum(db2[o]);
+    }
+    g.b1 = hsum(db1);
+    g.b0 = hsum(db0);
   }
-#pragma unroll
-  for (int o = 0; o < 3; ++o) {
-    g.w2[o] = hsum(dW2a[o] + dW2b[o]);
-    g.b2[o] = wsum(db2[o]);
-  }
-  g.b1 = hsum(db1);
-  g.b0 = hsum(db0);
   // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
   float qsum = 0.0f;
   if (UPRIOR || A.prior_uniform) {  // UPRIOR: the kernel variant launched only for such priors has no other path
@@ -515,18 +520,22 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int, bool counts) {
       const float d = tv - mu0;
       if (counts) qsum += d * d * iv0;
-      float gn = gv - d * iv0;
-      if (has_temp) gn *= temp;
-      gv = gn;
+      if (GRAD) {
+        float gn = gv - d * iv0;
+        if (has_temp) gn *= temp;
+        gv = gn;
+      }
     });
   } else {
     for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int idx, bool counts) {
       const float d = tv - A.mu[idx];
       const float iv = A.inv_var[idx];
       if (counts) qsum += d * d * iv;
-      float gn = gv - d * iv;
-      if (has_temp) gn *= temp;
-      gv = gn;
+      if (GRAD) {
+        float gn = gv - d * iv;
+        if (has_temp) gn *= temp;
+        gv = gn;
+      }
     });
   }
   float prior = 0.0f;
@@ -537,7 +546,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
   if (has_temp) { lik *= temp; prior *= temp; }
 #if EY_PHASE_TIMING
   if (ph_on) {
-    const float keep = lik + prior + g.w1[0] + g.b1;  // the epilogue's results must exist before the clock is read
+    const float keep = lik + prior + (GRAD ? g.w1[0] + g.b1 : 0.0f);  // the epilogue's results must exist before the clock is read
     if (keep == 1.2345e-30f) g.b0 += 1.0f;
   }
   PH(10);
@@ -586,6 +595,22 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
   if (lane == 0) A.mom_acc[chain] += accepted ? 1.0 : 0.0;
 }
 
+// The chain's N(0,1) stream for all NPAR elements, generated by the wave together: lane l computes the blocks of four
+// l, l + 64, ... (ey_rng_normal4: one Philox call per block) into the two transpose buffers of this wave's LDS region
+// (free between evaluations), from where every lane then picks the 29 elements of its register layout.  One call
+// per element in every lane, as a lane-local draw needs, costs 29 Philox calls per lane instead of at most 6.
+__device__ __forceinline__ const float* stage_normals(float* lw, const EyRng& rn, int lane) {
+  float* st = lw + O_TB0;  // O_TB0 and O_TB1 are adjacent: 2304 floats >= NPAR + 3
+  constexpr int NB = (NPAR + 3) / 4;
+  for (int b = lane; b < NB; b += 64) {
+    float o[4];
+    ey_rng_normal4<float>(rn, (uint32_t)b, o);
+    *reinterpret_cast<f32x4*>(st + 4 * b) = f32x4{o[0], o[1], o[2], o[3]};
+  }
+  wave_lds_fence();
+  return st;
+}
+
 // One chain of one launch: everything between reading theta and writing the accepted state back.
 template <int MODE, int PARK, bool UPRIOR>
 __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int it,
@@ -627,8 +652,9 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     float qf = 0.0f;
     Vec gp;
     if (MODE == MODE_MALA) for_each(g, c, h, lane, [&](float& v, int idx, bool) { v = grg[idx]; });
+    const float* zst = zin ? nullptr : stage_normals(lw, rn, lane);
     for_each3(th, g, p, c, h, lane, [&](float& tv, float& gv, float& pv, int idx, bool counts) {
-      const float zi = zin ? zin[idx] : ey_rng_normal<float>(rn, (uint32_t)idx);
+      const float zi = zin ? zin[idx] : zst[idx];
       if (MODE == MODE_MALA) {
         const float loc = tv + 0.5f * eps * gv;  // kernel_mean, mala.py:35-36
         pv = loc + sc * zi;
@@ -638,8 +664,9 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
         pv = tv + A.scale[idx] * zi;  // NormalKernel(theta, scale).sample()
       }
     });
+    wave_lds_fence();  // the staged normals have been read; the evaluation reuses that LDS
     write_images(lw, p, c, h);
-    const float tv = eval<PARK, UPRIOR>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
+    const float tv = eval<PARK, UPRIOR, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
     float log_rate = tv - A.target[chain];  // symmetric kernel: metropolis_hastings.py:50
     if (MODE == MODE_MALA) {
       float qb = 0.0f;
@@ -671,10 +698,12 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   if (MODE == MODE_HMC) {
     const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_NORMAL);
     const float* p0 = A.p0 ? A.p0 + chain * NPAR : nullptr;
+    const float* pst = p0 ? nullptr : stage_normals(lw, rn, lane);
     for_each(p, c, h, lane, [&](float& v, int idx, bool counts) {
-      v = p0 ? p0[idx] : ey_rng_normal<float>(rn, (uint32_t)idx);   // hmc.py:134
+      v = p0 ? p0[idx] : pst[idx];   // hmc.py:134
       if (counts) kin += v * v;
     });
+    wave_lds_fence();  // the staged normals have been read; the evaluations reuse that LDS
     kin = wsum(kin);
     t_cur = A.target[chain];
     if (!A.recompute) for_each(g, c, h, lane, [&](float& v, int idx, bool) { v = grg[idx]; });
