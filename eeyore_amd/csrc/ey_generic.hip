@@ -185,6 +185,8 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
           const T* dj = dcur + j * TS;
           const T* hi = hin_t + i * TS;
           T acc = T(0);
+          // few lanes are active when a layer is small: keep several LDS reads in flight per lane
+#pragma unroll 8
           for (int r = 0; r < rows; ++r) acc += dj[r] * hi[r];
           gr[m.woff[k] + idx] += acc;
         }
@@ -192,6 +194,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
           for (int j = lane; j < dout; j += WAVE) {
             const T* dj = dcur + j * TS;
             T acc = T(0);
+#pragma unroll 8
             for (int r = 0; r < rows; ++r) acc += dj[r];
             gr[m.boff[k] + j] += acc;
           }
