@@ -1,9 +1,10 @@
 // Fused HMC trajectory kernel on the f32 matrix cores for MLP(4-32-32-3)-shaped models (BASELINE configs 3/4).
 //
-// One wavefront per chain, four chains per workgroup.  The whole draw -- momentum, L leapfrog steps with the MLP
-// forward + hand-coded backward over all data rows, Hamiltonians, accept -- runs in one launch; theta, momentum and
-// the gradient never leave registers, weights are re-staged through LDS once per leapfrog step, activations once
-// per 32-row tile.  HBM is touched at trajectory start and end only.
+// One wavefront per chain; a persistent 8-wave workgroup per CU whose waves walk over chains (and, for ey_hmc_run,
+// over iterations).  The whole draw -- momentum, L leapfrog steps with the MLP forward + hand-coded backward over all
+// data rows, Hamiltonians, accept -- runs inside the launch; theta, momentum and the gradient never leave registers,
+// weights are re-staged through LDS once per leapfrog step, activations once per 32-row tile.  HBM is touched at
+// trajectory start and end only.
 //
 // Reference semantics restated (paths relative to papamarkou/eeyore): MLP.forward eeyore/models/mlp.py:45-50,
 // CE-sum eeyore/constants/constants.py:17, log_target eeyore/models/bayesian_model.py:30-56, gradient

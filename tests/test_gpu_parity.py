@@ -440,7 +440,7 @@ def test_mfma32_serves_config3_and_matches_generic_kernel():
     from eeyore_amd import _lib as L
     rec, pl = _cfg3_plan()
     assert pl.kernel == "mfma32"
-    C = 37  # not a multiple of the 4 chains per workgroup
+    C = 37  # fewer chains than CUs, not a multiple of the waves per workgroup
     th = 0.2 * pl.philox_normal(C, seed=3, it=0)
     t, g = pl.log_target_grad(th)
     p0, u = pl.philox_normal(C, seed=3, it=1), pl.philox_uniform(C, seed=3, it=1)
