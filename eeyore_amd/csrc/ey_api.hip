@@ -237,9 +237,8 @@ int ey_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C,
   if (rc) return rc < 0 ? rc : EY_OK;
   if (!theta || !rows) EY_FAIL(EY_ERR_INVALID, "ey_log_lik_rows: null argument");
   if (C == 0) return EY_OK;
-  if (use_large(pl))
-    EY_FAIL(EY_ERR_UNSUPPORTED, "ey_log_lik_rows: not built for models whose parameters do not fit LDS");
   EY_HIP(hipSetDevice(pl->device));
+  if (use_large(pl)) return ey_large_log_lik_rows(pl, theta, temp, C, rows, (hipStream_t)stream);
   return ey_generic_log_lik_rows(pl, theta, temp, C, rows, (hipStream_t)stream);
 }
 
@@ -348,6 +347,7 @@ int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* 
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
   if (pl->mfma32_ok) return ey_mfma32_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
+  if (use_large(pl)) return ey_large_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
   return ey_generic_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
 }
 
@@ -364,8 +364,12 @@ int ey_mala_step(ey_plan* pl, void* theta, void* target, void* grad, const void*
   if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
                           log_rate, (hipStream_t)stream);
-  rc = ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
-                       log_rate, (hipStream_t)stream);
+  if (use_large(pl))
+    rc = ey_large_mala_mh(pl, theta, target, grad, z, u, step, step_vec, nullptr, temp, C, seed, iter, chain_offset,
+                          accepted, log_rate, (hipStream_t)stream);
+  else
+    rc = ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
+                         log_rate, (hipStream_t)stream);
   return moments_trailing(pl, rc, theta, accepted, C, stream);
 }
 
@@ -381,8 +385,12 @@ int ey_mh_step(ey_plan* pl, void* theta, void* target, const void* z, const void
   if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
                         (hipStream_t)stream);
-  rc = ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
-                     (hipStream_t)stream);
+  if (use_large(pl))
+    rc = ey_large_mala_mh(pl, theta, target, nullptr, z, u, 0.0, nullptr, scale, temp, C, seed, iter, chain_offset,
+                          accepted, log_rate, (hipStream_t)stream);
+  else
+    rc = ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
+                       (hipStream_t)stream);
   return moments_trailing(pl, rc, theta, accepted, C, stream);
 }
 

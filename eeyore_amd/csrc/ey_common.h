@@ -104,6 +104,12 @@ int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void*
                  const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                  uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
                  hipStream_t s);
+int ey_large_mala_mh(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                     const void* step_vec, const void* scale, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                     uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s);
+int ey_large_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                      int64_t C, void* target, void* grad, hipStream_t s);
+int ey_large_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, hipStream_t s);
 void ey_large_free(ey_plan* pl);
 
 // mfma32 kernels (ey_mfma32.hip)

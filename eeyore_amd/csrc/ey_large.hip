@@ -278,17 +278,19 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // log-likelihood of every chain and the output delta = dL/dh_K * act'(h_K); one block per chain
 __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ out, float* __restrict__ delta,
                                               const float* __restrict__ y, const int* __restrict__ labels, int N, int dK,
-                                              int lik_code, int act_last, float* __restrict__ lik_o) {
+                                              int lik_code, int act_last, float* __restrict__ lik_o,
+                                              float* __restrict__ rows_o, const float* __restrict__ temp) {
   __shared__ float red[4];
   const long c = blockIdx.x;
   const float* o = out + c * (long)N * dK;
   float* d = delta + c * (long)N * dK;
   float lik = 0.0f;
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    float row = 0.0f;  // this row's term of the sum (ey_log_lik_rows)
     if (lik_code == EY_LIK_BCE_SUM) {
       for (int j = 0; j < dK; ++j) {
         const float p = o[n * dK + j], yy = y[n * dK + j];
-        lik += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
+        row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
         d[n * dK + j] = (yy / p - (1.0f - yy) / (1.0f - p)) * l_dact(act_last, p);
       }
     } else {
@@ -297,13 +299,15 @@ __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ out, flo
       for (int j = 1; j < dK; ++j) mx = fmaxf(mx, o[n * dK + j]);
       float ssum = 0.0f;
       for (int j = 0; j < dK; ++j) ssum += __expf(o[n * dK + j] - mx);
-      lik += o[n * dK + lab] - (mx + __logf(ssum));
+      row = o[n * dK + lab] - (mx + __logf(ssum));
       const float rs = 1.0f / ssum;
       for (int j = 0; j < dK; ++j) {
         const float v = o[n * dK + j];
         d[n * dK + j] = ((j == lab ? 1.0f : 0.0f) - __expf(v - mx) * rs) * l_dact(act_last, v);
       }
     }
+    lik += row;
+    if (rows_o) rows_o[c * (long)N + n] = temp ? row * temp[c] : row;
   }
   lik = block_sum(lik, red);
   if (threadIdx.x == 0) lik_o[c] = lik;
@@ -473,7 +477,7 @@ static size_t act_floats_per_chain(const EyModel& m) {
 // value (+ gradient when grad != null) for chains [0, C) of theta, using `ws` (2 * C * act_floats floats) as scratch
 static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C, float* lik_o, float* prior_o,
                       float* target_o, float* grad, float* ws, float* lik_tmp, hipStream_t s,
-                      const float* qpart = nullptr) {
+                      const float* qpart = nullptr, float* rows_o = nullptr) {
   const EyModel& m = pl->m;
   const int K = m.nl, N = m.N, P = m.P;
   const size_t af = act_floats_per_chain(m);
@@ -503,7 +507,7 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     if ((rc = bgemm(g, C, s))) return rc;
   }
   hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
-                     m.dims[K], m.lik, m.act[K - 1], lik_tmp);
+                     m.dims[K], m.lik, m.act[K - 1], lik_tmp, rows_o, rows_o ? temp : nullptr);
   const int ltop = K - 1;
   if (grad) {
     for (int l = ltop; l >= 0; --l) {
@@ -623,5 +627,179 @@ int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void*
                        hprop ? (float*)hprop + c0 : nullptr);
   }
   EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- MALA / MH / leapfrog
+// proposal of every chain: MALA  prop = theta + eps/2 grad + sqrt(eps) z   (mala.py:35-41,53)
+//                          MH    prop = theta + scale z                    (metropolis_hastings.py:45, normal_kernel.py)
+__global__ void __launch_bounds__(256) k_propose(const float* __restrict__ theta, const float* __restrict__ grad,
+                                                 const float* __restrict__ z_in, const float* __restrict__ scale,
+                                                 float* __restrict__ prop, int P, float step,
+                                                 const float* __restrict__ step_vec, float sqrt_step, uint64_t seed,
+                                                 uint64_t iter, uint64_t chain_offset) {
+  const long c = blockIdx.x;
+  const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
+  const float eps = step_vec ? step_vec[c] : step;
+  const float sc = step_vec ? sqrtf(eps) : sqrt_step;
+  for (int b = threadIdx.x; 4 * b < P; b += blockDim.x) {
+    float o[4];
+    if (!z_in) ey_rng_normal4<float>(rn, (uint32_t)b, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * b + j;
+      if (i >= P) break;
+      const long k = c * P + i;
+      const float zi = z_in ? z_in[k] : o[j];
+      prop[k] = grad ? (theta[k] + 0.5f * eps * grad[k]) + sc * zi : theta[k] + scale[i] * zi;
+    }
+  }
+}
+
+// log-rate, accept and state update of every chain (mala.py:55-82; metropolis_hastings.py:47-73)
+__global__ void __launch_bounds__(256) k_mh_finish(float* theta, float* grad, float* target, const float* prop,
+                                                   const float* gprop, const float* tprop, const float* u_in, int P,
+                                                   float step, const float* step_vec, float sqrt_step, uint64_t seed,
+                                                   uint64_t iter, uint64_t chain_offset, unsigned char* accepted,
+                                                   float* log_rate_o) {
+  __shared__ float red[4];
+  __shared__ int s_acc;
+  const long c = blockIdx.x;
+  float qf = 0.0f, qb = 0.0f;
+  const float eps = step_vec ? step_vec[c] : step;
+  if (gprop) {  // MALA: forward and backward proposal densities (their normalising terms cancel, mala.py:58-64)
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+      const long k = c * P + i;
+      const float df = prop[k] - (theta[k] + 0.5f * eps * grad[k]);
+      const float db = theta[k] - (prop[k] + 0.5f * eps * gprop[k]);
+      qf += df * df;
+      qb += db * db;
+    }
+    qf = block_sum(qf, red);
+    qb = block_sum(qb, red);
+  }
+  if (threadIdx.x == 0) {
+    float log_rate = tprop[c] - target[c];
+    if (gprop) {
+      const float sc = step_vec ? sqrtf(eps) : sqrt_step;
+      log_rate += (qf - qb) * (1.0f / (2.0f * sc * sc));
+    }
+    const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
+    const float u = u_in ? u_in[c] : ey_rng_uniform<float>(ru);
+    const int acc = __logf(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
+    s_acc = acc;
+    accepted[c] = (unsigned char)acc;
+    if (acc) target[c] = tprop[c];
+    if (log_rate_o) log_rate_o[c] = log_rate;
+  }
+  __syncthreads();
+  if (s_acc) {
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+      theta[c * P + i] = prop[c * P + i];
+      if (gprop) grad[c * P + i] = gprop[c * P + i];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_negate(float* p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = -p[i];
+}
+
+// One MALA.draw (grad != null) or MetropolisHastings.draw (scale != null) for C chains
+int ey_large_mala_mh(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                     const void* step_vec, const void* scale, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                     uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
+  const EyModel& m = pl->m;
+  const int P = m.P;
+  const bool mala = grad != nullptr;
+  const int cc = chunk_size(pl, C);
+  const size_t af = act_floats_per_chain(m);
+  const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 2 * (size_t)cc * P + (size_t)cc;
+  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  if (rc) return rc;
+  float* ws = (float*)pl->d_work;
+  float* lik_tmp = ws + 2 * (size_t)cc * af;
+  float* prop = lik_tmp + cc;
+  float* gprop = prop + (size_t)cc * P;
+  float* tprop = gprop + (size_t)cc * P;
+  const float sqrt_step = (float)sqrt(step);  // scale = sqrt(step) in double on the host (mala.py:39)
+  for (int64_t c0 = 0; c0 < C; c0 += cc) {
+    const int n = (int)((C - c0) < cc ? (C - c0) : cc);
+    float* th_c = (float*)theta + c0 * P;
+    float* g_c = mala ? (float*)grad + c0 * P : nullptr;
+    const float* temp_c = temp ? (const float*)temp + c0 : nullptr;
+    const float* sv_c = step_vec ? (const float*)step_vec + c0 : nullptr;
+    hipLaunchKernelGGL(k_propose, dim3(n), dim3(256), 0, s, (const float*)th_c, (const float*)g_c,
+                       z ? (const float*)z + c0 * P : nullptr, (const float*)scale, prop, P, (float)step, sv_c,
+                       sqrt_step, seed, iter, chain_offset + (uint64_t)c0);
+    if ((rc = eval_chunk(pl, prop, temp_c, n, nullptr, nullptr, tprop, mala ? gprop : nullptr, ws, lik_tmp, s)))
+      return rc;
+    hipLaunchKernelGGL(k_mh_finish, dim3(n), dim3(256), 0, s, th_c, g_c, (float*)target + c0, (const float*)prop,
+                       mala ? (const float*)gprop : nullptr, (const float*)tprop,
+                       u ? (const float*)u + c0 : nullptr, P, (float)step, sv_c, sqrt_step, seed, iter,
+                       chain_offset + (uint64_t)c0, (unsigned char*)accepted + c0,
+                       log_rate ? (float*)log_rate + c0 : nullptr);
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+// HMC.leapfrog (hmc.py:100-124) as the reference runs it: L steps, L+1 gradient evaluations, momentum negated at the end
+int ey_large_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                      int64_t C, void* target, void* grad, hipStream_t s) {
+  const EyModel& m = pl->m;
+  const int P = m.P;
+  const int cc = chunk_size(pl, C);
+  const size_t af = act_floats_per_chain(m);
+  const int nblk = (P + 255) / 256;
+  const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + (size_t)cc * nblk;
+  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  if (rc) return rc;
+  float* ws = (float*)pl->d_work;
+  float* lik_tmp = ws + 2 * (size_t)cc * af;
+  float* qpart = lik_tmp + cc;
+  const float* mu = (const float*)m.mu;
+  const float* iv = (const float*)m.inv_var;
+  for (int64_t c0 = 0; c0 < C; c0 += cc) {
+    const int n = (int)((C - c0) < cc ? (C - c0) : cc);
+    float* th_c = (float*)theta + c0 * P;
+    float* p_c = (float*)p + c0 * P;
+    float* g_c = (float*)grad + c0 * P;
+    float* t_c = (float*)target + c0;
+    const float* temp_c = temp ? (const float*)temp + c0 : nullptr;
+    const float* sv_c = step_vec ? (const float*)step_vec + c0 : nullptr;
+    const dim3 grid(nblk, n);
+    if ((rc = eval_chunk(pl, th_c, temp_c, n, nullptr, nullptr, t_c, g_c, ws, lik_tmp, s))) return rc;  // :104
+    hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, th_c, p_c, (const float*)g_c, P, (float)step, sv_c, 0.5f, 1.0f,
+                       mu, iv, qpart);
+    for (int k = 1; k <= L; ++k) {
+      if ((rc = eval_chunk(pl, th_c, temp_c, n, nullptr, nullptr, t_c, g_c, ws, lik_tmp, s, qpart))) return rc;
+      hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, th_c, p_c, (const float*)g_c, P, (float)step, sv_c,
+                         k < L ? 1.0f : 0.5f, k < L ? 1.0f : 0.0f, mu, iv, qpart);
+    }
+    const long tot = (long)n * P;
+    hipLaunchKernelGGL(k_negate, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p_c, tot);  // :122
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+// the N terms of the log-likelihood sum of every chain (ey_log_lik_rows): forward products and the loss kernel only
+int ey_large_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, hipStream_t s) {
+  const EyModel& m = pl->m;
+  const int cc = chunk_size(pl, C);
+  const size_t af = act_floats_per_chain(m);
+  const size_t ws_floats = 2 * (size_t)cc * af + 2 * (size_t)cc;
+  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  if (rc) return rc;
+  float* ws = (float*)pl->d_work;
+  float* lik_tmp = ws + 2 * (size_t)cc * af;
+  for (int64_t c0 = 0; c0 < C; c0 += cc) {
+    const int n = (int)((C - c0) < cc ? (C - c0) : cc);
+    rc = eval_chunk(pl, (const float*)theta + c0 * m.P, temp ? (const float*)temp + c0 : nullptr, n, nullptr, nullptr,
+                    lik_tmp + cc, nullptr, ws, lik_tmp, s, nullptr, (float*)rows + c0 * m.N);
+    if (rc) return rc;
+  }
   return EY_OK;
 }

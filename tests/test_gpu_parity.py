@@ -877,6 +877,80 @@ def test_bgemm_path_on_small_models_vs_oracle(dims, acts, bias, lik, N):
         _force_large(False)
 
 
+@pytest.mark.parametrize("dims,acts,bias,lik,N", [
+    ([4, 3, 3], [1, 0], [1, 1], 1, 150),
+    ([6, 70, 33, 2], [1, 2, 1], [1, 1, 1], 0, 130),
+])
+def test_bgemm_path_mala_mh_leapfrog_rows_vs_oracle(dims, acts, bias, lik, N):
+    """The other entry points of the layerwise path (ey_mala_step, ey_mh_step, ey_hmc_leapfrog, ey_log_lik_rows for
+    models beyond LDS), forced onto models the oracle handles in seconds."""
+    from eeyore_amd.plan import Plan
+    from oracle import mlp_oracle as mo
+    rng = np.random.default_rng(sum(dims) + N + 1)
+    x = rng.standard_normal((N, dims[0]))
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(float)
+    P = sum((dims[l] + bias[l]) * dims[l + 1] for l in range(len(dims) - 1))
+    mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+    co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=np.float32, bias=bias, nthreads=4)
+    f32 = torch.float32
+    _force_large(True)
+    try:
+        pl = Plan(dims, bias, acts, lik, f32, DEV)
+        pl.set_data(_t(x, f32), _t(y, f32))
+        pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+        assert pl.kernel == "bgemm"
+        C = 9
+        th0 = (0.3 * rng.standard_normal((C, P))).astype(np.float32)
+        t, g = pl.log_target_grad(_t(th0, f32))
+        # ---- MALA
+        z = rng.standard_normal((C, P)).astype(np.float32); u = rng.random(C).astype(np.float32)
+        th, tv, gg = _t(th0, f32).clone(), t.clone(), g.clone()
+        out = pl.mala_step(th, tv, gg, 0.002, z=_t(z, f32), u=_t(u, f32))
+        tho, tvo, go = th0.copy(), t.cpu().numpy().copy(), g.cpu().numpy().copy()
+        acc, lr = co.mala_draw(tho, tvo, go, z, u, 0.002)
+        np.testing.assert_allclose(out["log_rate"].cpu().numpy(), lr, rtol=5e-3, atol=5e-2)
+        decided = np.abs(np.log(u) - lr) > 0.1
+        np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+        same = out["accepted"].cpu().numpy() == acc
+        np.testing.assert_allclose(th.cpu().numpy()[same], tho[same], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(gg.cpu().numpy()[same], go[same], rtol=5e-3, atol=5e-3 * max(1.0, np.abs(go).max()))
+        # ---- random-walk MH
+        th, tv = _t(th0, f32).clone(), t.clone()
+        out = pl.mh_step(th, tv, 0.02, z=_t(z, f32), u=_t(u, f32))
+        tho, tvo = th0.copy(), t.cpu().numpy().copy()
+        acc, lr = co.mh_draw(tho, tvo, z, u, 0.02)
+        np.testing.assert_allclose(out["log_rate"].cpu().numpy(), lr, rtol=5e-3, atol=2e-2)
+        decided = np.abs(np.log(u) - lr) > 0.05
+        np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+        same = out["accepted"].cpu().numpy() == acc
+        np.testing.assert_allclose(th.cpu().numpy()[same], tho[same], rtol=2e-3, atol=2e-4)
+        # in-kernel Philox == streams passed in
+        a = [_t(th0, f32).clone(), t.clone(), g.clone()]
+        b = [_t(th0, f32).clone(), t.clone(), g.clone()]
+        oa = pl.mala_step(*a, 0.002, seed=6, it=3, chain_offset=4)
+        ob = pl.mala_step(*b, 0.002, z=pl.philox_normal(C, 6, 3, 4), u=pl.philox_uniform(C, 6, 3, 4))
+        assert torch.equal(oa["accepted"], ob["accepted"]) and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+        # ---- HMC.leapfrog: L steps, L + 1 evaluations, momentum negated
+        p0 = rng.standard_normal((C, P)).astype(np.float32)
+        th, p = _t(th0, f32).clone(), _t(p0, f32).clone()
+        tl, gl = pl.leapfrog(th, p, 0.01, 5)
+        for c in (0, C - 1):
+            tho, po, to, go = co.leapfrog(th0[c], p0[c], 0.01, 5)
+            np.testing.assert_allclose(th[c].cpu().numpy(), tho, rtol=2e-3, atol=2e-4)
+            np.testing.assert_allclose(p[c].cpu().numpy(), po, rtol=5e-3, atol=5e-3)
+            np.testing.assert_allclose(tl[c].item(), to, rtol=2e-4, atol=2e-2)
+            np.testing.assert_allclose(gl[c].cpu().numpy(), go, rtol=5e-3, atol=5e-3 * max(1.0, np.abs(go).max()))
+        # ---- rows of the log-likelihood
+        rows = pl.log_lik_rows(_t(th0, f32)).cpu().numpy()
+        np.testing.assert_allclose(rows.sum(1), pl.log_target(_t(th0, f32))[0].cpu().numpy(), rtol=1e-4, atol=1e-2)
+        spec = mo.Spec(dims, acts, lik, bias=bias)
+        for n in (0, 64, N - 1):
+            want = mo.log_lik(spec, th0[2].astype(np.float64), x[n:n + 1], y[n:n + 1])
+            np.testing.assert_allclose(rows[2, n], want, rtol=2e-4, atol=2e-4)
+    finally:
+        _force_large(False)
+
+
 def test_config5_shape_mnist_like_model_runs_on_bgemm_path():
     """BASELINE config 5's model shape: MLP(784-128-10), P = 101 770 (does not fit LDS) -> batched-GEMM path."""
     from eeyore_amd.plan import Plan
@@ -909,6 +983,18 @@ def test_config5_shape_mnist_like_model_runs_on_bgemm_path():
     np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=1e-3)
     np.testing.assert_allclose(th.cpu().numpy()[out["accepted"].cpu().numpy() == acc],
                                tho[out["accepted"].cpu().numpy() == acc], rtol=2e-3, atol=2e-4)
+    # MALA and random-walk MH on the same shape (in-kernel random streams): finite log-rates, some of each outcome
+    C2 = 24
+    th = 0.05 * pl.philox_normal(C2, seed=3, it=0)
+    tv, gg = pl.log_target_grad(th)
+    o1 = pl.mala_step(th, tv, gg, 2e-5, seed=3, it=1)
+    o2 = pl.mh_step(th, tv, 1e-3, seed=3, it=2)
+    for o in (o1, o2):
+        assert torch.isfinite(o["log_rate"]).all() and 0 < o["accepted"].sum().item() <= C2
+    tn, gn = pl.log_target_grad(th)
+    np.testing.assert_allclose(tv.cpu().numpy(), tn.cpu().numpy(), rtol=1e-5)  # the cached target follows the state
+    rows = pl.log_lik_rows(th)
+    np.testing.assert_allclose(rows.sum(1).cpu().numpy(), pl.log_target(th)[0].cpu().numpy(), rtol=1e-4)
 
 
 def test_per_chain_dual_averaging_on_the_mfma_model():
