@@ -41,6 +41,9 @@ SYMBOLS = {
     "ey_plan_attach_moments": (_i, [_vp, _vp, _vp, _vp, _i64]),
     "ey_hmc_run": (_i, [_vp, _vp, _vp, _vp, _d, _vp, _i, _vp, _i64, _u64, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp,
                         _vp, _vp]),
+    "ey_mala_run": (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i64, _u64, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp, _vp,
+                         _vp]),
+    "ey_mh_run": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ey_log_lik_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "ey_inse_univariate": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
     "ey_debug_set_variant": (_i, [_i]),

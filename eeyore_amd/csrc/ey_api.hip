@@ -351,47 +351,132 @@ int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* 
   return ey_generic_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
 }
 
+// the kernel families that do not fuse attached moments replay them from the per-iteration records of a *_run call
+static int moments_replay(ey_plan* pl, const EyRun* run, const void* theta, const void* accepted, int64_t C,
+                          const char* who, void* stream) {
+  if (!pl->mom_s1) return EY_OK;
+  if (!run || run->n_iters == 1) return ey_stats_update(theta, accepted, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2,
+                                                        pl->mom_acc, stream);
+  if (!run->samples || !run->accepted)
+    EY_FAIL(EY_ERR_UNSUPPORTED, std::string(who) + ": attached moments with n_iters > 1 need the samples and accepted "
+                                                   "records on this kernel family");
+  const size_t es = esize(pl);
+  for (int it = 0; it < run->n_iters; ++it) {
+    int rc = ey_stats_update((const char*)run->samples + (size_t)it * C * pl->m.P * es,
+                             (const char*)run->accepted + (size_t)it * C, C, pl->m.P, pl->dtype, pl->mom_s1,
+                             pl->mom_s2, pl->mom_acc, stream);
+    if (rc) return rc;
+  }
+  return EY_OK;
+}
+
+// copy the state after one iteration of a host-looped run into the per-iteration records
+static int record_iteration(ey_plan* pl, const EyRun* run, int it, const void* theta, const void* target,
+                            const void* accepted, int64_t C, hipStream_t s) {
+  const size_t es = esize(pl);
+  if (run->samples)
+    EY_HIP(hipMemcpyAsync((char*)run->samples + (size_t)it * C * pl->m.P * es, theta, (size_t)C * pl->m.P * es,
+                          hipMemcpyDeviceToDevice, s));
+  if (run->targets)
+    EY_HIP(hipMemcpyAsync((char*)run->targets + (size_t)it * C * es, target, (size_t)C * es, hipMemcpyDeviceToDevice, s));
+  if (run->accepted)
+    EY_HIP(hipMemcpyAsync((char*)run->accepted + (size_t)it * C, accepted, (size_t)C, hipMemcpyDeviceToDevice, s));
+  if (run->accept_count)
+    hipLaunchKernelGGL(k_count_accepts, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned char*)accepted, run->accept_count, C);
+  return EY_OK;
+}
+
+static int mala_impl(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                     const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                     uint64_t chain_offset, uint32_t flags, void* accepted, void* log_rate, void* stream,
+                     const EyRun* run, const char* who) {
+  int rc = check_ready(pl, C, who);
+  if (rc) return rc < 0 ? rc : EY_OK;
+  if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": null argument");
+  if (!(step > 0.0) && !step_vec) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": step must be positive");
+  if (run && run->n_iters < 1) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": n_iters must be >= 1");
+  if (C == 0) return EY_OK;
+  if ((rc = moments_check(pl, C, who))) return rc;
+  EY_HIP(hipSetDevice(pl->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+    return ey_mfma32_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
+                          log_rate, s, run);
+  if (!use_large(pl)) {
+    rc = ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
+                         log_rate, s, run);
+    return rc ? rc : moments_replay(pl, run, theta, accepted, C, who, stream);
+  }
+  const int n = run ? run->n_iters : 1;
+  for (int it = 0; it < n; ++it) {  // models beyond LDS: launches queued back to back
+    rc = ey_large_mala_mh(pl, theta, target, grad, z, u, step, step_vec, nullptr, temp, C, seed, iter + it,
+                          chain_offset, accepted, log_rate, s);
+    if (rc) return rc;
+    if (run && (rc = record_iteration(pl, run, it, theta, target, accepted, C, s))) return rc;
+    if ((rc = moments_trailing(pl, EY_OK, theta, accepted, C, stream))) return rc;
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+static int mh_impl(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
+                   const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
+                   void* accepted, void* log_rate, void* stream, const EyRun* run, const char* who) {
+  int rc = check_ready(pl, C, who);
+  if (rc) return rc < 0 ? rc : EY_OK;
+  if (!theta || !target || !scale || !accepted) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": null argument");
+  if (run && run->n_iters < 1) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": n_iters must be >= 1");
+  if (C == 0) return EY_OK;
+  if ((rc = moments_check(pl, C, who))) return rc;
+  EY_HIP(hipSetDevice(pl->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+    return ey_mfma32_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run);
+  if (!use_large(pl)) {
+    rc = ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run);
+    return rc ? rc : moments_replay(pl, run, theta, accepted, C, who, stream);
+  }
+  const int n = run ? run->n_iters : 1;
+  for (int it = 0; it < n; ++it) {
+    rc = ey_large_mala_mh(pl, theta, target, nullptr, z, u, 0.0, nullptr, scale, temp, C, seed, iter + it, chain_offset,
+                          accepted, log_rate, s);
+    if (rc) return rc;
+    if (run && (rc = record_iteration(pl, run, it, theta, target, accepted, C, s))) return rc;
+    if ((rc = moments_trailing(pl, EY_OK, theta, accepted, C, stream))) return rc;
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
 int ey_mala_step(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                  const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                  uint64_t chain_offset, uint32_t flags, void* accepted, void* log_rate, void* stream) {
-  int rc = check_ready(pl, C, "ey_mala_step");
-  if (rc) return rc < 0 ? rc : EY_OK;
-  if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: null argument");
-  if (!(step > 0.0) && !step_vec) EY_FAIL(EY_ERR_INVALID, "ey_mala_step: step must be positive");
-  if (C == 0) return EY_OK;
-  if ((rc = moments_check(pl, C, "ey_mala_step"))) return rc;
-  EY_HIP(hipSetDevice(pl->device));
-  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
-    return ey_mfma32_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
-                          log_rate, (hipStream_t)stream);
-  if (use_large(pl))
-    rc = ey_large_mala_mh(pl, theta, target, grad, z, u, step, step_vec, nullptr, temp, C, seed, iter, chain_offset,
-                          accepted, log_rate, (hipStream_t)stream);
-  else
-    rc = ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
-                         log_rate, (hipStream_t)stream);
-  return moments_trailing(pl, rc, theta, accepted, C, stream);
+  return mala_impl(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, flags, accepted,
+                   log_rate, stream, nullptr, "ey_mala_step");
+}
+
+int ey_mala_run(ey_plan* pl, void* theta, void* target, void* grad, double step, const void* step_vec, const void* temp,
+                int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags, int n_iters,
+                void* samples, void* targets, void* accepted_rec, void* accept_count, void* accepted, void* stream) {
+  const EyRun run = {n_iters, samples, targets, accepted_rec, (int*)accept_count};
+  return mala_impl(pl, theta, target, grad, nullptr, nullptr, step, step_vec, temp, C, seed, iter, chain_offset, flags,
+                   accepted, nullptr, stream, &run, "ey_mala_run");
 }
 
 int ey_mh_step(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
                void* accepted, void* log_rate, void* stream) {
-  int rc = check_ready(pl, C, "ey_mh_step");
-  if (rc) return rc < 0 ? rc : EY_OK;
-  if (!theta || !target || !scale || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_mh_step: null argument");
-  if (C == 0) return EY_OK;
-  if ((rc = moments_check(pl, C, "ey_mh_step"))) return rc;
-  EY_HIP(hipSetDevice(pl->device));
-  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
-    return ey_mfma32_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
-                        (hipStream_t)stream);
-  if (use_large(pl))
-    rc = ey_large_mala_mh(pl, theta, target, nullptr, z, u, 0.0, nullptr, scale, temp, C, seed, iter, chain_offset,
-                          accepted, log_rate, (hipStream_t)stream);
-  else
-    rc = ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
-                       (hipStream_t)stream);
-  return moments_trailing(pl, rc, theta, accepted, C, stream);
+  return mh_impl(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, flags, accepted, log_rate, stream,
+                 nullptr, "ey_mh_step");
+}
+
+int ey_mh_run(ey_plan* pl, void* theta, void* target, const void* scale, const void* temp, int64_t C, uint64_t seed,
+              uint64_t iter, uint64_t chain_offset, uint32_t flags, int n_iters, void* samples, void* targets,
+              void* accepted_rec, void* accept_count, void* accepted, void* stream) {
+  const EyRun run = {n_iters, samples, targets, accepted_rec, (int*)accept_count};
+  return mh_impl(pl, theta, target, nullptr, nullptr, scale, temp, C, seed, iter, chain_offset, flags, accepted, nullptr,
+                 stream, &run, "ey_mh_run");
 }
 
 }  // extern "C"

@@ -91,10 +91,10 @@ int ey_generic_leapfrog(ey_plan* pl, void* theta, void* p, double step, const vo
                         int64_t C, void* target, void* grad, hipStream_t s);
 int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                     const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
-                    uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s);
+                    uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run = nullptr);
 int ey_generic_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                   const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
-                  void* log_rate, hipStream_t s);
+                  void* log_rate, hipStream_t s, const EyRun* run = nullptr);
 
 // layerwise batched-GEMM kernels for large models, f32 (ey_large.hip)
 bool ey_large_needed(const ey_plan* pl);   // true when the generic kernels cannot hold the model in LDS
@@ -123,10 +123,10 @@ int ey_mfma32_log_target_grad(ey_plan* pl, const void* theta, const void* temp, 
                               hipStream_t s);
 int ey_mfma32_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                    const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
-                   uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s);
+                   uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run = nullptr);
 int ey_mfma32_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                  const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
-                 void* log_rate, hipStream_t s);
+                 void* log_rate, hipStream_t s, const EyRun* run = nullptr);
 int ey_mfma32_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                        int64_t C, void* target, void* grad, hipStream_t s);
 

@@ -376,8 +376,8 @@ __global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, 
 template <typename T>
 __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T* grad, const T* z_in, const T* u_in,
                                                T step, T sqrt_step, const T* step_vec, const T* temp, uint64_t seed,
-                                               uint64_t iter, uint64_t chain_offset, unsigned char* accepted,
-                                               T* log_rate_o) {
+                                               uint64_t iter0, uint64_t chain_offset, unsigned char* accepted,
+                                               T* log_rate_o, EyRun run, int64_t C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds<T> l = carve<T>(m, smem, 4);
   const int64_t c = blockIdx.x;
@@ -390,6 +390,11 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
   const T inv2v = T(1) / (T(2) * sc * sc);
   T* prop = l.a;
   T* gp = l.b;
+  T t_state = target[c];
+  // ey_mala_run: n_iters draws in one launch; every lane re-reads only what it wrote itself (theta, grad), the
+  // log-target is carried in a register
+  for (int it = 0; it < run.n_iters; ++it) {
+  const uint64_t iter = iter0 + (uint64_t)it;
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   T qf = T(0);
   if (!z_in) fill_normals<T>(prop, rn, P);
@@ -415,27 +420,38 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
   qf = wave_sum(qf);
   qb = wave_sum(qb);
   // log q terms share -P log(scale) - P/2 log(2 pi): they cancel in log_rate (mala.py:58-64)
-  const T log_rate = (tv - target[c]) + qf * inv2v - qb * inv2v;
+  const T log_rate = (tv - t_state) + qf * inv2v - qb * inv2v;
   const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
   const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
   const bool acc = Num<T>::log(u) < log_rate;  // mala.py:66
   if (acc) {
+    t_state = tv;
     for (int i = lane; i < P; i += WAVE) {
       theta[c * P + i] = prop[i];
       grad[c * P + i] = gp[i];
     }
   }
+  if (run.samples) {  // the state the chain is left in (what ChainList.update stores, chain_list.py:64-67)
+    T* so = static_cast<T*>(run.samples) + ((int64_t)it * C + c) * P;
+    for (int i = lane; i < P; i += WAVE) so[i] = acc ? prop[i] : l.th[i];
+  }
   if (lane == 0) {
     if (acc) target[c] = tv;
     accepted[c] = acc ? 1 : 0;
     if (log_rate_o) log_rate_o[c] = log_rate;
+    if (run.targets) static_cast<T*>(run.targets)[(int64_t)it * C + c] = t_state;
+    if (run.accepted) static_cast<unsigned char*>(run.accepted)[(int64_t)it * C + c] = acc ? 1 : 0;
+    if (run.accept_count && acc) run.accept_count[c] += 1;
+  }
+  __syncthreads();
   }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, const T* z_in, const T* u_in,
-                                             const T* scale, const T* temp, uint64_t seed, uint64_t iter,
-                                             uint64_t chain_offset, unsigned char* accepted, T* log_rate_o) {
+                                             const T* scale, const T* temp, uint64_t seed, uint64_t iter0,
+                                             uint64_t chain_offset, unsigned char* accepted, T* log_rate_o, EyRun run,
+                                             int64_t C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Lds<T> l = carve<T>(m, smem, 2);
   const int64_t c = blockIdx.x;
@@ -443,6 +459,9 @@ __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, con
   const int P = m.P;
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
+  T t_state = target[c];
+  for (int it = 0; it < run.n_iters; ++it) {  // ey_mh_run: see k_mala
+  const uint64_t iter = iter0 + (uint64_t)it;
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   if (!z_in) fill_normals<T>(l.th, rn, P);
   for (int i = lane; i < P; i += WAVE) {
@@ -451,17 +470,27 @@ __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, con
   }
   __syncthreads();
   const T tv = eval_target<T, false>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
-  const T log_rate = tv - target[c];  // symmetric kernel (metropolis_hastings.py:50)
+  const T log_rate = tv - t_state;  // symmetric kernel (metropolis_hastings.py:50)
   const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
   const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
   const bool acc = Num<T>::log(u) < log_rate;  // :56
   if (acc) {
+    t_state = tv;
     for (int i = lane; i < P; i += WAVE) theta[c * P + i] = l.th[i];
+  }
+  if (run.samples) {
+    T* so = static_cast<T*>(run.samples) + ((int64_t)it * C + c) * P;
+    for (int i = lane; i < P; i += WAVE) so[i] = acc ? l.th[i] : theta[c * P + i];
   }
   if (lane == 0) {
     if (acc) target[c] = tv;
     accepted[c] = acc ? 1 : 0;
     if (log_rate_o) log_rate_o[c] = log_rate;
+    if (run.targets) static_cast<T*>(run.targets)[(int64_t)it * C + c] = t_state;
+    if (run.accepted) static_cast<unsigned char*>(run.accepted)[(int64_t)it * C + c] = acc ? 1 : 0;
+    if (run.accept_count && acc) run.accept_count[c] += 1;
+  }
+  __syncthreads();
   }
 }
 
@@ -555,46 +584,48 @@ int ey_generic_leapfrog(ey_plan* pl, void* theta, void* p, double step, const vo
 template <typename T>
 static int launch_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                        const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
-                       uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
+                       uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run) {
+  const EyRun one = {1, nullptr, nullptr, nullptr, nullptr};
   const size_t bytes = lds_bytes(pl->m, 4, sizeof(T));
   int rc;
   if ((rc = prep(k_mala<T>, bytes))) return rc;
   // scale = np.sqrt(step) on the python float, then cast to the model dtype (mala.py:39)
   hipLaunchKernelGGL((k_mala<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
                      (const T*)z, (const T*)u, (T)step, (T)sqrt(step), (const T*)step_vec, (const T*)temp, seed, iter,
-                     chain_offset, (unsigned char*)accepted, (T*)log_rate);
+                     chain_offset, (unsigned char*)accepted, (T*)log_rate, run ? *run : one, C);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
 
 int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                     const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
-                    uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
+                    uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run) {
   return pl->dtype == EY_F32 ? launch_mala<float>(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter,
-                                                  chain_offset, accepted, log_rate, s)
+                                                  chain_offset, accepted, log_rate, s, run)
                              : launch_mala<double>(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter,
-                                                   chain_offset, accepted, log_rate, s);
+                                                   chain_offset, accepted, log_rate, s, run);
 }
 
 template <typename T>
 static int launch_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                      const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
-                     void* log_rate, hipStream_t s) {
+                     void* log_rate, hipStream_t s, const EyRun* run) {
+  const EyRun one = {1, nullptr, nullptr, nullptr, nullptr};
   const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
   int rc;
   if ((rc = prep(k_mh<T>, bytes))) return rc;
   hipLaunchKernelGGL((k_mh<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (const T*)z,
                      (const T*)u, (const T*)scale, (const T*)temp, seed, iter, chain_offset, (unsigned char*)accepted,
-                     (T*)log_rate);
+                     (T*)log_rate, run ? *run : one, C);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
 
 int ey_generic_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                   const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
-                  void* log_rate, hipStream_t s) {
-  return pl->dtype == EY_F32
-             ? launch_mh<float>(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s)
-             : launch_mh<double>(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate,
-                                 s);
+                  void* log_rate, hipStream_t s, const EyRun* run) {
+  return pl->dtype == EY_F32 ? launch_mh<float>(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset,
+                                                accepted, log_rate, s, run)
+                             : launch_mh<double>(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset,
+                                                 accepted, log_rate, s, run);
 }

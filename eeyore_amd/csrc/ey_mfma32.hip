@@ -668,7 +668,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     wave_lds_fence();  // the staged normals have been read; the evaluation reuses that LDS
     write_images(lw, p, c, h);
     const float tv = eval<PARK, UPRIOR, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
-    float log_rate = tv - A.target[chain];  // symmetric kernel: metropolis_hastings.py:50
+    const float t_old = A.target[chain];
+    float log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
     if (MODE == MODE_MALA) {
       float qb = 0.0f;
       for_each3(th, gp, p, c, h, lane, [&](float& tv0, float& gpv, float& pv, int, bool counts) {
@@ -690,8 +691,17 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
       if (acc) A.target[chain] = tv;
       A.accepted[chain] = acc ? 1 : 0;
       if (A.rate) A.rate[chain] = log_rate;
+      if (A.rec_targets) A.rec_targets[(int64_t)it * A.C + chain] = acc ? tv : t_old;
+      if (A.rec_accepted) A.rec_accepted[(int64_t)it * A.C + chain] = acc ? 1 : 0;
+      if (A.accept_count && acc) A.accept_count[chain] += 1;
     }
     if (A.mom_s1) add_moments(A, chain, acc ? p : th, thg, false, acc, c, h, lane);
+    if (A.rec_samples) {  // the state this chain is left in (chain_list.py:64-67): both candidates are in registers
+      float* so = A.rec_samples + ((int64_t)it * A.C + chain) * NPAR;
+      for_each2(th, p, [&](float& tv0, float& pv) { tv0 = acc ? pv : tv0; });
+      for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) so[idx] = v; });
+    }
+    if (A.n_iters > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     return;
   }
 
@@ -839,13 +849,13 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   {  // row tiles this wave evaluates in the whole launch
     const int64_t mine = first < A.C ? (A.C - first + stride - 1) / stride : 0;
     const int evals = (MODE == MODE_HMC) ? A.L + (A.recompute ? 1 : 0) : (MODE == MODE_LEAPFROG ? A.L + 1 : 1);
-    const int iters = (MODE == MODE_HMC) ? A.n_iters : 1;
+    const int iters = (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) ? A.n_iters : 1;
     pc.left = (int)std::min<int64_t>(mine * evals * A.ntiles * iters, 0x3fffffff);
     if (lane == 0) ctl[wave] = pc.left;
   }
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(ctl[pc.partner]) == 0) pc.on = false;  // the partner has no chain at all
-  const int n_iters = (MODE == MODE_HMC) ? A.n_iters : 1;
+  const int n_iters = (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) ? A.n_iters : 1;
   for (int it = 0; it < n_iters; ++it) {
     for (int64_t chain = first; chain < A.C; chain += stride) {  // whole waves; no workgroup synchronisation below
       // Re-read the arguments from the kernarg segment in every round: hoisted out of this loop they would all stay
@@ -971,6 +981,17 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   return mf_launch_v<MODE, 8, 0>(a, pl->n_cu, s);
 }
 
+static void mf_set_run(MfArgs& a, const EyRun* run) {
+  a.n_iters = 1;
+  if (run) {
+    a.n_iters = run->n_iters;
+    a.rec_samples = (float*)run->samples;
+    a.rec_targets = (float*)run->targets;
+    a.rec_accepted = (unsigned char*)run->accepted;
+    a.accept_count = run->accept_count;
+  }
+}
+
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
@@ -981,36 +1002,31 @@ int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void
   a.L = L; a.temp = (const float*)temp; a.seed = seed; a.iter = iter; a.chain_offset = chain_offset;
   a.recompute = (flags & EY_RECOMPUTE_INITIAL_GRAD) ? 1 : 0;
   a.accepted = (unsigned char*)accepted; a.rate = (float*)rate; a.hcur = (float*)hcur; a.hprop = (float*)hprop;
-  a.n_iters = 1;
-  if (run) {
-    a.n_iters = run->n_iters;
-    a.rec_samples = (float*)run->samples;
-    a.rec_targets = (float*)run->targets;
-    a.rec_accepted = (unsigned char*)run->accepted;
-    a.accept_count = run->accept_count;
-  }
+  mf_set_run(a, run);
   return mf_launch<MODE_HMC>(pl, a, s);
 }
 
 int ey_mfma32_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                    const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
-                   uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
+                   uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run) {
   MfArgs a = {};
   a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)grad;
   a.p0 = (const float*)z; a.u = (const float*)u; a.step = (float)step; a.sqrt_step = (float)sqrt(step);
   a.step_vec = (const float*)step_vec; a.temp = (const float*)temp; a.seed = seed; a.iter = iter;
   a.chain_offset = chain_offset; a.accepted = (unsigned char*)accepted; a.rate = (float*)log_rate;
+  mf_set_run(a, run);
   return mf_launch<MODE_MALA>(pl, a, s);
 }
 
 int ey_mfma32_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                  const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
-                 void* log_rate, hipStream_t s) {
+                 void* log_rate, hipStream_t s, const EyRun* run) {
   MfArgs a = {};
   a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)theta;  // grad unused by MH
   a.p0 = (const float*)z; a.u = (const float*)u; a.scale = (const float*)scale; a.temp = (const float*)temp;
   a.seed = seed; a.iter = iter; a.chain_offset = chain_offset; a.accepted = (unsigned char*)accepted;
   a.rate = (float*)log_rate;
+  mf_set_run(a, run);
   return mf_launch<MODE_MH>(pl, a, s);
 }
 

@@ -177,6 +177,15 @@ class Plan:
             out = dict(accepted=self.empty(C, dtype=torch.uint8))
         temp, step_vec = self._opt(temp, C), self._opt(step_vec, C)
         n_iters = int(n_iters)
+        self._records(n_iters, C, samples, targets, accepted_rec, accept_count)
+        L.check(L.lib().ey_hmc_run(self.handle, L.ptr(theta), L.ptr(target), L.ptr(grad), float(step), L.ptr(step_vec),
+                                   int(num_steps), L.ptr(temp), C, int(seed), int(it), int(chain_offset), int(flags),
+                                   n_iters, L.ptr(samples), L.ptr(targets), L.ptr(accepted_rec), L.ptr(accept_count),
+                                   L.ptr(out["accepted"]), _stream(self.device)), "ey_hmc_run")
+        self._stepped(n_iters)
+        return out
+
+    def _records(self, n_iters, C, samples, targets, accepted_rec, accept_count):
         for name, t, shape, dt in (("samples", samples, (n_iters, C, self.P), self.dtype),
                                    ("targets", targets, (n_iters, C), self.dtype),
                                    ("accepted_rec", accepted_rec, (n_iters, C), torch.uint8),
@@ -184,10 +193,37 @@ class Plan:
             if t is not None and (tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous()
                                   or t.device != self.device):
                 raise ValueError(f"{name} must be a contiguous {dt} tensor of shape {shape} on the plan's device")
-        L.check(L.lib().ey_hmc_run(self.handle, L.ptr(theta), L.ptr(target), L.ptr(grad), float(step), L.ptr(step_vec),
-                                   int(num_steps), L.ptr(temp), C, int(seed), int(it), int(chain_offset), int(flags),
-                                   n_iters, L.ptr(samples), L.ptr(targets), L.ptr(accepted_rec), L.ptr(accept_count),
-                                   L.ptr(out["accepted"]), _stream(self.device)), "ey_hmc_run")
+
+    def mala_run(self, theta, target, grad, step, n_iters, step_vec=None, temp=None, seed=0, it=0, chain_offset=0,
+                 flags=0, samples=None, targets=None, accepted_rec=None, accept_count=None, out=None):
+        """``n_iters`` MALA iterations of every chain in one launch (ey_mala_run); records as in ``hmc_run``."""
+        C = self._theta(theta)
+        if out is None:
+            out = dict(accepted=self.empty(C, dtype=torch.uint8))
+        temp, step_vec = self._opt(temp, C), self._opt(step_vec, C)
+        n_iters = int(n_iters)
+        self._records(n_iters, C, samples, targets, accepted_rec, accept_count)
+        L.check(L.lib().ey_mala_run(self.handle, L.ptr(theta), L.ptr(target), L.ptr(grad), float(step), L.ptr(step_vec),
+                                    L.ptr(temp), C, int(seed), int(it), int(chain_offset), int(flags), n_iters,
+                                    L.ptr(samples), L.ptr(targets), L.ptr(accepted_rec), L.ptr(accept_count),
+                                    L.ptr(out["accepted"]), _stream(self.device)), "ey_mala_run")
+        self._stepped(n_iters)
+        return out
+
+    def mh_run(self, theta, target, scale, n_iters, temp=None, seed=0, it=0, chain_offset=0, flags=0, samples=None,
+               targets=None, accepted_rec=None, accept_count=None, out=None):
+        """``n_iters`` random-walk MH iterations of every chain in one launch (ey_mh_run); records as in ``hmc_run``."""
+        C = self._theta(theta)
+        if out is None:
+            out = dict(accepted=self.empty(C, dtype=torch.uint8))
+        scale = self._prep(torch.broadcast_to(torch.as_tensor(scale, dtype=self.dtype, device=self.device), (self.P,)))
+        temp = self._opt(temp, C)
+        n_iters = int(n_iters)
+        self._records(n_iters, C, samples, targets, accepted_rec, accept_count)
+        L.check(L.lib().ey_mh_run(self.handle, L.ptr(theta), L.ptr(target), L.ptr(scale), L.ptr(temp), C, int(seed),
+                                  int(it), int(chain_offset), int(flags), n_iters, L.ptr(samples), L.ptr(targets),
+                                  L.ptr(accepted_rec), L.ptr(accept_count), L.ptr(out["accepted"]),
+                                  _stream(self.device)), "ey_mh_run")
         self._stepped(n_iters)
         return out
 

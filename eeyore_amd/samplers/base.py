@@ -112,8 +112,59 @@ class SerialSampler(Sampler):
 class SingleChainSerialSampler(SerialSampler):
     """State handling shared by HMC / MALA / MetropolisHastings."""
 
+    fused_block = 256  # iterations per launch of the fused run loop (0 disables it)
+
     def __init__(self, counter):
         super().__init__(counter=counter)
+
+    # -- the run loop (serial_sampler.py:35-52) with whole blocks of iterations inside one launch where nothing on the
+    #    host has to look at the state in between
+    def _can_fuse(self, verbose):
+        return (self.fused_block > 0 and self.batched and self.rng == 'philox' and not verbose
+                and self.counter.num_batches == 1 and isinstance(self.chain, ChainBuffer)
+                and set(self.chain.keys) <= {'sample', 'target_val', 'accepted'})
+
+    def run(self, num_epochs, num_burnin_epochs, verbose=False, verbose_step=100):
+        """As SerialSampler.run; for C chains on the in-kernel random streams with a full batch, the iterations in
+        which no tuner adapts run in blocks of ``fused_block`` per launch (ey_hmc_run / ey_mala_run / ey_mh_run) and
+        are recorded straight into the chain buffer.  The chains are the same, bit for bit, as with one launch per
+        iteration."""
+        if not self._can_fuse(verbose):
+            return super().run(num_epochs, num_burnin_epochs, verbose=verbose, verbose_step=verbose_step)
+        counter = self.counter
+        counter.set_epoch_info(num_epochs, num_burnin_epochs)
+        x, y = next(iter(self.dataloader))
+        if not hasattr(self.model._plan(x, y), 'hmc_run'):  # a plan without the block entry points
+            return super().run(num_epochs, num_burnin_epochs, verbose=verbose, verbose_step=verbose_step)
+        while counter.idx < counter.num_iters:
+            burning = counter.idx < counter.num_burnin_iters
+            if burning and getattr(self, 'tuner', None) is not None:
+                self.draw(x, y, savestate=False)  # the tuner looks at every iteration's acceptance rates
+                counter.increment_idx()
+                continue
+            k = min(self.fused_block, (counter.num_burnin_iters if burning else counter.num_iters) - counter.idx)
+            self._draw_block(x, y, k, savestate=not burning)
+            for _ in range(k):
+                counter.increment_idx()
+
+    def _draw_block(self, x, y, k, savestate):
+        plan = self.model._plan(x, y)
+        rec = {}
+        if savestate:
+            views = self.chain.block(k, dict(sample=self._theta, target_val=self._target,
+                                             accepted=torch.empty(self.num_chains, dtype=torch.uint8,
+                                                                  device=self._theta.device)))
+            rec = dict(samples=views.get('sample'), targets=views.get('target_val'),
+                       accepted_rec=views.get('accepted'))
+        out = self._run_block(plan, k, rec)
+        self._iter += k
+        self._publish(out['accepted'])
+        self.last = out
+        if savestate:
+            self.chain.commit(k)
+
+    def _run_block(self, plan, k, rec):
+        raise NotImplementedError
 
     def _configure(self, model, dataloader, theta0, chain, rng, seed, chain_offset, temperature):
         self.model = model

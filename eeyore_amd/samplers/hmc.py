@@ -1,7 +1,6 @@
 import torch
 
 from .base import SingleChainSerialSampler, default_counter
-from eeyore_amd.chains import ChainBuffer
 from eeyore_amd.tuners import HMCDATuner, PerChainDATuner
 from eeyore_amd import _lib as L
 
@@ -19,7 +18,6 @@ class HMC(SingleChainSerialSampler):
     every sampler, hmc.py:11)."""
 
     keys = ['sample', 'target_val', 'grad_val', 'momentum', 'hamiltonian', 'accepted']
-    fused_block = 256  # iterations per launch of the fused run loop (0 disables it)
 
     def __init__(self, model, theta0=None, dataloader=None, data0=None, counter=None, step=0.1, num_steps=10,
                  tuner=None, chain=None, rng=None, seed=0, chain_offset=0, recompute_initial_grad=False,
@@ -94,53 +92,14 @@ class HMC(SingleChainSerialSampler):
             self.step = self.step * 2. ** direction
             ratio = ratio_after_one_step()
 
-    # -- the run loop (serial_sampler.py:35-52) with whole blocks of iterations inside one launch where nothing on the
-    #    host has to look at the state in between
-    def _can_fuse(self, verbose):
-        return (self.fused_block > 0 and self.batched and self.rng == 'philox' and not verbose
-                and self.counter.num_batches == 1 and isinstance(self.chain, ChainBuffer)
-                and set(self.chain.keys) <= {'sample', 'target_val', 'accepted'})
-
-    def run(self, num_epochs, num_burnin_epochs, verbose=False, verbose_step=100):
-        """As SerialSampler.run; for C chains on the in-kernel random streams with a full batch, the iterations in
-        which no tuner adapts run in blocks of ``fused_block`` per launch (ey_hmc_run) and are recorded straight into
-        the chain buffer.  The chains are the same, bit for bit, as with one launch per iteration."""
-        if not self._can_fuse(verbose):
-            return super().run(num_epochs, num_burnin_epochs, verbose=verbose, verbose_step=verbose_step)
-        counter = self.counter
-        counter.set_epoch_info(num_epochs, num_burnin_epochs)
-        x, y = next(iter(self.dataloader))
-        while counter.idx < counter.num_iters:
-            burning = counter.idx < counter.num_burnin_iters
-            if burning and self.tuner is not None:
-                self.draw(x, y, savestate=False)  # the tuner looks at every iteration's acceptance rates
-                counter.increment_idx()
-                continue
-            k = min(self.fused_block, (counter.num_burnin_iters if burning else counter.num_iters) - counter.idx)
-            self._draw_block(x, y, k, savestate=not burning)
-            for _ in range(k):
-                counter.increment_idx()
-
-    def _draw_block(self, x, y, k, savestate):
-        plan = self.model._plan(x, y)
+    def _run_block(self, plan, k, rec):
         step, step_vec = self._step_args()
-        rec = {}
-        if savestate:
-            views = self.chain.block(k, dict(sample=self._theta, target_val=self._target,
-                                             accepted=torch.empty(self.num_chains, dtype=torch.uint8,
-                                                                  device=self._theta.device)))
-            rec = dict(samples=views.get('sample'), targets=views.get('target_val'),
-                       accepted_rec=views.get('accepted'))
         out = plan.hmc_run(self._theta, self._target, self._grad, step, self.num_steps, k, step_vec=step_vec,
                            temp=self._temp(), seed=self.seed, it=self._iter, chain_offset=self.chain_offset,
                            flags=L.EY_RECOMPUTE_INITIAL_GRAD if self.recompute_initial_grad else 0, **rec)
-        self._iter += k
-        self._publish(out['accepted'])
         self.current['momentum'] = None
         self.current['hamiltonian'] = None
-        self.last = out
-        if savestate:
-            self.chain.commit(k)
+        return out
 
     def draw(self, x, y, savestate=False):
         """One HMC iteration of every chain (hmc.py:126-170)."""

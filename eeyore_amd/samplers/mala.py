@@ -41,6 +41,11 @@ class MALA(SingleChainSerialSampler):
         loc = self.kernel_mean(self.current)
         return NormalKernel(loc, torch.full_like(loc, math.sqrt(self.step)))
 
+    def _run_block(self, plan, k, rec):
+        step, step_vec = self._step_args()
+        return plan.mala_run(self._theta, self._target, self._grad, step, k, step_vec=step_vec, temp=self._temp(),
+                             seed=self.seed, it=self._iter, chain_offset=self.chain_offset, **rec)
+
     def draw(self, x, y, savestate=False):
         plan = self.model._plan(x, y)
         temp = self._temp()

@@ -41,6 +41,19 @@ class MetropolisHastings(SingleChainSerialSampler):
     def set_kernel(self, state, scale=None, scale_tril=None):
         self.kernel.set_density_params(state['sample'].clone().detach())
 
+    def _scale(self):
+        scale = self.kernel.density.scale
+        return scale[0] if scale.dim() > 1 else scale
+
+    def _run_block(self, plan, k, rec):
+        out = plan.mh_run(self._theta, self._target, self._scale(), k, temp=self._temp(), seed=self.seed, it=self._iter,
+                          chain_offset=self.chain_offset, **rec)
+        return out
+
+    def _draw_block(self, x, y, k, savestate):
+        super()._draw_block(x, y, k, savestate)
+        self.kernel.set_density_params(self.current['sample'])
+
     def draw(self, x, y, savestate=False):
         plan = self.model._plan(x, y)
         if self.counter.num_batches != 1:  # metropolis_hastings.py:44-45

@@ -130,6 +130,16 @@ int ey_mh_step(ey_plan* plan, void* theta, void* target, const void* z, const vo
                const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
                void* accepted, void* log_rate, void* stream);
 
+/* n_iters consecutive MALA.draw / MetropolisHastings.draw iterations inside one launch, with the same records as
+ * ey_hmc_run: exactly what n_iters calls of ey_mala_step / ey_mh_step with z = u = NULL do. */
+int ey_mala_run(ey_plan* plan, void* theta, void* target, void* grad, double step, const void* step_vec,
+                const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, uint32_t flags,
+                int n_iters, void* samples, void* targets, void* accepted_rec, void* accept_count, void* accepted,
+                void* stream);
+int ey_mh_run(ey_plan* plan, void* theta, void* target, const void* scale, const void* temp, int64_t C, uint64_t seed,
+              uint64_t iter, uint64_t chain_offset, uint32_t flags, int n_iters, void* samples, void* targets,
+              void* accepted_rec, void* accept_count, void* accepted, void* stream);
+
 /* PowerPosteriorSampler.between_chain_move (eeyore/samplers/power_posterior_sampler.py:135-163) decision for C
  * chain pairs: log_rate = dlogq + (t_i - t_j) * (ell_j - ell_i) with ell the UNTEMPERED log-target; swap iff
  * log(u) < log_rate (:160).  All arrays [C] of `dtype`; dlogq may be NULL (symmetric partner choice). */

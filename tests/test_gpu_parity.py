@@ -408,11 +408,18 @@ def test_hmc_fused_run_loop_gives_the_same_chains():
     loader = DataLoader(data, batch_size=len(data), shuffle=False)
     C = 96
     th0 = 0.1 * torch.randn(C, P, device=DEV)
-    for with_tuner in (False, True):
+    from eeyore_amd.samplers import MALA, MetropolisHastings
+    for with_tuner in (False, True, "mala", "mh"):
         runs = []
         for block in (0, 4, 256):
-            tuner = PerChainDATuner(torch.full((C,), 0.02, device=DEV), num_steps=6) if with_tuner else None
-            s = HMC(model, theta0=th0, dataloader=loader, seed=7, step=0.02, num_steps=6, tuner=tuner)
+            if with_tuner == "mala":
+                s = MALA(model, theta0=th0, dataloader=loader, seed=7, step=0.0005)
+            elif with_tuner == "mh":
+                s = MetropolisHastings(model, theta0=th0, dataloader=loader, seed=7)
+                s.kernel.set_density_params(s.current['sample'], scale=torch.full((P,), 0.005, device=DEV))
+            else:
+                tuner = PerChainDATuner(torch.full((C,), 0.02, device=DEV), num_steps=6) if with_tuner else None
+                s = HMC(model, theta0=th0, dataloader=loader, seed=7, step=0.02, num_steps=6, tuner=tuner)
             s.fused_block = block
             s.run(num_epochs=17, num_burnin_epochs=6)
             ch = s.get_chain()
@@ -1102,6 +1109,60 @@ def test_chain_buffer_ess_after_a_short_run():
     assert ok.float().mean().item() > 0.99
     assert (ess[ok] > 1.0).all() and (ess[ok] < 20 * n).all()
     assert tuple(buf.mc_se().shape) == (C, pl.P)
+
+
+@pytest.mark.parametrize("kind", ["mfma32", "generic_f32", "generic_f64", "bgemm"])
+@pytest.mark.parametrize("sampler", ["mala", "mh"])
+def test_mala_and_mh_run_equal_consecutive_steps(kind, sampler):
+    """ey_mala_run / ey_mh_run: as test_hmc_run_equals_consecutive_steps for the other two samplers."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.distributed import ChainStats
+    if kind == "bgemm":
+        _force_large(True)
+    try:
+        if kind == "generic_f64":
+            rec = groups(load("g4_hmc_traces.npz"))["mlp2321"]
+            pl, step, sc = _plan(rec, torch.float64), 0.05, 0.3
+        else:
+            rec, pl = _cfg3_plan()
+            step, sc = 0.0005, 0.005
+        flags = L.EY_FORCE_GENERIC if kind.startswith("generic") else 0
+        C, n = (2300 if kind == "mfma32" else 40), 6
+        th = 0.2 * pl.philox_normal(C, seed=33, it=0)
+        t, g = pl.log_target_grad(th)
+        a = [th.clone(), t.clone(), g.clone()]
+        b = [th.clone(), t.clone(), g.clone()]
+        scale = torch.full((pl.P,), sc, dtype=pl.dtype, device=DEV)
+        want_s, want_t, want_a = [], [], []
+        st_a = ChainStats(C, pl.P, DEV)
+        for it in range(n):
+            if sampler == "mala":
+                out = pl.mala_step(a[0], a[1], a[2], step, seed=33, it=10 + it, flags=flags)
+            else:
+                out = pl.mh_step(a[0], a[1], scale, seed=33, it=10 + it, flags=flags)
+            want_s.append(a[0].clone()); want_t.append(a[1].clone()); want_a.append(out["accepted"].clone())
+            st_a.update(a[0], out["accepted"])
+        recs = dict(samples=pl.empty(n, C, pl.P), targets=pl.empty(n, C),
+                    accepted_rec=pl.empty(n, C, dtype=torch.uint8),
+                    accept_count=torch.zeros(C, dtype=torch.int32, device=DEV))
+        st_b = ChainStats(C, pl.P, DEV)
+        st_b.attach(pl)
+        if sampler == "mala":
+            out = pl.mala_run(b[0], b[1], b[2], step, n, seed=33, it=10, flags=flags, **recs)
+        else:
+            out = pl.mh_run(b[0], b[1], scale, n, seed=33, it=10, flags=flags, **recs)
+        pl.detach_moments()
+        assert torch.equal(b[0], a[0]) and torch.equal(b[1], a[1])
+        if sampler == "mala":
+            assert torch.equal(b[2], a[2])
+        assert torch.equal(recs["samples"], torch.stack(want_s)) and torch.equal(recs["targets"], torch.stack(want_t))
+        assert torch.equal(recs["accepted_rec"], torch.stack(want_a)) and torch.equal(out["accepted"], want_a[-1])
+        assert torch.equal(recs["accept_count"].long(), torch.stack(want_a).long().sum(0))
+        assert 0 < recs["accept_count"].sum().item() <= n * C
+        assert st_b.n == n and torch.equal(st_b.s1, st_a.s1) and torch.equal(st_b.s2, st_a.s2)
+        assert torch.equal(st_b.acc, st_a.acc)
+    finally:
+        _force_large(False)
 
 
 @pytest.mark.parametrize("kind", ["mfma32", "generic_f32", "generic_f64", "bgemm"])

@@ -68,3 +68,10 @@ for dtype in (torch.float32, torch.float64):
         acc = torch.stack(accs[-50:]).float().mean().item()
         print(f"cfg2 MALA {C} chains MLP(2-3-2-1) N=256 {str(dtype)[6:]}: {dt * 1e6:.1f} us/draw -> {C / dt:.3e} "
               f"draws/s x chains, acceptance {acc:.2f}")
+        K2 = 100
+        def f2run():
+            it[0] += K2
+            pl.mala_run(th, t, g, 0.02, K2, seed=2, it=it[0])
+        dt = timed(f2run, 10) / K2
+        print(f"     the same, {K2} iterations per launch (ey_mala_run): {dt * 1e6:.1f} us/draw -> {C / dt:.3e} "
+              f"draws/s x chains")
