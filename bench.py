@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
-    ap.add_argument("--iters-per-launch", type=int, default=10,
+    ap.add_argument("--iters-per-launch", type=int, default=25,
                     help="HMC iterations (bench steps) per kernel launch: ey_hmc_run, as HMC.run issues them; 1 = ey_hmc_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true", help="time the generic VALU kernel instead of the MFMA one")
