@@ -47,3 +47,60 @@ def ess(samples):
 def mc_se(samples):
     """eeyore/stats/mc_se.py:4-5 with mc_se_from_cov.py:3-4 for p = 1: sqrt of the asymptotic variance."""
     return torch.sqrt(inse_univariate(samples)["sig2"])
+
+
+# ---------------------------------------------------------------------------------------------- multivariate, many chains
+def inse_mc_cov_chains(x):
+    """The reference's multivariate initial-sequence estimator (eeyore/stats/inse_mc_cov.py:9-83, adjust=False) for C
+    chains at once: x [C, n, p] -> [C, p, p].  Every lag pair is ONE batched product over all chains (the reference's
+    torch.ger double loop, :24-31), the positive-definiteness test (:41, a Cholesky attempt on a symmetric matrix,
+    eeyore/linalg/is_pos_def.py:3-11) and the determinant test (:62-65) are batched too; chains leave the loop one by
+    one through masks.  Chains for which the reference raises 'Not enough samples' (:45-46) come back as NaN.
+    For small models (p up to a few dozen); for one parameter at a time over millions of series use inse_univariate."""
+    if x.dim() != 3:
+        raise ValueError("x must be [chains, iterations, parameters]")
+    C, n, p = x.shape
+    xc = x - x.mean(1, keepdim=True)                                     # :10
+    ub = n // 2                                                          # :14
+
+    def gam(lag):                                                        # :24-31 for every chain
+        return torch.matmul(xc[:, :n - lag].transpose(1, 2), xc[:, lag:]) / n
+
+    def pos_def(m):
+        sym = (m == m.transpose(1, 2)).flatten(1).all(1)
+        _, info = torch.linalg.cholesky_ex(m)
+        return sym & (info == 0)
+
+    sig = torch.zeros(C, p, p, dtype=x.dtype, device=x.device)
+    last = torch.zeros(C, dtype=x.dtype, device=x.device)
+    state = torch.zeros(C, dtype=torch.int8, device=x.device)            # 0 searching, 1 extending, 2 stopped
+    for m in range(ub):
+        if bool((state == 2).all()):
+            break
+        g0, g1 = gam(2 * m), gam(2 * m + 1)
+        G = g0 + g1
+        G = (G + G.transpose(1, 2)) / 2                                  # :33-34
+        searching, extending = state == 0, state == 1
+        cand = torch.where(torch.tensor(m == 0, device=x.device), -g0 + 2 * G, sig + 2 * G)  # :36-39 / :62
+        # chains still searching: accept the sum unconditionally, then test positive definiteness (:41-43)
+        sig = torch.where(searching[:, None, None], cand, sig)
+        found = searching & pos_def(torch.where(searching[:, None, None], sig, torch.eye(p, dtype=x.dtype,
+                                                                                       device=x.device).expand(C, p, p)))
+        det_new = torch.linalg.det(torch.where(found[:, None, None], sig, cand))
+        last = torch.where(found, det_new, last)                         # :48
+        # chains extending: keep the candidate only while the determinant strictly grows (:62-70)
+        grow = extending & (det_new > last)
+        sig = torch.where(grow[:, None, None], cand, sig)
+        last = torch.where(grow, det_new, last)
+        state = torch.where(found, torch.ones_like(state), state)
+        state = torch.where(extending & ~grow, torch.full_like(state, 2), state)
+    sig = torch.where((state == 0)[:, None, None], torch.full_like(sig, float('nan')), sig)
+    return sig
+
+
+def multi_ess_chains(x):
+    """multi_ess (eeyore/stats/multi_ess.py:6-14) for C chains at once: x [C, n, p] -> [C]."""
+    C, n, p = x.shape
+    xc = x - x.mean(1, keepdim=True)
+    cov = torch.matmul(xc.transpose(1, 2), xc) / (n - 1)                 # eeyore/stats/cov.py:5-15
+    return n * (torch.linalg.det(cov) / torch.linalg.det(inse_mc_cov_chains(x))) ** (1.0 / p)

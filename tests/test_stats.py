@@ -46,3 +46,22 @@ def test_running_mean_and_nearest_pd():
     a = torch.tensor([[1.0, 2.0], [2.0, 1.0]], dtype=torch.float64)  # indefinite
     p = st.nearest_pd(a)
     assert st.is_pos_def(p) and not st.is_pos_def(a)
+
+
+def test_batched_multivariate_inse_and_ess_over_chains():
+    """stats.batched.inse_mc_cov_chains / multi_ess_chains: all chains per lag in one batched product, against the
+    reference's numbers (G7) and the per-chain function on chains that stop at different lags."""
+    from eeyore_amd.stats import batched
+    z = load("g7_stats.npz")
+    x = torch.tensor(z["chains"])
+    np.testing.assert_allclose(batched.inse_mc_cov_chains(x).numpy(), z["inse_mc_cov"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(batched.multi_ess_chains(x).numpy(), z["multi_ess"], rtol=1e-8)
+    rng = np.random.default_rng(0)
+    y = torch.tensor(rng.standard_normal((7, 240, 4)).cumsum(1) * 0.1 + rng.standard_normal((7, 240, 4)))
+    y[3] = 1.5  # a constant chain: never positive definite -> the reference raises 'Not enough samples'
+    got = batched.inse_mc_cov_chains(y)
+    for i in range(7):
+        if i == 3:
+            assert torch.isnan(got[i]).all()
+            continue
+        np.testing.assert_allclose(got[i].numpy(), st.inse_mc_cov(y[i]).numpy(), rtol=1e-10, atol=1e-13)
