@@ -37,6 +37,7 @@ SYMBOLS = {
     "ey_pt_swap_decide": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "ey_philox_normal": (_i, [_vp, _i64, _i64, _u64, _u64, _u64, _i, _vp]),
     "ey_philox_uniform": (_i, [_vp, _i64, _u64, _u64, _u64, _i, _vp]),
+    "ey_philox_block": (_i, [ct.POINTER(ct.c_uint32), ct.POINTER(ct.c_uint32), ct.POINTER(ct.c_uint32)]),
     "ey_stats_update": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
     "ey_plan_attach_moments": (_i, [_vp, _vp, _vp, _vp, _i64]),
     "ey_hmc_run": (_i, [_vp, _vp, _vp, _vp, _d, _vp, _i, _vp, _i64, _u64, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp,

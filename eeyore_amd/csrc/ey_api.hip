@@ -555,6 +555,12 @@ int ey_philox_normal(void* out, int64_t C, int64_t P, uint64_t seed, uint64_t it
   return EY_OK;
 }
 
+int ey_philox_block(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+  if (!counter || !key || !out) EY_FAIL(EY_ERR_INVALID, "ey_philox_block: null argument");
+  ey_philox4x32_10(counter[0], counter[1], counter[2], counter[3], key[0], key[1], out);
+  return EY_OK;
+}
+
 int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, int dtype,
                       void* stream) {
   if (!out) EY_FAIL(EY_ERR_INVALID, "ey_philox_uniform: null argument");

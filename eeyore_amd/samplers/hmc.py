@@ -74,8 +74,16 @@ class HMC(SingleChainSerialSampler):
         t, g = self.model._plan(x, y).leapfrog(th, p, step, self.num_steps, step_vec=step_vec, temp=self._temp())
         return (th[0], p[0], t[0], g[0]) if single else (th, p, t, g)
 
-    def init_step(self, theta):
-        """Double or halve a unit step until the one-step acceptance ratio crosses 1/2 (hmc.py:38-77; chain 0)."""
+    def init_step(self, theta, intended=False):
+        """First step size for the dual-averaging tuner, as ``HMC.init_step`` (hmc.py:38-77) computes it for chain 0:
+        from step 1 with one leapfrog step per trial, the same momentum in every trial, r = exp(H_cur - H_prop).
+
+        The reference's direction a = 2 (r > 1/2) - 1 is an integer tensor, so its ``torch.pow(2, -a)`` / ``torch.pow(2, a)``
+        (:60, :67) are integer powers and 2**(-1) is 0: for a = +1 the step doubles until r underflows to 0 (or is NaN),
+        for a = -1 it becomes 0 at once (``tuner.num_steps`` then raises ZeroDivisionError, :27).  That behaviour is kept
+        by default so that a run started here starts where the reference's does (pinned by the G9 fixture);
+        ``intended=True`` gives what :58-77 set out to write (Hoffman & Gelman 2014, algorithm 4: double or halve until r
+        crosses 1/2), which is also what ``init_step_per_chain`` does."""
         x, y = next(iter(self.dataloader))
         self.step, self.num_steps = 1., 1
         th = (theta if theta.dim() == 1 else theta[0]).to(self.model.device, self.model.dtype)
@@ -84,13 +92,48 @@ class HMC(SingleChainSerialSampler):
 
         def ratio_after_one_step():
             _, p_new, t_new, _ = self.leapfrog(th, momentum, x, y)
-            return torch.exp(h_start - self.hamiltonian(-t_new, p_new))
+            return torch.exp(h_start - self.hamiltonian(-t_new, p_new)).item()
 
         ratio = ratio_after_one_step()
         direction = 1 if ratio > 0.5 else -1
-        while ratio ** direction > 2. ** (-direction):
-            self.step = self.step * 2. ** direction
+        if intended:
+            threshold, factor = 2. ** (-direction), 2. ** direction
+        else:
+            threshold, factor = (0, 2) if direction == 1 else (2, 0)
+        for _ in range(2200):  # f64 steps leave the representable range long before
+            if not (ratio ** direction if ratio != 0 or direction == 1 else float('inf')) > threshold:
+                break
+            self.step = factor * self.step
             ratio = ratio_after_one_step()
+        self.step = float(self.step)
+
+    def init_step_per_chain(self, theta, max_trials=60):
+        """One starting step size PER CHAIN for ``theta`` [C, P]: Hoffman & Gelman's heuristic
+        (2014, algorithm 4) for every chain at once -- each trial is one launch of ``ey_hmc_leapfrog`` with the per-chain
+        step vector; chains whose ratio has crossed 1/2 keep their step.  Returns steps [C] on the device."""
+        x, y = next(iter(self.dataloader))
+        plan = self.model._plan(x, y)
+        th0 = self._state_tensor(theta)
+        C, P = th0.shape
+        momentum = torch.randn(C, P, dtype=self.model.dtype, device=self.model.device)
+        t0, _ = plan.log_target_grad(th0, temp=self._temp())
+        h_start = -t0 + 0.5 * momentum.pow(2).sum(-1)
+        step = torch.ones(C, dtype=self.model.dtype, device=self.model.device)
+
+        def ratio_after_one_step():
+            th, p = th0.clone(), momentum.clone()
+            t, _ = plan.leapfrog(th, p, 0.0, 1, step_vec=step, temp=self._temp())
+            return torch.exp(h_start - (-t + 0.5 * p.pow(2).sum(-1)))
+
+        ratio = torch.nan_to_num(ratio_after_one_step(), nan=0.0)
+        direction = torch.where(ratio > 0.5, 1.0, -1.0).to(step.dtype)
+        for _ in range(max_trials):
+            active = ratio.pow(direction) > torch.pow(2.0, -direction)
+            if not bool(active.any()):
+                break
+            step = torch.where(active, step * torch.pow(2.0, direction), step)
+            ratio = torch.nan_to_num(ratio_after_one_step(), nan=0.0)
+        return step
 
     def _run_block(self, plan, k, rec):
         step, step_vec = self._step_args()

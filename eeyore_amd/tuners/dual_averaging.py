@@ -14,14 +14,19 @@ class HMCDATuner(Tuner):
 
     def __init__(self, l, e0=None, d=0.65, eub=None):
         self.l, self.e0, self.d, self.eub = l, e0, d, eub
-        self.m = None if e0 is None else math.log(10 * e0)        # mu: the point log-steps shrink towards
+        self.m = None if e0 is None else self._log10x(e0)         # mu: the point log-steps shrink towards
         self.logeub = None if eub is None else math.log(eub)
         self.logbare = 0.                                         # log of the averaged step
         self.barh = 0.                                            # running mean of (target - observed) acceptance
         self.g, self.k = self.gamma, self.kappa                   # the reference's attribute names
 
+    @staticmethod
+    def _log10x(e0):
+        # numpy's log(0) = -inf (hmcda_tuner.py:32 warns and goes on; num_steps then divides by zero, hmc.py:27)
+        return math.log(10 * e0) if e0 > 0 else float('-inf')
+
     def set_m(self, e0):
-        self.m = math.log(10 * e0)
+        self.m = self._log10x(e0)
 
     def num_steps(self, e):
         return max(1, round(self.l / e))

@@ -153,6 +153,11 @@ int ey_philox_normal(void* out, int64_t C, int64_t P, uint64_t seed, uint64_t it
                      void* stream);
 int ey_philox_uniform(void* out, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, int dtype,
                       void* stream);
+/* One Philox4x32-10 block on the HOST (no device needed): out[4] = philox(counter[4], key[2]), the function the device
+ * streams above are built on (Salmon et al. 2011; checked against Random123's known-answer vectors in the tests).
+ * counter = (block, chain_lo, iter_lo, iter_hi << 8 | stream | chain_hi << 20), key = (seed_lo, seed_hi), stream 0 =
+ * normals, 1 = accept uniform. */
+int ey_philox_block(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 
 /* Running per-chain moments for ChainLists.mean / R-hat style summaries (eeyore/chains/chain_lists.py:65-66,
  * eeyore/stats/multi_rhat.py:10-40): s1 += theta, s2 += theta^2 ([C,P] double accumulators), acc += accepted

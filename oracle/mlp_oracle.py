@@ -231,6 +231,79 @@ def hmc_draw(spec, cur, p0, u, x, y, step, num_steps, temperature="spec"):
     return new, info
 
 
+def init_step(spec, theta, momentum, x, y):
+    """``HMC.init_step`` (eeyore/samplers/hmc.py:38-77) on one full batch, AS THE REFERENCE BEHAVES: from step 1 with
+    one leapfrog step per trial and the acceptance ratio r = exp(H_cur - H_prop); ``momentum`` replaces the
+    ``torch.randn`` of :48 and is kept through all trials (:46-49, :71-72).  The direction a = 2 (r > 1/2) - 1 (:58) is an
+    INTEGER tensor, so ``torch.pow(2, -a)`` (:60) and ``torch.pow(2, a)`` (:67) are integer powers and 2**(-1) is 0:
+      a = +1: the loop condition r > pow(2, -1) is r > 0 -- the step doubles until exp underflows to 0 (or r is NaN);
+      a = -1: the condition 1/r > 2 holds, the step is multiplied by pow(2, -1) = 0, the next ratio is exp(0) = 1 and
+              the loop ends with step 0 (``tuner.num_steps`` then raises ZeroDivisionError, hmc.py:27).
+    (What :58-77 evidently intend -- Hoffman & Gelman 2014, algorithm 4: double or halve until r crosses 1/2 -- is
+    ``init_step_intended`` below, the form the per-chain extension uses.)"""
+    dt = theta.dtype
+    h_cur = hamiltonian(log_target(spec, theta, x, y), momentum)
+
+    def ratio(step):
+        _, p, tv, _ = leapfrog(spec, theta, momentum, x, y, step, 1)
+        with np.errstate(over="ignore", invalid="ignore"):
+            return np.exp(dt.type(h_cur - hamiltonian(tv, p)))
+
+    step = 1.0
+    r = ratio(step)
+    a = 1 if r > 0.5 else -1
+    threshold, factor = (0, 2) if a == 1 else (2, 0)  # integer pow(2, -a), pow(2, a)
+    with np.errstate(divide="ignore"):
+        while r ** a > threshold:
+            step = factor * step
+            r = ratio(step)
+    return float(step)
+
+
+def init_step_intended(spec, theta, momentum, x, y, max_doublings=60):
+    """Hoffman & Gelman's heuristic for a first step size (2014, algorithm 4), which hmc.py:38-77 set out to write:
+    double the step while the one-step acceptance ratio stays above 1/2, or halve it while it stays below."""
+    dt = theta.dtype
+    h_cur = hamiltonian(log_target(spec, theta, x, y), momentum)
+
+    def ratio(step):
+        _, p, tv, _ = leapfrog(spec, theta, momentum, x, y, step, 1)
+        with np.errstate(over="ignore", invalid="ignore"):
+            return np.exp(dt.type(h_cur - hamiltonian(tv, p)))
+
+    step = 1.0
+    r = ratio(step)
+    a = 1 if r > 0.5 else -1
+    for _ in range(max_doublings):
+        if not r ** a > 2.0 ** (-a):
+            break
+        step = step * 2.0 ** a
+        r = ratio(step)
+    return float(step)
+
+
+def dual_averaging(l, e0, d, eub, rates):
+    """``HMCDATuner.tune`` (eeyore/tuners/hmcda_tuner.py:43-59; Hoffman & Gelman 2014, algorithms 4-5) fed with the
+    acceptance rates of iterations 0, 1, ...: the exploring step exp(log e) and ``num_steps = max(1, round(l / e))``
+    after each, the averaged step for the last one (``return_e=False``, as hmc.py:158-163 asks at the end of burn-in)."""
+    g, t0, k = 0.05, 10, 0.75
+    m = np.log(10 * e0)
+    barh, logbare = 0.0, 0.0
+    steps, nsteps = [], []
+    for idx, rate in enumerate(rates):
+        it = idx + 1
+        d_w, e_w = 1 / (it + t0), 1 / it ** k
+        barh = (1 - d_w) * barh + d_w * (d - rate)
+        loge = m - np.sqrt(it) * barh / g
+        if eub is not None:
+            loge = min(loge, np.log(eub))
+        logbare = e_w * loge + (1 - e_w) * logbare
+        e = np.exp(loge) if idx < len(rates) - 1 else np.exp(logbare)
+        steps.append(e)
+        nsteps.append(max(1, round(l / e)))
+    return np.array(steps), np.array(nsteps), (barh, logbare, m)
+
+
 # --------------------------------------------------------------------------- MALA / MH
 
 def normal_log_prob_sum(v, loc, scale):

@@ -359,7 +359,7 @@ def g6_power_posterior():
 # ----------------------------------------------------------------------------- G7: chain statistics (next rows)
 def g7_stats():
     out = {}
-    chains = [np.loadtxt(os.path.join(REF, "examples", "stats", f"chain0{i}.csv"), delimiter=",", skiprows=1)
+    chains = [np.loadtxt(os.path.join(REF, "examples", "stats", f"chain0{i}.csv"), delimiter=",")
               for i in range(1, 5)]
     x = torch.tensor(np.array(chains), dtype=torch.float64)
     out["chains"] = x.numpy()
@@ -376,7 +376,7 @@ def g7_stats():
 def g8_univariate_stats():
     """inse_mc_cov / multi_ess of the reference applied to single columns (p = 1): the statistic the batched device
     kernel ey_inse_univariate computes for every (chain, parameter) series."""
-    chains = [np.loadtxt(os.path.join(REF, "examples", "stats", f"chain0{i}.csv"), delimiter=",", skiprows=1)
+    chains = [np.loadtxt(os.path.join(REF, "examples", "stats", f"chain0{i}.csv"), delimiter=",")
               for i in range(1, 5)]
     x = torch.tensor(np.array(chains), dtype=torch.float64)
     m, n, p = x.shape
@@ -396,6 +396,137 @@ def g8_univariate_stats():
     print("g8 inse", inse, "var", var)
 
 
+# ----------------------------------------------------------------------------- G9: tuner, init_step, chain files
+def g9_tuner_initstep_chainfile():
+    """Host-side pieces around the step that the reference's own tests do not pin: HMCDATuner.tune
+    sequences (hmcda_tuner.py:43-59), HMC.init_step with its momentum recorded (hmc.py:38-77), a burn-in of HMC.draw
+    with the tuner in the loop (hmc.py:158-163), the bytes ChainFile / ChainList.to_chainfile write
+    (chain_file.py:21-45, chain_list.py:112-124) and the directory SerialSampler.benchmark leaves
+    (serial_sampler.py:54-126)."""
+    import tempfile
+    from pathlib import Path
+    from eeyore.chains import ChainFile, ChainLists
+    from eeyore.tuners import HMCDATuner
+    out = {}
+    # ---- (a) tuner sequences
+    rng = np.random.default_rng(42)
+    for key, l, e0, d_, eub in (("plain", 1.0, 0.07, 0.65, None), ("eub", 0.5, 0.2, 0.8, 0.25), ("low", 2.0, 0.01, 0.65, None)):
+        rates = np.clip(rng.beta(4, 2, size=60) + (0.3 if key == "low" else 0.0), 0.0, 1.0)
+        t = HMCDATuner(l, e0=e0, d=d_, eub=eub)
+        es, ns = [], []
+        for i, r in enumerate(rates):
+            e, n = t.tune(float(r), i, return_e=i < len(rates) - 1)
+            es.append(e); ns.append(n)
+        out[f"tuner/{key}/args"] = np.array([l, e0, d_, np.nan if eub is None else eub])
+        out[f"tuner/{key}/rates"] = rates
+        out[f"tuner/{key}/step"] = np.array(es)
+        out[f"tuner/{key}/num_steps"] = np.array(ns)
+        out[f"tuner/{key}/final_state"] = np.array([t.barh, t.logbare, t.m])
+    # ---- (b) init_step, momentum recorded
+    d = datasets(torch.float64)
+    th221 = torch.tensor([1.1, -2.9, -0.4, 0.8, 4.3, 9.2, 4.44, -3.4, 7.2], dtype=torch.float64)
+    # (only starts whose first ratio exceeds 1/2 are recorded: in the halving direction the reference multiplies by
+    # torch.pow(2, a) with an INTEGER tensor a = -1, hmc.py:67, which is 0, so its step collapses to 0 at once and
+    # tuner.num_steps divides by zero -- observed here for every MLP(4-...) start tried)
+    for key, name, th0, sig, seed in (("mlp221", "mlp221", th221, 100.0, 31),
+                                      ("mlp2321_a", "mlp2321", None, float(np.sqrt(3.0)), 32),
+                                      ("mlp2321_b", "mlp2321", None, float(np.sqrt(3.0)), 33)):
+        m = make_model(name, torch.float64, prior_sigma=sig)
+        data = d[MODELS[name][3]]
+        P = m.num_params()
+        loader = DataLoader(data, batch_size=len(data), shuffle=False)
+        torch.manual_seed(seed)
+        if th0 is None:
+            th0 = 0.1 * torch.randn(P, dtype=torch.float64)
+        with Recorder() as r:
+            s = HMC(m, theta0=th0.clone(), dataloader=loader, tuner=HMCDATuner(1.0), chain=ChainList())
+        rec = spec_arrays(name, data, sig, P)
+        rec.update(theta0=tnp(th0), momentum=r.z[0].reshape(-1), step=np.array(s.step), num_steps=np.array(s.num_steps),
+                   tuner_m=np.array(s.tuner.m))
+        print("g9 init_step", key, s.step, s.num_steps)
+        for k, v in rec.items():
+            out[f"init_step/{key}/{k}"] = v
+    # ---- (c) burn-in with the tuner in the loop: HMC.draw + HMCDATuner.tune, randoms recorded
+    for key, name, sig, l, e0, eub, burn, keep, seed in (("mlp2321", "mlp2321", float(np.sqrt(3.0)), 4.0, None, 1.5, 40, 10, 32),
+                                                         ("mlp433", "mlp433", float(np.sqrt(3.0)), 0.3, 0.02, None, 30, 6, 7)):
+        m = make_model(name, torch.float64, prior_sigma=sig)
+        data = d[MODELS[name][3]]
+        P = m.num_params()
+        loader = DataLoader(data, batch_size=len(data), shuffle=False)
+        torch.manual_seed(seed)
+        th0 = 0.1 * torch.randn(P, dtype=torch.float64)
+        with Recorder() as r0:
+            s = HMC(m, theta0=th0.clone(), dataloader=loader, tuner=HMCDATuner(l, e0=e0, eub=eub), chain=ChainList())
+        steps, nsteps, zs, us, acc, samples, rates = [], [], [], [], [], [], []
+        s.counter.set_epoch_info(burn + keep, burn)
+        for it in range(burn + keep):
+            steps.append(s.step); nsteps.append(s.num_steps)
+            with Recorder() as r:
+                s.draw(data.x, data.y, savestate=it >= burn)
+            zs.append(r.z[0].reshape(-1)); us.append(r.u[0].reshape(-1)[0])
+            acc.append(s.current["accepted"]); samples.append(tnp(s.current["sample"]))
+            s.counter.increment_idx()
+        rec = spec_arrays(name, data, sig, P)
+        rec.update(theta0=tnp(th0), init_momentum=r0.z[0].reshape(-1) if r0.z else np.zeros(0), l=np.array(l),
+                   e0=np.array(np.nan if e0 is None else e0), eub=np.array(np.nan if eub is None else eub),
+                   burn=np.array(burn), step=np.array(steps), num_steps=np.array(nsteps), z=np.array(zs), u=np.array(us),
+                   accepted=np.array(acc), sample=np.array(samples), final_step=np.array(s.step),
+                   final_num_steps=np.array(s.num_steps))
+        print("g9 da trace", key, "acc", np.mean(acc), "final step", s.step, s.num_steps)
+        for k, v in rec.items():
+            out[f"da_trace/{key}/{k}"] = v
+    # ---- (d) the bytes of the chain files
+    rng = np.random.default_rng(3)
+    n, P = 7, 5
+    smp = rng.standard_normal((n, P)) * np.array([1e-3, 1.0, 1e3, 1e-12, 7.0])
+    tv = -np.abs(rng.standard_normal(n)) * 100
+    gv = rng.standard_normal((n, P))
+    ac = (rng.random(n) < 0.6).astype(int)
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        ch = ChainList(keys=["sample", "target_val", "grad_val", "accepted"])
+        for i in range(n):
+            ch.update(dict(sample=torch.tensor(smp[i], dtype=dt), target_val=torch.tensor(tv[i], dtype=dt),
+                           grad_val=torch.tensor(gv[i], dtype=dt), accepted=int(ac[i])))
+        with tempfile.TemporaryDirectory() as td:
+            ch.to_chainfile(path=Path(td), mode="w")
+            for k in ("sample", "target_val", "grad_val", "accepted"):
+                out[f"chainfile/{tag}/{k}.csv"] = np.frombuffer(Path(td, f"{k}.csv").read_bytes(), dtype=np.uint8)
+            back = ChainFile(keys=["sample", "target_val", "accepted"], path=Path(td)).to_chainlist(dtype=dt)
+            out[f"chainfile/{tag}/readback_sample"] = torch.stack(back.vals["sample"]).numpy()
+            out[f"chainfile/{tag}/readback_target_val"] = torch.stack(back.vals["target_val"]).numpy()
+            out[f"chainfile/{tag}/readback_accepted"] = np.array(back.vals["accepted"])
+    out["chainfile/sample"] = smp; out["chainfile/target_val"] = tv; out["chainfile/grad_val"] = gv
+    out["chainfile/accepted"] = ac
+    # per-iteration appends (ChainFile.update with its defaults: reopen, append, close)
+    with tempfile.TemporaryDirectory() as td:
+        cf = ChainFile(keys=["sample", "target_val", "accepted"], path=Path(td), mode="a")
+        cf.close()
+        for i in range(3):
+            cf.update(dict(sample=torch.tensor(smp[i]), target_val=torch.tensor(tv[i]), accepted=int(ac[i])))
+        for k in ("sample", "target_val", "accepted"):
+            out[f"chainfile/append3/{k}.csv"] = np.frombuffer(Path(td, f"{k}.csv").read_bytes(), dtype=np.uint8)
+    # ---- (e) what SerialSampler.benchmark leaves on disk
+    name, sig = "mlp221", 100.0
+    m = make_model(name, torch.float64, prior_sigma=sig)
+    data = d["xor"]
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    torch.manual_seed(5)
+    inits = [0.5 * torch.randn(9, dtype=torch.float64) for _ in range(3)]
+    s = MALA(m, theta0=inits[0].clone(), dataloader=loader, step=0.3, chain=ChainList())
+    with tempfile.TemporaryDirectory() as td:
+        s.benchmark(num_chains=3, num_epochs=9, num_burnin_epochs=4, path=td, init=inits)
+        listing = sorted(str(p.relative_to(td)) for p in Path(td).rglob("*"))
+        out["benchmark/listing"] = np.array(listing)
+        out["benchmark/run_counts.txt"] = np.frombuffer(Path(td, "run_counts.txt").read_bytes(), dtype=np.uint8)
+        out["benchmark/lines_per_file"] = np.array([len(Path(td, "run1", f"{k}.csv").read_text().splitlines())
+                                                    for k in ("sample", "target_val", "accepted")])
+        cl = ChainLists.from_file([Path(td, f"run{i}") for i in (1, 2, 3)])
+        out["benchmark/from_file_shape"] = np.array(cl.get_samples().shape)
+    out["benchmark/args"] = np.array([3, 9, 4])
+    np.savez_compressed(os.path.join(HERE, "g9_host_side.npz"), **out)
+    print("g9", len(out), out["benchmark/listing"])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     if len(sys.argv) > 1:  # regenerate selected groups only, e.g. `make_golden.py g8_univariate_stats`
@@ -410,6 +541,7 @@ if __name__ == "__main__":
     g6_power_posterior()
     g7_stats()
     g8_univariate_stats()
+    g9_tuner_initstep_chainfile()
     # bundled datasets re-exported as data fixtures (inputs only)
     d = datasets(torch.float64)
     np.savez_compressed(os.path.join(HERE, "datasets.npz"), xor_x=d["xor"].x.numpy(), xor_y=d["xor"].y.numpy(),

@@ -21,6 +21,16 @@ def groups(npz):
     return out
 
 
+def subgroups(npz, prefix):
+    """{'name': {field: array}} for the keys 'prefix/name/field' of an npz."""
+    out = {}
+    for k in npz.files:
+        if k.startswith(prefix + "/"):
+            name, field = k[len(prefix) + 1:].split("/", 1)
+            out.setdefault(name, {})[field] = npz[k]
+    return out
+
+
 def spec_from(rec, dtype=np.float64, temperature=None):
     t = temperature
     if t is None and "temperature" in rec and not np.isnan(rec["temperature"]):

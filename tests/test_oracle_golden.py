@@ -145,3 +145,14 @@ def test_g8_univariate_inse_oracle_matches_reference():
             np.testing.assert_allclose(do.sample_var(x[i, :200, j]), z["var_first200"][i, j], rtol=1e-12)
     with np.testing.assert_raises(RuntimeError):
         do.inse_univariate(np.ones(10))  # a constant series never gives a positive Sig
+
+
+def test_g7_is_the_reference_published_check():
+    """G7 must be the reference's own example (examples/stats/multi_rhat.py:14, multi_ess.py: genfromtxt with no
+    skipped row, 1000 x 3 per chain): SURVEY.md section 4 quotes these two values from running it."""
+    z = load("g7_stats.npz")
+    assert z["chains"].shape == (4, 1000, 3)
+    assert float(z["multi_rhat"]) == 1.0134832973360262
+    assert float(z["multi_ess"][0]) == 564.6937234344964
+    z8 = load("g8_univariate_stats.npz")
+    assert z8["chains"].shape == (4, 1000, 3) and np.array_equal(z8["chains"], z["chains"])

@@ -24,24 +24,40 @@ theta = 0.1 * plan.philox_normal(C, seed=0, it=0)
 target, grad = plan.log_target_grad(theta)
 out = dict(accepted=plan.empty(C, dtype=torch.uint8), rate=plan.empty(C), h_cur=plan.empty(C), h_prop=plan.empty(C))
 it = 1
-for _ in range(10):
-    plan.hmc_step(theta, target, grad, step, 20, seed=1, it=it, out=out); it += 1
+IPL = int(os.environ.get("AB_IPL", "1"))  # > 1: time ey_hmc_run launches of IPL iterations with moments attached (the bench's form)
+if IPL > 1:
+    from eeyore_amd.distributed import ChainStats
+    stats = ChainStats(C, plan.P, dev)
+    stats.attach(plan)
+
+
+def draw(n=1):
+    global it
+    for _ in range(n):
+        if IPL > 1:
+            plan.hmc_run(theta, target, grad, step, 20, IPL, seed=1, it=it, out=out); it += IPL
+        else:
+            plan.hmc_step(theta, target, grad, step, 20, seed=1, it=it, out=out); it += 1
+
+
+draw(10 if IPL == 1 else 2)
 torch.cuda.synchronize()
 times = {v: [] for v in variants}
 for rnd in range(8):
     for v in variants:
         L.lib().ey_debug_set_variant(v)
-        plan.hmc_step(theta, target, grad, step, 20, seed=1, it=it, out=out); it += 1  # warm the variant
+        draw()  # warm the variant
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5 if IPL == 1 else 2
         a.record()
-        for _ in range(5):
-            plan.hmc_step(theta, target, grad, step, 20, seed=1, it=it, out=out); it += 1
+        draw(n)
         b.record()
         torch.cuda.synchronize()
-        times[v].append(a.elapsed_time(b) / 5)
+        times[v].append(a.elapsed_time(b) / (n * IPL))
 L.lib().ey_debug_set_variant(0)
 F = 1092690 * 20 * C
-print(f"chains {C} step {step} acceptance {out['accepted'].float().mean().item():.3f}")
+print(f"chains {C} step {step} acceptance {out['accepted'].float().mean().item():.3f} "
+      f"checksum {theta.double().sum().item():.10e} {target.double().sum().item():.10e}")
 for v in variants:
     t = np.array(times[v])
     print(f"variant {v}: median {np.median(t):.4f} ms  min {t.min():.4f} ms  -> {F / np.median(t) / 1e9:.1f} TFLOP/s "
