@@ -42,11 +42,49 @@ def flops_per_leapfrog_step(dims, n_rows):
     return 2 * n_rows * (2 * sum(prods) + sum(prods[1:])) + 6 * P
 
 
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("ey_mfma32.hip", "ey_common.h"):
+        with open(os.path.join(ROOT, "eeyore_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def cpu_reference_faithful(x, y, sigma, budget_s=8.0):
+    """the reference's own op sequence on torch-CPU autograd (oracle/torch_autograd_path.py:
+    nn.Linear -> sigmoid -> CrossEntropyLoss(sum) -> Normal.log_prob -> autograd.grad(create_graph=True), L + 1
+    evaluations per draw, one chain after the other), timed on this host.  fp32 as the reference's examples run
+    (examples/samplers/mlp/iris/mala_cpu_chainlist.py:30).  The reference itself cannot travel to this box."""
+    from oracle.torch_autograd_path import TorchReferencePath
+    tp = TorchReferencePath(DIMS, [1, 1, 0], 1, x, y, 0.0, sigma, dtype=torch.float32)
+    # one thread: the path is dispatch-bound (BASELINE.md section 2: ~1 ms per evaluation whatever the thread count), and
+    # torch's default of one thread per hardware thread of a 256-thread host only adds synchronisation to 32-wide products
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    cur = tp.start(0.1 * torch.randn(tp.P, dtype=torch.float32))
+    for _ in range(2):
+        cur = tp.hmc_draw(cur, STEP_SIZE, L_STEPS)
+    t0 = time.perf_counter()
+    iters = 0
+    while time.perf_counter() - t0 < budget_s:
+        cur = tp.hmc_draw(cur, STEP_SIZE, L_STEPS)
+        iters += 1
+    t = time.perf_counter() - t0
+    torch.set_num_threads(threads_before)
+    return {"value": iters * L_STEPS / t, "unit": "leapfrog-steps/sec x chains", "cores": 1,
+            "kind": "port", "sample": f"1 chain x {iters} HMC iterations (L={L_STEPS}, L+1 autograd evaluations each), f32, "
+                                      f"torch {torch.__version__} CPU autograd op for op as the reference, {t:.1f} s; chains "
+                                      f"run serially in the reference, so x chains = the same number"}
+
+
 def cpu_baseline(x, y, sigma, budget_s=12.0):
     """The C oracle (oracle/mlp_oracle.c, a port of the reference's algorithm) timed on this host's cores on a
     bounded sample of the same workload.  The oracle is the checker, never the product."""
     from oracle.c_oracle import COracle
-    cores = min(os.cpu_count() or 1, 16)
+    host_cpus = os.cpu_count() or 1
+    cores = min(host_cpus, 16)  # a one-GPU box's CPU share is 16 threads; the host count is reported beside it
     co = COracle(DIMS, [1, 1, 0], 1, x, y, 0.0, sigma, dtype=np.float32, nthreads=cores)
     rng = np.random.default_rng(0)
     P = co.P
@@ -71,8 +109,10 @@ def cpu_baseline(x, y, sigma, budget_s=12.0):
     C0 = int(cores * max(2, min(256, total // iters)))
     t = run(C0, iters)
     return {"value": C0 * iters * L_STEPS / t, "unit": "leapfrog-steps/sec x chains", "cores": cores, "kind": "port",
+            "host_cpus": host_cpus,
             "sample": f"{C0} chains x {iters} HMC iterations (L={L_STEPS}, L+1 gradient evaluations each as "
-                      f"hmc.py:104), f32, C oracle with OpenMP over chains, {t:.1f} s"}
+                      f"hmc.py:104), f32, C oracle with OpenMP over chains ({cores} of the host's {host_cpus} hardware "
+                      f"threads), {t:.1f} s"}
 
 
 def main():
@@ -84,6 +124,8 @@ def main():
     ap.add_argument("--iters-per-launch", type=int, default=25,
                     help="HMC iterations (bench steps) per kernel launch: ey_hmc_run, as HMC.run issues them; 1 = ey_hmc_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.0,
+                    help="untimed launches before the timed region, on top of --warmup, until the clocks have settled")
     ap.add_argument("--force-generic", action="store_true", help="time the generic VALU kernel instead of the MFMA one")
     args = ap.parse_args()
 
@@ -139,22 +181,35 @@ def main():
     stats.attach(plan)
     it = 1
     steps(it, args.warmup); it += args.warmup
-    if args.warmup > 1:
-        stats.summary()  # also warms the torch elementwise kernels used in the timed region
-    stats = ChainStats(C, P, dev)
-    stats.attach(plan)
+    stats.summary()  # warms the torch elementwise kernels (and the RCCL communicator) of the summary below
+    warm_stats, stats = stats, ChainStats(C, P, dev)  # the timed region's accumulators, allocated and zeroed now
+    # Clock settling, independent of --warmup: the device drops its clocks whenever it idles for a few milliseconds
+    # (the allocations and host work above) and ramps them over the first hundreds of milliseconds of load, so a 20-step
+    # run (23 ms) would be timed on the ramp.  Untimed launches, the same as the timed ones, queued without a gap; the
+    # timed region follows the last of them directly (one synchronize, one barrier, no other host work in between).
     torch.cuda.synchronize()
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_seconds:
+        for _ in range(4):
+            steps(it, ipl); it += ipl
+        torch.cuda.synchronize()
+    stats.attach(plan)  # host-side only: no device work between the warm launches and the timed ones
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     steps(it, args.steps); it += args.steps
-    summ = stats.summary() if args.steps > 1 else None  # RCCL all-reduce of [3, P] partial sums when world > 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # the gather of chain statistics (R-hat summary; one RCCL all-reduce of [3, P] partial sums when world > 1) happens
+    # once per run, not per step: timed on its own and reported in config
+    t1 = time.perf_counter()
+    summ = stats.summary() if args.steps > 1 else None
+    torch.cuda.synchronize()
+    summary_ms = 1e3 * (time.perf_counter() - t1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,6 +248,7 @@ def main():
                 "chains_per_gpu": C, "num_steps": L_STEPS, "step_size": STEP_SIZE, "rng": "in-kernel Philox4x32-10",
                 "kernel": "generic" if args.force_generic else plan.kernel,
                 "gradient_evaluations_per_iteration": L_STEPS, "iterations_per_launch": ipl,
+                "stats_summary_ms": round(summary_ms, 3),
                 "acceptance": None if summ is None else round(summ["acceptance"], 4),
                 "max_rhat": None if summ is None else round(float(summ["rhat"].max().item()), 4),
             },
@@ -210,13 +266,15 @@ def main():
         if os.path.exists(pmc) and not args.force_generic and C == CHAINS_PER_GPU:
             with open(pmc) as f:
                 pm = json.load(f)
-            if pm.get("kernel", "").startswith("k_mfma32"):
+            # only counters collected on THIS kernel source count (tools/pmc_passes.sh records its hash)
+            if pm.get("kernel", "").startswith("k_mfma32") and pm.get("kernel_source_sha256") == kernel_source_hash():
                 # per launch of `ipl` iterations (the PMC run's dispatches held pm["iterations_per_launch"] each)
                 line["roofline"]["traffic"] = ((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024.0 * ipl
                                                / pm.get("iterations_per_launch", 1))
                 line["roofline"]["traffic_source"] = pm.get("source", "profiles/pmc_latest.json")
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(xs, ys, sigma)
+            line["cpu_baseline"]["reference_faithful"] = cpu_reference_faithful(xs, ys, sigma)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -2,6 +2,7 @@
 // families.  No torch types cross this boundary.
 #include <math.h>
 
+#include <atomic>
 #include <cstring>
 #include <vector>
 
@@ -9,6 +10,20 @@
 
 static thread_local std::string g_err;
 void ey_set_error(const std::string& msg) { g_err = msg; }
+
+// labels = argmax(y, 1), first maximal index (eeyore/constants/constants.py:17)
+template <typename T>
+__global__ void k_labels(const T* __restrict__ y, int* __restrict__ labels, int64_t N, int dK) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int best = 0;
+  T bv = y[n * dK];
+  for (int j = 1; j < dK; ++j) {
+    const T v = y[n * dK + j];
+    if (v > bv) { bv = v; best = j; }
+  }
+  labels[n] = best;
+}
 
 extern "C" {
 
@@ -63,12 +78,15 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
   pl->d_x = pl->d_y = pl->d_mu = pl->d_inv_var = nullptr;
   pl->d_labels = nullptr;
   pl->d_xpack = nullptr;
+  pl->cap_N = 0;
+  pl->mfma32_data_ok = false;
   pl->d_work = nullptr;
   pl->work_bytes = 0;
   hipDeviceProp_t prop;
   EY_HIP(hipGetDeviceProperties(&prop, device_id));
   pl->n_cu = prop.multiProcessorCount;
   pl->mfma32_ok = ey_mfma32_supports(pl);
+  pl->fused16_ok = !pl->mfma32_ok && ey_fused16_supports(pl);
   *out = pl;
   return EY_OK;
 }
@@ -83,6 +101,7 @@ int ey_plan_destroy(ey_plan* pl) {
   (void)hipFree(pl->d_inv_var);
   (void)hipFree(pl->d_labels);
   (void)hipFree(pl->d_xpack);
+  (void)hipFree(pl->d_xpack16);
   ey_large_free(pl);
   delete pl;
   return EY_OK;
@@ -94,18 +113,27 @@ int ey_plan_num_params(const ey_plan* pl, int64_t* P) {
   return EY_OK;
 }
 
-int g_ey_force_large = 0;  // ey_debug_set_variant bit 4: route f32 plans through the batched-GEMM path (tests)
-static bool use_large(const ey_plan* pl) {
-  return pl->dtype == EY_F32 && (ey_large_needed(pl) || (g_ey_force_large && !pl->mfma32_ok));
+std::atomic<int> g_ey_force_large{0};  // ey_debug_set_variant bit 4: route f32 plans through the batched-GEMM path (tests)
+// the fused MFMA kernel serves this plan with the batch it currently holds
+static bool use_mfma32(const ey_plan* pl) { return pl->mfma32_ok && (pl->mfma32_data_ok || !pl->has_data); }
+// nvec: state vectors the generic kernel of the calling operation keeps in LDS (2 value/MH, 3 HMC, 4 MALA)
+static bool use_large(const ey_plan* pl, int nvec = 3) {
+  return pl->dtype == EY_F32 && (ey_large_needed(pl, nvec) || (g_ey_force_large.load() && !pl->mfma32_ok));
 }
+// the fused 16x16x4 kernels serve this plan (any batch size: their data image lives in global memory)
+static bool use_fused16(const ey_plan* pl) { return pl->fused16_ok && !g_ey_force_large.load(); }
 const char* ey_plan_kernel(const ey_plan* pl) {
   if (!pl) return "generic";
-  if (pl->mfma32_ok) return "mfma32";
+  if (use_mfma32(pl)) return "mfma32";
+  if (use_fused16(pl)) return "fused16";
   return use_large(pl) ? "bgemm" : "generic";
 }
 
 static size_t esize(const ey_plan* pl) { return pl->dtype == EY_F32 ? 4 : 8; }
 
+// Asynchronous on `stream` (a sampler calls this once per minibatch, eeyore/samplers/serial_sampler.py:41-46): the
+// plan's copies of the batch are written by device-to-device copies and two small kernels ordered on the stream; the
+// buffers only grow, so the only synchronisation is the reallocation when a batch is larger than any before it.
 int ey_plan_set_data(ey_plan* pl, const void* x, const void* y, int64_t N, void* stream) {
   if (!pl || !x || !y) EY_FAIL(EY_ERR_INVALID, "ey_plan_set_data: null argument");
   if (N < 1 || N > (1 << 24)) EY_FAIL(EY_ERR_INVALID, "ey_plan_set_data: N out of range");
@@ -114,29 +142,22 @@ int ey_plan_set_data(ey_plan* pl, const void* x, const void* y, int64_t N, void*
   EyModel& m = pl->m;
   const size_t es = esize(pl);
   const int d0 = m.dims[0], dK = m.dims[m.nl];
-  EY_HIP(hipStreamSynchronize(s));
-  (void)hipFree(pl->d_x); (void)hipFree(pl->d_y); (void)hipFree(pl->d_labels);
-  pl->d_x = pl->d_y = nullptr; pl->d_labels = nullptr;
-  EY_HIP(hipMalloc(&pl->d_x, es * N * d0));
-  EY_HIP(hipMalloc(&pl->d_y, es * N * dK));
-  EY_HIP(hipMalloc((void**)&pl->d_labels, sizeof(int) * N));
+  if (N > pl->cap_N) {
+    EY_HIP(hipDeviceSynchronize());  // launches on any stream may still read the old buffers
+    (void)hipFree(pl->d_x); (void)hipFree(pl->d_y); (void)hipFree(pl->d_labels);
+    pl->d_x = pl->d_y = nullptr; pl->d_labels = nullptr;
+    pl->cap_N = 0;
+    EY_HIP(hipMalloc(&pl->d_x, es * N * d0));
+    EY_HIP(hipMalloc(&pl->d_y, es * N * dK));
+    EY_HIP(hipMalloc((void**)&pl->d_labels, sizeof(int) * N));
+    pl->cap_N = N;
+  }
   EY_HIP(hipMemcpyAsync(pl->d_x, x, es * N * d0, hipMemcpyDeviceToDevice, s));
   EY_HIP(hipMemcpyAsync(pl->d_y, y, es * N * dK, hipMemcpyDeviceToDevice, s));
-  // labels = argmax(y, 1), first maximal index (eeyore/constants/constants.py:17)
-  std::vector<unsigned char> hy(es * N * dK);
-  EY_HIP(hipMemcpyAsync(hy.data(), y, hy.size(), hipMemcpyDeviceToHost, s));
-  EY_HIP(hipStreamSynchronize(s));
-  std::vector<int> lab(N);
-  for (int64_t n = 0; n < N; ++n) {
-    int best = 0;
-    double bv = 0;
-    for (int j = 0; j < dK; ++j) {
-      const double v = es == 4 ? (double)((const float*)hy.data())[n * dK + j] : ((const double*)hy.data())[n * dK + j];
-      if (j == 0 || v > bv) { bv = v; best = j; }
-    }
-    lab[n] = best;
-  }
-  EY_HIP(hipMemcpy(pl->d_labels, lab.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+  const dim3 grid((unsigned)((N + 255) / 256));
+  if (es == 4) hipLaunchKernelGGL(k_labels<float>, grid, dim3(256), 0, s, (const float*)pl->d_y, pl->d_labels, N, dK);
+  else hipLaunchKernelGGL(k_labels<double>, grid, dim3(256), 0, s, (const double*)pl->d_y, pl->d_labels, N, dK);
+  EY_HIP(hipGetLastError());
   m.N = (int)N;
   m.x = pl->d_x;
   m.y = pl->d_y;
@@ -144,6 +165,10 @@ int ey_plan_set_data(ey_plan* pl, const void* x, const void* y, int64_t N, void*
   pl->has_data = true;
   if (pl->mfma32_ok) {
     int rc = ey_mfma32_set_data(pl, s);
+    if (rc) return rc;
+  }
+  if (pl->fused16_ok) {
+    int rc = ey_fused16_set_data(pl, s);
     if (rc) return rc;
   }
   return EY_OK;
@@ -228,6 +253,7 @@ int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, v
   if (!theta) EY_FAIL(EY_ERR_INVALID, "ey_log_target: null theta");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
+  if (use_fused16(pl)) return ey_fused16_log_target(pl, theta, temp, C, log_lik, log_prior, nullptr, nullptr, (hipStream_t)stream);
   if (use_large(pl)) return ey_large_log_target(pl, theta, temp, C, log_lik, log_prior, nullptr, nullptr, (hipStream_t)stream);
   return ey_generic_log_target(pl, theta, temp, C, log_lik, log_prior, nullptr, nullptr, (hipStream_t)stream);
 }
@@ -249,7 +275,8 @@ int ey_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t
   if (!theta || !target || !grad) EY_FAIL(EY_ERR_INVALID, "ey_log_target_grad: null argument");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
-  if (pl->mfma32_ok) return ey_mfma32_log_target_grad(pl, theta, temp, C, target, grad, (hipStream_t)stream);
+  if (use_mfma32(pl)) return ey_mfma32_log_target_grad(pl, theta, temp, C, target, grad, (hipStream_t)stream);
+  if (use_fused16(pl)) return ey_fused16_log_target(pl, theta, temp, C, nullptr, nullptr, target, grad, (hipStream_t)stream);
   if (use_large(pl)) return ey_large_log_target(pl, theta, temp, C, nullptr, nullptr, target, grad, (hipStream_t)stream);
   return ey_generic_log_target(pl, theta, temp, C, nullptr, nullptr, target, grad, (hipStream_t)stream);
 }
@@ -265,10 +292,13 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
   if (C == 0) return EY_OK;
   if ((rc = moments_check(pl, C, "ey_hmc_step"))) return rc;
   EY_HIP(hipSetDevice(pl->device));
-  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))  // accumulates attached moments itself
+  if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC))  // accumulates attached moments itself
     return ey_mfma32_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                          accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
-  if (use_large(pl))
+  if (use_fused16(pl) && !(flags & EY_FORCE_GENERIC))
+    rc = ey_fused16_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+                        accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
+  else if (use_large(pl))
     rc = ey_large_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                       accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
   else
@@ -296,17 +326,23 @@ int ey_hmc_run(ey_plan* pl, void* theta, void* target, void* grad, double step, 
   EY_HIP(hipSetDevice(pl->device));
   hipStream_t s = (hipStream_t)stream;
   EyRun run = {n_iters, samples, targets, accepted_rec, (int*)accept_count};
-  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+  if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
                          flags, accepted, nullptr, nullptr, nullptr, s, &run);
-  if (!use_large(pl)) {
-    rc = ey_generic_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
-                        flags, accepted, nullptr, nullptr, nullptr, s, &run);
-    if (rc != EY_OK || !pl->mom_s1) return rc;
-    // the generic kernels do not fuse the moments: replay them from the recorded samples when there are any
-    if (n_iters > 1 && (!samples || !accepted_rec))
+  const bool f16 = use_fused16(pl) && !(flags & EY_FORCE_GENERIC);
+  if (f16 || !use_large(pl)) {
+    // the generic kernels do not fuse the moments: they are replayed from the recorded samples, which must then exist
+    // (checked BEFORE the launch: a failure must leave the chains where they were)
+    if (pl->mom_s1 && n_iters > 1 && (!samples || !accepted_rec))
       EY_FAIL(EY_ERR_UNSUPPORTED, "ey_hmc_run: attached moments with n_iters > 1 need the samples and accepted records "
                                   "on this kernel family");
+    if (f16)
+      rc = ey_fused16_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
+                          flags, accepted, nullptr, nullptr, nullptr, s, &run);
+    else
+      rc = ey_generic_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter,
+                          chain_offset, flags, accepted, nullptr, nullptr, nullptr, s, &run);
+    if (rc != EY_OK || !pl->mom_s1) return rc;
     const size_t es = esize(pl);
     for (int it = 0; it < n_iters; ++it) {
       const void* th_it = n_iters > 1 ? (const void*)((const char*)samples + (size_t)it * C * pl->m.P * es) : theta;
@@ -346,20 +382,26 @@ int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* 
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_leapfrog: num_steps must be >= 1");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
-  if (pl->mfma32_ok) return ey_mfma32_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
+  if (use_mfma32(pl)) return ey_mfma32_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
+  if (use_fused16(pl)) return ey_fused16_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
   if (use_large(pl)) return ey_large_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
   return ey_generic_leapfrog(pl, theta, p, step, step_vec, L, temp, C, target, grad, (hipStream_t)stream);
 }
 
 // the kernel families that do not fuse attached moments replay them from the per-iteration records of a *_run call
+static int moments_replay_check(const ey_plan* pl, const EyRun* run, const char* who) {
+  if (pl->mom_s1 && run && run->n_iters > 1 && (!run->samples || !run->accepted))
+    EY_FAIL(EY_ERR_UNSUPPORTED, std::string(who) + ": attached moments with n_iters > 1 need the samples and accepted "
+                                                   "records on this kernel family");
+  return EY_OK;
+}
 static int moments_replay(ey_plan* pl, const EyRun* run, const void* theta, const void* accepted, int64_t C,
                           const char* who, void* stream) {
   if (!pl->mom_s1) return EY_OK;
   if (!run || run->n_iters == 1) return ey_stats_update(theta, accepted, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2,
                                                         pl->mom_acc, stream);
-  if (!run->samples || !run->accepted)
-    EY_FAIL(EY_ERR_UNSUPPORTED, std::string(who) + ": attached moments with n_iters > 1 need the samples and accepted "
-                                                   "records on this kernel family");
+  int rcc = moments_replay_check(pl, run, who);
+  if (rcc) return rcc;
   const size_t es = esize(pl);
   for (int it = 0; it < run->n_iters; ++it) {
     int rc = ey_stats_update((const char*)run->samples + (size_t)it * C * pl->m.P * es,
@@ -400,12 +442,16 @@ static int mala_impl(ey_plan* pl, void* theta, void* target, void* grad, const v
   if ((rc = moments_check(pl, C, who))) return rc;
   EY_HIP(hipSetDevice(pl->device));
   hipStream_t s = (hipStream_t)stream;
-  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+  if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
                           log_rate, s, run);
-  if (!use_large(pl)) {
-    rc = ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
-                         log_rate, s, run);
+  const bool f16 = use_fused16(pl) && !(flags & EY_FORCE_GENERIC);
+  if (f16 || !use_large(pl, 4)) {  // k_mala carves four state vectors from LDS
+    if ((rc = moments_replay_check(pl, run, who))) return rc;  // before the launch: a failure leaves the chains alone
+    rc = f16 ? ey_fused16_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
+                               log_rate, s, run)
+             : ey_generic_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
+                               log_rate, s, run);
     return rc ? rc : moments_replay(pl, run, theta, accepted, C, who, stream);
   }
   const int n = run ? run->n_iters : 1;
@@ -431,10 +477,13 @@ static int mh_impl(ey_plan* pl, void* theta, void* target, const void* z, const 
   if ((rc = moments_check(pl, C, who))) return rc;
   EY_HIP(hipSetDevice(pl->device));
   hipStream_t s = (hipStream_t)stream;
-  if (pl->mfma32_ok && !(flags & EY_FORCE_GENERIC))
+  if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run);
-  if (!use_large(pl)) {
-    rc = ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run);
+  const bool f16 = use_fused16(pl) && !(flags & EY_FORCE_GENERIC);
+  if (f16 || !use_large(pl, 2)) {
+    if ((rc = moments_replay_check(pl, run, who))) return rc;
+    rc = f16 ? ey_fused16_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run)
+             : ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run);
     return rc ? rc : moments_replay(pl, run, theta, accepted, C, who, stream);
   }
   const int n = run ? run->n_iters : 1;

@@ -62,8 +62,14 @@ struct ey_plan {
   int64_t mom_C = 0;
   int* d_labels;
   // mfma32 path (4-32-32-3-like models, f32): padded/packed data image
-  bool mfma32_ok;
+  bool mfma32_ok;        // the model is one the fused kernel serves
+  bool mfma32_data_ok;   // ... and the current batch fits its LDS image (recomputed by every ey_plan_set_data)
   void* d_xpack;
+  int64_t cap_N;         // rows the data buffers below were allocated for (they only grow)
+  // fused16 path (d0-H-H-dK with H in {16, 32, 64}, f32 and f64): operand-order data image in global memory
+  bool fused16_ok = false;
+  void* d_xpack16 = nullptr;
+  size_t xpack16_bytes = 0;
   int n_cu;
   // layerwise batched-GEMM path for models whose parameters do not fit LDS (ey_large.hip): workspace it owns
   void* d_work;
@@ -97,7 +103,7 @@ int ey_generic_mh(ey_plan* pl, void* theta, void* target, const void* z, const v
                   void* log_rate, hipStream_t s, const EyRun* run = nullptr);
 
 // layerwise batched-GEMM kernels for large models, f32 (ey_large.hip)
-bool ey_large_needed(const ey_plan* pl);   // true when the generic kernels cannot hold the model in LDS
+bool ey_large_needed(const ey_plan* pl, int nvec = 3);  // true when the generic kernels cannot hold the model in LDS
 int ey_large_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                         void* target, void* grad, hipStream_t s);
 int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
@@ -129,6 +135,24 @@ int ey_mfma32_mh(ey_plan* pl, void* theta, void* target, const void* z, const vo
                  void* log_rate, hipStream_t s, const EyRun* run = nullptr);
 int ey_mfma32_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                        int64_t C, void* target, void* grad, hipStream_t s);
+
+// fused kernels on 16x16x4 tiles (ey_fused16.hip)
+bool ey_fused16_supports(const ey_plan* pl);
+int ey_fused16_set_data(ey_plan* pl, hipStream_t s);
+int ey_fused16_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                   hipStream_t s, const EyRun* run = nullptr);
+int ey_fused16_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                    const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                    uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run = nullptr);
+int ey_fused16_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
+                  const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
+                  void* log_rate, hipStream_t s, const EyRun* run = nullptr);
+int ey_fused16_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+                          void* target, void* grad, hipStream_t s);
+int ey_fused16_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                        int64_t C, void* target, void* grad, hipStream_t s);
 
 // ----------------------------------------------------------------------------------------------- Philox4x32-10
 // Counter-based generator (Salmon et al. 2011).  One call per (element, chain, iteration, stream): the value a

@@ -1,0 +1,917 @@
+// Fused trajectory kernels on 16x16x4 matrix-core tiles for three-layer MLPs d0-H-H-dK with H in {16, 32, 64},
+// d0 <= 8, dK <= 4, in f32 (v_mfma_f32_16x16x4_f32) and f64 (v_mfma_f64_16x16x4_f64): the models the reference
+// builds besides the headline 4-32-32-3 (eeyore/models/mlp.py:9-19,37-50 takes any dims; its own tests are
+// BCE nets, tests/test_binary_classif_mlp2321_log_lik.py) and the reference's default dtype (eeyore/models/model.py:7).
+// CE-sum on logits or BCE-sum on a sigmoid output (eeyore/constants/constants.py:15-18), hidden activations sigmoid /
+// tanh / relu, every layer with a bias.  Same structure as ey_mfma32.hip: one wavefront per chain in a persistent
+// workgroup per CU, the whole draw inside one launch, theta and the gradient in registers, the momentum in LDS.
+//
+// Reference semantics restated (paths relative to papamarkou/eeyore): MLP.forward eeyore/models/mlp.py:45-50,
+// losses eeyore/constants/constants.py:15-18 and eeyore/stats/loss.py:1-11 (naive BCE logs kept), log_target
+// eeyore/models/bayesian_model.py:30-56, gradient eeyore/models/log_target_model.py:15-23 (autograd there),
+// HMC.leapfrog / draw eeyore/samplers/hmc.py:100-156, MALA.draw eeyore/samplers/mala.py:46-82, MetropolisHastings.draw
+// eeyore/samplers/metropolis_hastings.py:41-73.
+//
+// Tiles.  Lane l = (c = l & 15, g = l >> 4).  One 16x16x4 product D += A B takes A[i = c][k = g] and B[k = g][j = c]
+// from lane (c, g) and leaves D[i = fi(g, r)][j = c] in register r, where the two dtypes differ (measured with
+// tools/mfma_probe.hip):  fi(g, r) = 4g + r for v_mfma_f32_16x16x4_f32,  4r + g for v_mfma_f64_16x16x4_f64.
+//   "T tile" m of Q[feature][row]: register r of lane (c, g) = Q[16m + fi(g, r)][row c]    (an accumulator as it stands)
+//   "U tile" n of Q             : register r of lane (c, g) = Q[16n + c][row fi(g, r)]     (read back transposed from LDS)
+// Every layer is computed transposed (H_l^T = W_l H_{l-1}^T), so a T tile is directly the B operand of the next layer's
+// product (k-step (m, r) gives k-slot g the feature 16m + fi(g, r)) and the A operand of the untransposed
+// dH0 = delta1 W1, whose accumulator is then a U tile; the products that contract over rows (dW_l) take U tiles, one
+// LDS round trip each: a T tile is stored with its row c at column perm(c) of the buffer (perm(4g + r) = fi(g, r), an
+// involution), so that the four rows fi(g, 0..3) of a U tile are one aligned vector read.  Skinny dimensions (d0, dK)
+// are padded to one 16-wide tile with zeros in the staged operand images.
+//
+// Canonical registers of theta / gradient (the D layouts of the weight-gradient products), lane (c, g), f = fi(g, r):
+//   w1[(mo MT + n) 4 + r] = W1[16mo + f][16n + c]      w0[4m + r] = W0[16m + f][c]   (c < d0)
+//   w2[4n + r] = W2[f][16n + c]   (f < dK)             b1[mo] = b1[16mo + c], b0[m] = b0[16m + c]   b2[o] uniform
+#include <algorithm>
+
+#include "ey_common.h"
+
+enum { F16_HMC = 0, F16_GRAD = 1, F16_LEAPFROG = 2, F16_MALA = 3, F16_MH = 4 };
+#define F16_TS 20  // row stride of the transpose buffers: 16 rows + 4 (keeps the 4-element reads aligned)
+
+template <typename T>
+struct F16Args {
+  int d0, dK, act0, act1, lik, P;
+  int iW0, iB0, iW1, iB1, iW2, iB2;  // offsets of the layers in theta (weights row-major, then the bias, per layer)
+  const T* xpack;                    // [ntiles][xt] operand-order data image (k_f16_pack)
+  int ntiles, ks0, xt;
+  const T* mu;
+  const T* inv_var;
+  T prior_const;
+  int64_t C;
+  T* theta;
+  T* target;
+  T* grad;
+  const T* p0;   // HMC: momentum [C,P]; MALA / MH: standard normals [C,P]; null => Philox
+  T* pio;        // LEAPFROG: momentum in/out
+  const T* u;
+  T step, sqrt_step;
+  const T* scale;  // MH proposal scale [P]
+  const T* step_vec;
+  int L;
+  const T* temp;
+  uint64_t seed, iter, chain_offset;
+  int recompute, mode;
+  unsigned char* accepted;
+  T *rate, *hcur, *hprop;
+  int n_iters;
+  T* rec_samples;
+  T* rec_targets;
+  unsigned char* rec_accepted;
+  int* accept_count;
+};
+
+template <typename T>
+struct V4 {
+  typedef T type __attribute__((ext_vector_type(4)));
+};
+template <typename T>
+using v4 = typename V4<T>::type;
+
+template <typename T>
+__device__ __forceinline__ v4<T> mfma16(T a, T b, v4<T> c) {
+  if constexpr (sizeof(T) == 8) return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// D-register layout of the two 16x16x4 instructions (see the header)
+template <typename T>
+struct Lay {
+  static __host__ __device__ __forceinline__ int fi(int g, int r) { return sizeof(T) == 8 ? 4 * r + g : 4 * g + r; }
+  static __host__ __device__ __forceinline__ int perm(int j) { return fi(j >> 2, j & 3); }  // position 4g + r <-> fi(g, r)
+};
+
+template <typename T>
+struct Nm;
+template <>
+struct Nm<float> {
+  static __device__ __forceinline__ float exp(float v) { return expf(v); }
+  static __device__ __forceinline__ float log(float v) { return logf(v); }
+  static __device__ __forceinline__ float tanh(float v) { return tanhf(v); }
+  static __device__ __forceinline__ float sqrt(float v) { return sqrtf(v); }
+};
+template <>
+struct Nm<double> {
+  static __device__ __forceinline__ double exp(double v) { return ::exp(v); }
+  static __device__ __forceinline__ double log(double v) { return ::log(v); }
+  static __device__ __forceinline__ double tanh(double v) { return ::tanh(v); }
+  static __device__ __forceinline__ double sqrt(double v) { return ::sqrt(v); }
+};
+// the same formulas as the generic kernels (ey_generic.hip): both families must agree with the oracle
+template <typename T>
+__device__ __forceinline__ T f16_act(int code, T g) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return T(1) / (T(1) + Nm<T>::exp(-g));
+    case EY_ACT_TANH: return Nm<T>::tanh(g);
+    case EY_ACT_RELU: return g > T(0) ? g : T(0);
+    default: return g;
+  }
+}
+template <typename T>
+__device__ __forceinline__ T f16_dact(int code, T h) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return h * (T(1) - h);
+    case EY_ACT_TANH: return T(1) - h * h;
+    case EY_ACT_RELU: return h > T(0) ? T(1) : T(0);
+    default: return T(1);
+  }
+}
+template <typename T>
+__device__ __forceinline__ T f16_wsum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the four lane groups g (lanes c, c + 16, c + 32, c + 48): every lane gets the total of its column c
+template <typename T>
+__device__ __forceinline__ T f16_gsum(T v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ void f16_fence() {
+  // LDS operations of one wave execute in issue order; this only stops the compiler from moving them
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int H>
+struct F16Cfg {
+  static constexpr int MT = H / 16;
+  static constexpr int NW1 = MT * MT * 4, NW0 = MT * 4, NW2 = MT * 4;
+  static constexpr int S_W0 = NW1, S_W2 = S_W0 + NW0, S_B1 = S_W2 + NW2, S_B0 = S_B1 + MT, S_B2 = S_B0 + MT;
+  static constexpr int NREG = S_B2 + 4;
+  // per-wave LDS carve, in elements
+  static constexpr int O_W1A = 0;                       // [(mo MT + m) 4 + r][lane]: A operands of F1
+  static constexpr int O_TB0 = H * H;                   // [H][TS] transpose buffer: H1, then delta1
+  static constexpr int O_TB1 = O_TB0 + H * F16_TS;      // [H][TS] transpose buffer: H0
+  static constexpr int O_W0A = O_TB1 + H * F16_TS;      // [m][s < 2][lane]: A operands of F0
+  static constexpr int O_W2A = O_W0A + MT * 2 * 64;     // [m][r][lane]: A operands of the logits
+  static constexpr int O_W2T = O_W2A + MT * 4 * 64;     // [m][lane]: A operands of dH1
+  static constexpr int O_B0 = O_W2T + MT * 64;          // [H]
+  static constexpr int O_B1 = O_B0 + H;                 // [H]
+  static constexpr int O_D2 = O_B1 + H;                 // [4][16] delta2[o][row]
+  static constexpr int O_P = O_D2 + 64;                 // [P]: the momentum (HMC) / the standard normals (MALA, MH)
+  static constexpr int PMAX = ((H * H + 14 * H + 4) + 3) & ~3;  // d0 <= 8, dK <= 4
+  static constexpr int WAVE_ELEMS = O_P + PMAX;
+};
+
+struct F16Slot {
+  int idx;
+  bool valid, counts;
+};
+// canonical element k of lane (c, g): its index in theta, whether this lane holds anything there, and whether this
+// lane's copy is the one that enters sums over parameters
+template <int H, typename T>
+__device__ __forceinline__ F16Slot f16_slot(int k, const F16Args<T>& a, int c, int g, int lane) {
+  typedef F16Cfg<H> K;
+  if (k < K::S_W0) {
+    const int r = k & 3, n = (k >> 2) % K::MT, mo = (k >> 2) / K::MT;
+    return {a.iW1 + (16 * mo + Lay<T>::fi(g, r)) * H + 16 * n + c, true, true};
+  }
+  if (k < K::S_W2) {
+    const int kk = k - K::S_W0, r = kk & 3, m = kk >> 2;
+    const bool v = c < a.d0;
+    return {a.iW0 + (16 * m + Lay<T>::fi(g, r)) * a.d0 + c, v, v};
+  }
+  if (k < K::S_B1) {
+    const int kk = k - K::S_W2, r = kk & 3, n = kk >> 2;
+    const bool v = Lay<T>::fi(g, r) < a.dK;
+    return {a.iW2 + Lay<T>::fi(g, r) * H + 16 * n + c, v, v};
+  }
+  if (k < K::S_B0) return {a.iB1 + 16 * (k - K::S_B1) + c, true, g == 0};
+  if (k < K::S_B2) return {a.iB0 + 16 * (k - K::S_B0) + c, true, g == 0};
+  const int o = k - K::S_B2;
+  return {a.iB2 + o, o < a.dK, lane == 0 && o < a.dK};
+}
+#define F16_EACH(k) _Pragma("unroll") for (int k = 0; k < K::NREG; ++k)
+
+// stage the operand images of the position `th` in this wave's LDS region (the zero padding of the images was
+// written once at kernel start and is never overwritten).  An element W[out][in] this lane holds goes where the lane
+// that feeds it to the product will read it: A operand lane (i & 15, k-slot), one image row of 64 per k-step.
+template <typename T, int H>
+__device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>::NREG], const F16Args<T>& a, int c, int g) {
+  typedef F16Cfg<H> K;
+  typedef Lay<T> L;
+  // the k-step register rk and k-slot gk at which input feature (16n +) c enters a product whose B operand is a T tile
+  const int pc = L::perm(c), rk = pc & 3, gk = pc >> 2;
+#pragma unroll
+  for (int k = 0; k < K::NW1; ++k) {  // W1[16mo + fi(g, r)][16n + c]: A operand of F1, k-step (n, rk)
+    const int r = k & 3, n = (k >> 2) % K::MT, mo = (k >> 2) / K::MT;
+    lw[K::O_W1A + ((mo * K::MT + n) * 4 + rk) * 64 + L::fi(g, r) + 16 * gk] = th[k];
+  }
+  if (c < a.d0) {
+#pragma unroll
+    for (int k = 0; k < K::NW0; ++k) {  // W0[16m + fi(g, r)][c]: A operand of F0, k-step c >> 2, k-slot c & 3 (as k_f16_pack lays x out)
+      const int r = k & 3, m = k >> 2;
+      lw[K::O_W0A + (m * 2 + (c >> 2)) * 64 + L::fi(g, r) + 16 * (c & 3)] = th[K::S_W0 + k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K::NW2; ++k) {  // W2[o = fi(g, r)][16n + c]
+    const int r = k & 3, n = k >> 2, o = L::fi(g, r);
+    if (o < a.dK) {
+      lw[K::O_W2A + (n * 4 + rk) * 64 + o + 16 * gk] = th[K::S_W2 + k];  // logits: A lane (o, gk), k-step (n, rk)
+      lw[K::O_W2T + n * 64 + c + 16 * o] = th[K::S_W2 + k];              // dH1: A lane (f & 15, k-slot o)
+    }
+  }
+  if (g == 0) {  // bias images in the order a vector read at 4g hands out the features fi(g, 0..3)
+#pragma unroll
+    for (int m = 0; m < K::MT; ++m) {
+      lw[K::O_B1 + 16 * m + pc] = th[K::S_B1 + m];
+      lw[K::O_B0 + 16 * m + pc] = th[K::S_B0 + m];
+    }
+  }
+  f16_fence();
+}
+
+template <typename T>
+__device__ __forceinline__ v4<T> f16_ld4(const T* p) {
+  return *reinterpret_cast<const v4<T>*>(p);
+}
+
+// log-target and gradient of the position whose images are staged in lw; returns the (tempered) log-target.
+// GRAD (wave-uniform) = false: the value only (random-walk MH).  Inlined at its three call sites: theta and the gradient
+// are register arrays, which a call would force into scratch memory.
+template <typename T, int H>
+__device__ __forceinline__ T f16_eval(const F16Args<T>& a, T* lw, const T (&th)[F16Cfg<H>::NREG],
+                                      T (&gr)[F16Cfg<H>::NREG], const bool GRAD, bool has_temp, T temp, int c, int g,
+                                      int lane, T* lik_out = nullptr, T* prior_out = nullptr) {
+  typedef F16Cfg<H> K;
+  typedef Lay<T> L;
+  constexpr int MT = K::MT;
+  const int pc = L::perm(c);  // this lane's row c sits at column pc of the transpose buffers
+  v4<T> dW1[MT * MT], dW0[MT], dW2[MT];
+  T db1[MT], db0[MT], db2[4] = {T(0), T(0), T(0), T(0)}, lik = T(0);
+#pragma unroll
+  for (int i = 0; i < MT * MT; ++i) dW1[i] = v4<T>{0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    dW0[i] = v4<T>{0, 0, 0, 0};
+    dW2[i] = v4<T>{0, 0, 0, 0};
+    db1[i] = db0[i] = T(0);
+  }
+  const T b2v[4] = {th[K::S_B2], th[K::S_B2 + 1], th[K::S_B2 + 2], th[K::S_B2 + 3]};
+  const int off_xu = a.ks0 * 64, off_lab = off_xu + 256, off_y = off_lab + 64;
+#pragma unroll 1
+  for (int t = 0; t < a.ntiles; ++t) {
+    const T* xt = a.xpack + (size_t)t * a.xt;
+    T xb[2];
+    xb[0] = xt[lane];
+    xb[1] = a.ks0 > 1 ? xt[64 + lane] : T(0);
+    const int lab = (int)xt[off_lab + c];  // -1 marks a padding row
+    const bool valid = lab >= 0;
+    // ---- F0: H0^T = act0(W0 X^T + b0)                                  (mlp.py:45-50)
+    v4<T> H0[MT], H1[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      v4<T> acc = f16_ld4(lw + K::O_B0 + 16 * m + 4 * g);
+      acc = mfma16<T>(lw[K::O_W0A + (m * 2) * 64 + lane], xb[0], acc);
+      if (a.ks0 > 1) acc = mfma16<T>(lw[K::O_W0A + (m * 2 + 1) * 64 + lane], xb[1], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H0[m][r] = f16_act<T>(a.act0, acc[r]);
+      if (GRAD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lw[K::O_TB1 + (16 * m + L::fi(g, r)) * F16_TS + pc] = H0[m][r];
+      }
+    }
+    // ---- F1: H1^T = act1(W1 H0^T + b1)
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) {
+      v4<T> acc = f16_ld4(lw + K::O_B1 + 16 * mo + 4 * g);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16<T>(lw[K::O_W1A + ((mo * MT + m) * 4 + r) * 64 + lane], H0[m][r], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H1[mo][r] = f16_act<T>(a.act1, acc[r]);
+      if (GRAD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lw[K::O_TB0 + (16 * mo + L::fi(g, r)) * F16_TS + pc] = H1[mo][r];
+      }
+    }
+    // ---- output layer: logits[o][row c] = W2 H1^T + b2 comes out in register r of lane group g with fi(g, r) = o;
+    // every lane then fetches the dK logits of its row c, so all four groups carry the same softmax
+    v4<T> lacc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = L::fi(g, r);  // < 4 only for one (g, r) pair per output: a select, not an indexed read
+      lacc[r] = o >= a.dK ? T(0) : (o == 0 ? b2v[0] : (o == 1 ? b2v[1] : (o == 2 ? b2v[2] : b2v[3])));
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lacc = mfma16<T>(lw[K::O_W2A + (m * 4 + r) * 64 + lane], H1[m][r], lacc);
+    T lg[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {  // o = fi(go, ro): f32 (0, o), f64 (o, 0)
+      const int go = sizeof(T) == 8 ? o : 0, ro = sizeof(T) == 8 ? 0 : o;
+      lg[o] = __shfl(lacc[ro], c + 16 * go, 64);
+    }
+    // ---- log-likelihood and the output delta                                (constants.py:15-18, loss.py:1-11)
+    T d2[4] = {T(0), T(0), T(0), T(0)};
+    const bool mine = valid && g == 0;
+    if (a.lik == EY_LIK_CE_SUM) {
+      T mx = lg[0];
+#pragma unroll
+      for (int o = 1; o < 4; ++o)
+        if (o < a.dK) mx = fmax(mx, lg[o]);
+      T ssum = T(0), llab = T(0);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < a.dK) {
+          ssum += Nm<T>::exp(lg[o] - mx);
+          if (o == lab) llab = lg[o];
+        }
+      if (mine) lik += llab - (mx + Nm<T>::log(ssum));
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < a.dK && mine) d2[o] = (o == lab ? T(1) : T(0)) - Nm<T>::exp(lg[o] - mx) / ssum;
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < a.dK) {
+          const T pr = f16_act<T>(EY_ACT_SIGMOID, lg[o]);
+          const T yy = xt[off_y + o * 16 + c];
+          // naive logs exactly as eeyore/stats/loss.py:2 (NaN once a sigmoid saturates)
+          const T term = Nm<T>::log(pr) * yy + Nm<T>::log(T(1) - pr) * (T(1) - yy);
+          if (mine) {
+            lik += term;
+            d2[o] = (yy / pr - (T(1) - yy) / (T(1) - pr)) * f16_dact<T>(EY_ACT_SIGMOID, pr);
+          }
+        }
+    }
+    if (!GRAD) continue;
+    if (g == 0) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        db2[o] += d2[o];
+        lw[K::O_D2 + o * 16 + pc] = d2[o];
+      }
+    }
+    f16_fence();
+    // ---- dH1^T = W2^T delta2^T, delta1 = dH1 * act1'(H1)
+    T d2all[4];  // the row's delta2 in every lane group (d2 itself is masked to g = 0 for the sums)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) d2all[o] = __shfl(d2[o], c, 64);
+    const T d2b = g == 0 ? d2all[0] : (g == 1 ? d2all[1] : (g == 2 ? d2all[2] : d2all[3]));  // delta2[row c][o = g]
+    v4<T> D1[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      D1[m] = mfma16<T>(lw[K::O_W2T + m * 64 + lane], d2b, v4<T>{0, 0, 0, 0});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D1[m][r] *= f16_dact<T>(a.act1, H1[m][r]);
+    }
+    // ---- dW2[o][f] += sum_n delta2[n][o] H1[n][f]           (contracts over rows: U tiles)
+    {
+      const v4<T> d2u = f16_ld4(lw + K::O_D2 + (c & 3) * 16 + 4 * g);  // delta2[rows fi(g, .)][o = c] for c < 4 (zero for o >= dK)
+#pragma unroll
+      for (int n = 0; n < MT; ++n) {
+        const v4<T> h1u = f16_ld4(lw + K::O_TB0 + (16 * n + c) * F16_TS + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dW2[n] = mfma16<T>(c < 4 ? d2u[r] : T(0), h1u[r], dW2[n]);
+      }
+    }
+    f16_fence();  // H1^T has been read: its buffer takes delta1^T
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lw[K::O_TB0 + (16 * m + L::fi(g, r)) * F16_TS + pc] = D1[m][r];
+    f16_fence();
+    // ---- dH0 = delta1 W1 untransposed (A = delta1 T tiles with M = rows, B = theta's own W1 registers): U tiles
+    v4<T> h0u[MT], d0u[MT];
+#pragma unroll
+    for (int n = 0; n < MT; ++n) {
+      h0u[n] = f16_ld4(lw + K::O_TB1 + (16 * n + c) * F16_TS + 4 * g);
+      v4<T> acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16<T>(D1[m][r], th[(m * MT + n) * 4 + r], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d0u[n][r] = acc[r] * f16_dact<T>(a.act0, h0u[n][r]);
+    }
+    // ---- dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) {
+      const v4<T> d1u = f16_ld4(lw + K::O_TB0 + (16 * mo + c) * F16_TS + 4 * g);
+#pragma unroll
+      for (int n = 0; n < MT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dW1[mo * MT + n] = mfma16<T>(d1u[r], h0u[n][r], dW1[mo * MT + n]);
+      db1[mo] += (d1u[0] + d1u[1]) + (d1u[2] + d1u[3]);
+    }
+    // ---- dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
+    {
+      T xu[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xu[r] = xt[off_xu + r * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dW0[m] = mfma16<T>(d0u[m][r], xu[r], dW0[m]);
+        db0[m] += (d0u[m][0] + d0u[m][1]) + (d0u[m][2] + d0u[m][3]);
+      }
+    }
+    f16_fence();
+  }
+  // ---- gather the gradient into the canonical registers
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < MT * MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gr[i * 4 + r] = dW1[i][r];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gr[K::S_W0 + m * 4 + r] = dW0[m][r];
+        gr[K::S_W2 + m * 4 + r] = dW2[m][r];
+      }
+      gr[K::S_B1 + m] = f16_gsum(db1[m]);
+      gr[K::S_B0 + m] = f16_gsum(db0[m]);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) gr[K::S_B2 + o] = f16_wsum(db2[o]);
+  }
+  // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
+  T qsum = T(0);
+  F16_EACH(k) {
+    const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+    if (s.valid) {
+      const T d = th[k] - a.mu[s.idx];
+      const T iv = a.inv_var[s.idx];
+      if (s.counts) qsum += d * d * iv;
+      if (GRAD) {
+        T gn = gr[k] - d * iv;
+        if (has_temp) gn *= temp;
+        gr[k] = gn;
+      }
+    } else if (GRAD) {
+      gr[k] = T(0);
+    }
+  }
+  lik = f16_wsum(lik);
+  T prior = a.prior_const - T(0.5) * f16_wsum(qsum);
+  if (has_temp) { lik *= temp; prior *= temp; }
+  if (lik_out) *lik_out = lik;
+  if (prior_out) *prior_out = prior;
+  return lik + prior;
+}
+
+// One chain of one launch: everything between reading theta and writing the accepted state back.
+template <typename T, int H>
+__device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const int64_t chain, const int it, const int c,
+                                              const int g, const int lane) {
+  typedef F16Cfg<H> K;
+  // later iterations of one launch read what this wave's lanes wrote at the end of the previous one
+  if (it > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const uint64_t iter = a.iter + (uint64_t)it;
+  const int P = a.P;
+  T* thg = a.theta + chain * P;
+  T* grg = a.grad + chain * P;
+  T* lp = lw + K::O_P;  // the momentum / the normals, indexed like theta
+  const bool has_temp = a.temp != nullptr;
+  const T temp = has_temp ? a.temp[chain] : T(1);
+  const T eps = a.step_vec ? a.step_vec[chain] : a.step;
+  const int mode = a.mode;
+
+  T th[K::NREG], gr[K::NREG];
+  F16_EACH(k) {
+    const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+    th[k] = s.valid ? thg[s.idx] : T(0);
+    gr[k] = T(0);
+  }
+
+  if (mode == F16_GRAD) {
+    f16_write_images<T, H>(lw, th, a, c, g);
+    T lik, prior;
+    const T t = f16_eval<T, H>(a, lw, th, gr, a.grad != nullptr, has_temp, temp, c, g, lane, &lik, &prior);
+    if (a.grad) {
+      F16_EACH(k) {
+        const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+        if (s.counts) grg[s.idx] = gr[k];
+      }
+    }
+    if (lane == 0) {
+      if (a.target) a.target[chain] = t;
+      if (a.hcur) a.hcur[chain] = lik;     // ey_log_target: the two parts
+      if (a.hprop) a.hprop[chain] = prior;
+    }
+    return;
+  }
+
+  // the chain's N(0,1) stream (or the caller's) into LDS, indexed like theta
+  const bool needs_normals = mode == F16_HMC || mode == F16_MALA || mode == F16_MH;
+  if (needs_normals) {
+    if (a.p0) {
+      const T* src = a.p0 + chain * P;
+      for (int i = lane; i < P; i += 64) lp[i] = src[i];
+    } else {
+      const EyRng rn = ey_rng_make(a.seed, a.chain_offset + (uint64_t)chain, iter, EY_STREAM_NORMAL);
+      for (int b = lane; 4 * b < P; b += 64) {
+        T o[4];
+        ey_rng_normal4<T>(rn, (uint32_t)b, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * b + j < P) lp[4 * b + j] = o[j];
+      }
+    }
+    f16_fence();
+  }
+
+  if (mode == F16_MALA || mode == F16_MH) {
+    // MALA.draw (mala.py:46-82) / MetropolisHastings.draw (metropolis_hastings.py:41-73): one evaluation at the proposal
+    const T sc = a.step_vec ? Nm<T>::sqrt(eps) : a.sqrt_step;  // scale = sqrt(step), mala.py:39
+    T pr[K::NREG], gp[K::NREG];
+    T qf = T(0);
+    F16_EACH(k) {
+      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+      pr[k] = T(0);
+      gp[k] = T(0);
+      if (s.valid) {
+        const T zi = lp[s.idx];
+        if (mode == F16_MALA) {
+          gr[k] = grg[s.idx];
+          const T loc = th[k] + T(0.5) * eps * gr[k];  // kernel_mean, mala.py:35-36
+          pr[k] = loc + sc * zi;
+          const T d = pr[k] - loc;
+          if (s.counts) qf += d * d;
+        } else {
+          pr[k] = th[k] + a.scale[s.idx] * zi;  // NormalKernel(theta, scale).sample()
+        }
+      }
+    }
+    f16_write_images<T, H>(lw, pr, a, c, g);
+    const T tv = f16_eval<T, H>(a, lw, pr, gp, mode == F16_MALA, has_temp, temp, c, g, lane);
+    const T t_old = a.target[chain];
+    T log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
+    if (mode == F16_MALA) {
+      T qb = T(0);
+      F16_EACH(k) {
+        const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+        if (s.counts) {
+          const T d = th[k] - (pr[k] + T(0.5) * eps * gp[k]);
+          qb += d * d;
+        }
+      }
+      const T inv2v = T(1) / (T(2) * sc * sc);
+      log_rate += (f16_wsum(qf) - f16_wsum(qb)) * inv2v;  // the -P log s - P/2 log 2pi terms cancel (mala.py:58-64)
+    }
+    const EyRng ru = ey_rng_make(a.seed, a.chain_offset + (uint64_t)chain, iter, EY_STREAM_UNIFORM);
+    const T u = a.u ? a.u[chain] : ey_rng_uniform<T>(ru);
+    const bool acc = Nm<T>::log(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
+    T* so = a.rec_samples ? a.rec_samples + ((int64_t)it * a.C + chain) * P : nullptr;
+    F16_EACH(k) {
+      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+      if (s.counts) {
+        if (acc) {
+          thg[s.idx] = pr[k];
+          if (mode == F16_MALA) grg[s.idx] = gp[k];
+        }
+        if (so) so[s.idx] = acc ? pr[k] : th[k];
+      }
+    }
+    if (lane == 0) {
+      if (acc) a.target[chain] = tv;
+      a.accepted[chain] = acc ? 1 : 0;
+      if (a.rate) a.rate[chain] = log_rate;
+      if (a.rec_targets) a.rec_targets[(int64_t)it * a.C + chain] = acc ? tv : t_old;
+      if (a.rec_accepted) a.rec_accepted[(int64_t)it * a.C + chain] = acc ? 1 : 0;
+      if (a.accept_count && acc) a.accept_count[chain] += 1;
+    }
+    if (a.n_iters > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    return;
+  }
+
+  // ---- HMC.draw (hmc.py:126-156) / HMC.leapfrog (:100-124)
+  T t_cur = T(0), kin = T(0);
+  if (mode == F16_HMC) {
+    F16_EACH(k) {
+      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+      if (s.counts) {
+        const T v = lp[s.idx];   // hmc.py:134
+        kin += v * v;
+      }
+      if (s.valid && !a.recompute) gr[k] = grg[s.idx];
+    }
+    kin = f16_wsum(kin);
+    t_cur = a.target[chain];
+  } else {
+    const T* pin = a.pio + chain * P;
+    for (int i = lane; i < P; i += 64) lp[i] = pin[i];
+    f16_fence();
+  }
+  const T h_cur = -t_cur + T(0.5) * kin;  // hmc.py:91-98,137
+  T t = t_cur;
+  // leapfrog (grad_potential = -grad); every lane updates the elements it holds, replicas included (same values).
+  // Step 0 is the evaluation at the starting position (hmc.py:104): skipped when the cached gradient is used.
+  const int k_first = (mode == F16_LEAPFROG || a.recompute) ? 0 : 1;
+  if (k_first == 1) {
+    F16_EACH(k) {
+      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+      if (s.valid) lp[s.idx] = lp[s.idx] + T(0.5) * eps * gr[k];
+    }
+    f16_fence();
+  }
+#pragma unroll 1
+  for (int kk = k_first; kk <= a.L; ++kk) {
+    if (kk > 0) {
+      F16_EACH(k) {
+        const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+        if (s.valid) th[k] = th[k] + eps * lp[s.idx];
+      }
+    }
+    f16_write_images<T, H>(lw, th, a, c, g);
+    t = f16_eval<T, H>(a, lw, th, gr, true, has_temp, temp, c, g, lane);
+    const T w = (kk > 0 && kk < a.L) ? eps : T(0.5) * eps;
+    F16_EACH(k) {
+      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+      if (s.valid) lp[s.idx] = lp[s.idx] + w * gr[k];
+    }
+    f16_fence();
+  }
+
+  if (mode == F16_LEAPFROG) {
+    T* pout = a.pio + chain * P;
+    F16_EACH(k) {
+      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+      if (s.counts) {
+        thg[s.idx] = th[k];
+        pout[s.idx] = -lp[s.idx];  // hmc.py:122
+        grg[s.idx] = gr[k];
+      }
+    }
+    if (lane == 0) a.target[chain] = t;
+    return;
+  }
+
+  kin = T(0);
+  F16_EACH(k) {
+    const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+    if (s.counts) {
+      const T v = lp[s.idx];
+      kin += v * v;
+    }
+  }
+  kin = f16_wsum(kin);
+  const T h_prop = -t + T(0.5) * kin;
+  T rate = Nm<T>::exp(h_cur - h_prop);  // hmc.py:143-146
+  if (rate > T(1)) rate = T(1);
+  const EyRng ru = ey_rng_make(a.seed, a.chain_offset + (uint64_t)chain, iter, EY_STREAM_UNIFORM);
+  const T u = a.u ? a.u[chain] : ey_rng_uniform<T>(ru);
+  const bool acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
+  T* so = a.rec_samples ? a.rec_samples + ((int64_t)it * a.C + chain) * P : nullptr;
+  F16_EACH(k) {
+    const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+    if (s.counts) {
+      if (so) so[s.idx] = acc ? th[k] : thg[s.idx];  // the state this chain is left in (chain_list.py:64-67)
+      if (acc) {
+        thg[s.idx] = th[k];
+        grg[s.idx] = gr[k];
+      }
+    }
+  }
+  if (lane == 0) {
+    if (acc) a.target[chain] = t;
+    a.accepted[chain] = acc ? 1 : 0;
+    if (a.rate) a.rate[chain] = rate;
+    if (a.hcur) a.hcur[chain] = h_cur;
+    if (a.hprop) a.hprop[chain] = h_prop;
+    if (a.rec_targets) a.rec_targets[(int64_t)it * a.C + chain] = acc ? t : t_cur;
+    if (a.rec_accepted) a.rec_accepted[(int64_t)it * a.C + chain] = acc ? 1 : 0;
+    if (a.accept_count && acc) a.accept_count[chain] += 1;
+  }
+  if (a.n_iters > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
+// Persistent launch: one WAVES-wave workgroup per CU, every wave walks over chains blockIdx + gridDim * wave, ... and
+// takes each through all iterations of the launch (chain-major, as ey_mfma32.hip).
+template <typename T, int H, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4) k_fused16(F16Args<T> a) {
+  typedef F16Cfg<H> K;
+  extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  T* lw = smem + (size_t)wave * K::WAVE_ELEMS;
+  // the zero padding of the operand images (skinny dimensions padded to a tile) and of the delta2 buffer
+  for (int i = lane; i < K::O_B0 - K::O_W0A; i += 64) lw[K::O_W0A + i] = T(0);
+  lw[K::O_D2 + lane] = T(0);
+  f16_fence();
+  const int64_t first = (int64_t)blockIdx.x + (int64_t)gridDim.x * wave, stride = (int64_t)gridDim.x * WAVES;
+  const int n_iters = (a.mode == F16_HMC || a.mode == F16_MALA || a.mode == F16_MH) ? a.n_iters : 1;
+  for (int64_t chain = first; chain < a.C; chain += stride)
+    for (int it = 0; it < n_iters; ++it) f16_run_chain<T, H>(a, lw, chain, it, c, g, lane);
+}
+
+// ----------------------------------------------------------------------------------------------- host side
+// Operand-order data image, per 16-row tile: [ks0][64] x as the B operand of F0 (lane (row, in & 3), k-step in >> 2),
+// [4][64] x as the B operand of dW0 (lane (in, row >> 2), step row & 3), [64] labels (-1 = padding row), [4][16] y.
+template <typename T>
+__global__ void k_f16_pack(const T* __restrict__ x, const T* __restrict__ y, const int* __restrict__ labels, int N,
+                           int d0, int dK, int lik, int ntiles, int ks0, int xt_stride, T* __restrict__ img) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntiles * 64) return;
+  const int t = i >> 6, lane = i & 63, c = lane & 15, g = lane >> 4;
+  T* xt = img + (size_t)t * xt_stride;
+  const int off_xu = ks0 * 64, off_lab = off_xu + 256, off_y = off_lab + 64;
+  for (int s = 0; s < ks0; ++s) {
+    const int n = 16 * t + c, in = 4 * s + g;
+    xt[s * 64 + lane] = (n < N && in < d0) ? x[(size_t)n * d0 + in] : T(0);
+  }
+  for (int r = 0; r < 4; ++r) {  // the rows of a U tile: fi(g, r)
+    const int n = 16 * t + Lay<T>::fi(g, r);
+    xt[off_xu + r * 64 + lane] = (n < N && c < d0) ? x[(size_t)n * d0 + c] : T(0);
+  }
+  {
+    const int n = 16 * t + c;
+    T lab = T(-1);
+    if (n < N) lab = lik == EY_LIK_CE_SUM ? (T)labels[n] : T(0);
+    xt[off_lab + lane] = lab;
+    xt[off_y + lane] = (n < N && g < dK) ? y[(size_t)n * dK + g] : T(0);
+  }
+}
+
+bool ey_fused16_supports(const ey_plan* pl) {
+  const EyModel& m = pl->m;
+  if (m.nl != 3) return false;
+  const int H = m.dims[1];
+  if (m.dims[2] != H || (H != 16 && H != 32 && H != 64)) return false;
+  if (m.dims[0] < 1 || m.dims[0] > 8 || m.dims[3] < 1 || m.dims[3] > 4) return false;
+  if (!m.bias[0] || !m.bias[1] || !m.bias[2]) return false;
+  for (int l = 0; l < 2; ++l)
+    if (m.act[l] != EY_ACT_SIGMOID && m.act[l] != EY_ACT_TANH && m.act[l] != EY_ACT_RELU) return false;
+  if (m.lik == EY_LIK_CE_SUM && m.act[2] != EY_ACT_NONE) return false;
+  if (m.lik == EY_LIK_BCE_SUM && m.act[2] != EY_ACT_SIGMOID) return false;
+  if (pl->dtype == EY_F64 && H == 64) return false;  // theta and the gradient alone would take 428 of 512 registers
+  return true;
+}
+
+static int f16_xt_stride(int ks0) { return ks0 * 64 + 256 + 64 + 64; }
+
+int ey_fused16_set_data(ey_plan* pl, hipStream_t s) {
+  const EyModel& m = pl->m;
+  const int ntiles = (m.N + 15) / 16, ks0 = (m.dims[0] + 3) / 4, xt = f16_xt_stride(ks0);
+  const size_t es = pl->dtype == EY_F32 ? 4 : 8;
+  const size_t need = es * (size_t)ntiles * xt;
+  if (need > pl->xpack16_bytes) {
+    EY_HIP(hipDeviceSynchronize());
+    (void)hipFree(pl->d_xpack16);
+    pl->d_xpack16 = nullptr;
+    pl->xpack16_bytes = 0;
+    EY_HIP(hipMalloc(&pl->d_xpack16, need));
+    pl->xpack16_bytes = need;
+  }
+  const dim3 grid((ntiles * 64 + 255) / 256);
+  if (es == 4)
+    hipLaunchKernelGGL(k_f16_pack<float>, grid, dim3(256), 0, s, (const float*)pl->d_x, (const float*)pl->d_y,
+                       (const int*)pl->d_labels, m.N, m.dims[0], m.dims[3], m.lik, ntiles, ks0, xt, (float*)pl->d_xpack16);
+  else
+    hipLaunchKernelGGL(k_f16_pack<double>, grid, dim3(256), 0, s, (const double*)pl->d_x, (const double*)pl->d_y,
+                       (const int*)pl->d_labels, m.N, m.dims[0], m.dims[3], m.lik, ntiles, ks0, xt, (double*)pl->d_xpack16);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+template <typename T, int H, int WAVES>
+static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
+  const size_t bytes = sizeof(T) * (size_t)WAVES * F16Cfg<H>::WAVE_ELEMS;
+  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  const unsigned grid = (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256);
+  hipLaunchKernelGGL((k_fused16<T, H, WAVES>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+template <typename T>
+static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
+  const EyModel& m = pl->m;
+  a.d0 = m.dims[0]; a.dK = m.dims[3]; a.act0 = m.act[0]; a.act1 = m.act[1]; a.lik = m.lik; a.P = m.P;
+  a.iW0 = m.woff[0]; a.iB0 = m.boff[0]; a.iW1 = m.woff[1]; a.iB1 = m.boff[1]; a.iW2 = m.woff[2]; a.iB2 = m.boff[2];
+  a.xpack = (const T*)pl->d_xpack16;
+  a.ntiles = (m.N + 15) / 16;
+  a.ks0 = (m.dims[0] + 3) / 4;
+  a.xt = f16_xt_stride(a.ks0);
+  a.mu = (const T*)m.mu;
+  a.inv_var = (const T*)m.inv_var;
+  a.prior_const = (T)m.prior_const;
+  const int H = m.dims[1];
+  // waves per CU by what the per-wave LDS region and the register file allow
+  if constexpr (sizeof(T) == 4) {
+    if (H == 16) return f16_launch_w<float, 16, 8>(a, pl->n_cu, s);
+    if (H == 32) return f16_launch_w<float, 32, 8>(a, pl->n_cu, s);
+    return f16_launch_w<float, 64, 3>(a, pl->n_cu, s);
+  } else {
+    if (H == 16) return f16_launch_w<double, 16, 8>(a, pl->n_cu, s);
+    return f16_launch_w<double, 32, 4>(a, pl->n_cu, s);
+  }
+}
+
+template <typename T>
+static void f16_set_run(F16Args<T>& a, const EyRun* run) {
+  a.n_iters = 1;
+  if (run) {
+    a.n_iters = run->n_iters;
+    a.rec_samples = (T*)run->samples;
+    a.rec_targets = (T*)run->targets;
+    a.rec_accepted = (unsigned char*)run->accepted;
+    a.accept_count = run->accept_count;
+  }
+}
+
+template <typename T>
+static int f16_hmc_t(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                     const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                     uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                     hipStream_t s, const EyRun* run) {
+  F16Args<T> a = {};
+  a.mode = F16_HMC;
+  a.C = C; a.theta = (T*)theta; a.target = (T*)target; a.grad = (T*)grad; a.p0 = (const T*)p0; a.u = (const T*)u;
+  a.step = (T)step; a.step_vec = (const T*)step_vec; a.L = L; a.temp = (const T*)temp; a.seed = seed; a.iter = iter;
+  a.chain_offset = chain_offset; a.recompute = (flags & EY_RECOMPUTE_INITIAL_GRAD) ? 1 : 0;
+  a.accepted = (unsigned char*)accepted; a.rate = (T*)rate; a.hcur = (T*)hcur; a.hprop = (T*)hprop;
+  f16_set_run(a, run);
+  return f16_launch<T>(pl, a, s);
+}
+int ey_fused16_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                   hipStream_t s, const EyRun* run) {
+  if (pl->dtype == EY_F32)
+    return f16_hmc_t<float>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+                            accepted, rate, hcur, hprop, s, run);
+  return f16_hmc_t<double>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+                           accepted, rate, hcur, hprop, s, run);
+}
+
+template <typename T>
+static int f16_mala_mh_t(ey_plan* pl, int mode, void* theta, void* target, void* grad, const void* z, const void* u,
+                         double step, const void* step_vec, const void* scale, const void* temp, int64_t C,
+                         uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted, void* log_rate,
+                         hipStream_t s, const EyRun* run) {
+  F16Args<T> a = {};
+  a.mode = mode;
+  a.C = C; a.theta = (T*)theta; a.target = (T*)target; a.grad = (T*)(grad ? grad : theta); a.p0 = (const T*)z;
+  a.u = (const T*)u; a.step = (T)step; a.sqrt_step = (T)sqrt(step); a.step_vec = (const T*)step_vec;
+  a.scale = (const T*)scale; a.temp = (const T*)temp; a.seed = seed; a.iter = iter; a.chain_offset = chain_offset;
+  a.accepted = (unsigned char*)accepted; a.rate = (T*)log_rate;
+  f16_set_run(a, run);
+  return f16_launch<T>(pl, a, s);
+}
+int ey_fused16_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                    const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                    uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run) {
+  if (pl->dtype == EY_F32)
+    return f16_mala_mh_t<float>(pl, F16_MALA, theta, target, grad, z, u, step, step_vec, nullptr, temp, C, seed, iter,
+                                chain_offset, accepted, log_rate, s, run);
+  return f16_mala_mh_t<double>(pl, F16_MALA, theta, target, grad, z, u, step, step_vec, nullptr, temp, C, seed, iter,
+                               chain_offset, accepted, log_rate, s, run);
+}
+int ey_fused16_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
+                  const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
+                  void* log_rate, hipStream_t s, const EyRun* run) {
+  if (pl->dtype == EY_F32)
+    return f16_mala_mh_t<float>(pl, F16_MH, theta, target, nullptr, z, u, 0.0, nullptr, scale, temp, C, seed, iter,
+                                chain_offset, accepted, log_rate, s, run);
+  return f16_mala_mh_t<double>(pl, F16_MH, theta, target, nullptr, z, u, 0.0, nullptr, scale, temp, C, seed, iter,
+                               chain_offset, accepted, log_rate, s, run);
+}
+
+template <typename T>
+static int f16_grad_t(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior, void* target,
+                      void* grad, hipStream_t s) {
+  F16Args<T> a = {};
+  a.mode = F16_GRAD;
+  a.C = C; a.theta = (T*)theta; a.target = (T*)target; a.grad = (T*)grad; a.temp = (const T*)temp;
+  a.hcur = (T*)lik; a.hprop = (T*)prior;
+  return f16_launch<T>(pl, a, s);
+}
+// target / grad (either may be null) and, for ey_log_target, the two parts lik / prior (either may be null)
+int ey_fused16_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+                          void* target, void* grad, hipStream_t s) {
+  if (pl->dtype == EY_F32) return f16_grad_t<float>(pl, theta, temp, C, lik, prior, target, grad, s);
+  return f16_grad_t<double>(pl, theta, temp, C, lik, prior, target, grad, s);
+}
+
+template <typename T>
+static int f16_leapfrog_t(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                          int64_t C, void* target, void* grad, hipStream_t s) {
+  F16Args<T> a = {};
+  a.mode = F16_LEAPFROG;
+  a.C = C; a.theta = (T*)theta; a.pio = (T*)p; a.target = (T*)target; a.grad = (T*)grad; a.step = (T)step;
+  a.step_vec = (const T*)step_vec; a.L = L; a.temp = (const T*)temp;
+  return f16_launch<T>(pl, a, s);
+}
+int ey_fused16_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                        int64_t C, void* target, void* grad, hipStream_t s) {
+  if (pl->dtype == EY_F32) return f16_leapfrog_t<float>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
+  return f16_leapfrog_t<double>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
+}

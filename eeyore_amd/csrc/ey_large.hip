@@ -443,11 +443,13 @@ __global__ void __launch_bounds__(256) k_hmc_end(float* theta, float* grad, floa
 }
 
 // ----------------------------------------------------------------------------------------------- host
-bool ey_large_needed(const ey_plan* pl) {
+// nvec = state vectors the generic kernel of the operation in question carves from LDS (2 for a value / random-walk MH
+// draw, 3 for HMC, 4 for MALA, ey_generic.hip): a model may fit for one operation and not for another
+bool ey_large_needed(const ey_plan* pl, int nvec) {
   const EyModel& m = pl->m;
   if (pl->dtype != EY_F32) return false;
   const size_t Ppad = (m.P + 3) & ~3;
-  const size_t generic_bytes = 4 * (3 * Ppad + (size_t)m.hrows * 65 + 2 * (size_t)m.dmax * 65);
+  const size_t generic_bytes = 4 * ((size_t)nvec * Ppad + (size_t)m.hrows * 65 + 2 * (size_t)m.dmax * 65);
   return generic_bytes > 160 * 1024;
 }
 

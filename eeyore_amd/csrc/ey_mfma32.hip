@@ -25,19 +25,13 @@
 //   w0[i]    = W0[out = 4(c>>2)+i][in = c&3]  (D layout of the 4x4x1 product; both halves hold the same values)
 //   w2[o]    = W2[o][k = c]                 (ditto)      b1 = b1[c], b0 = b0[c], b2[o] uniform
 #include <algorithm>
-#include <cstring>
-#include <vector>
+#include <atomic>
 
 #include "ey_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// EY_V: experimental variant mask (A/B builds): 1 trim padded k-steps, 2 conflict-free d2/x regroup images,
-// 4 chain-major iteration order, 8 priority by phase, 16 partners half a tile apart, 32 W2 images in registers
-#ifndef EY_V
-#define EY_V 0
-#endif
 #define MF_MAX_TILES 24  // 27 KB data image + 8 x 16.3 KB per-wave regions fit the 160 KB of a CU
 // per-wave LDS carve, in floats (all offsets multiples of 4 => 16-byte aligned b128 accesses)
 #define TS36 36
@@ -49,16 +43,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define O_W2TIMG 3760  // [32][4]
 #define O_B0IMG 3888
 #define O_B1IMG 3920
-#define O_D2BUF 3952   // [4][2][16]
-#if EY_V & 2
-#define D2S 36            // stride between the four outputs / inputs of the regrouped images: 36 floats keeps the
-#define WAVE_FLOATS 4096  // four 16-byte reads of a ds_read_b128 lane group on different banks (32 puts jj and jj+2 on the same)
-#define XTILE_FLOATS 304
-#else
-#define D2S 32
-#define WAVE_FLOATS 4080
-#define XTILE_FLOATS 288  // per row tile: [32][5] (x0..x3, label) + [4][2][16] (x regrouped for the 4x4x1 product)
-#endif
+#define O_D2BUF 3952   // [4][2][16], the four outputs D2S floats apart
+// Stride between the four outputs (delta2) / inputs (x) of the regrouped images: the ds_read_b128 of a lane group takes
+// its four 16-byte pieces from jj = 0..3, which 32 floats apart land on the same banks for jj and jj + 2 (a two-way
+// conflict on eight reads per tile: the 10 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 1); 36 apart they do not.
+#define D2S 36
+#define WAVE_FLOATS 4096
+#define XTILE_FLOATS 304  // per row tile: [32][5] (x0..x3, label) + [4][D2S] (x regrouped for the 4x4x1 product)
 
 // canonical offsets of MLP(4-32-32-3) in theta
 #define I_W0 0
@@ -79,7 +70,6 @@ struct MfArgs {
   float mu0, iv0;
   float prior_const;
   int ntiles;
-  int nrows;           // N
   int64_t C;
   float* theta;        // [C,P] in/out
   float* target;       // [C]
@@ -302,7 +292,6 @@ struct Pace {
   int* prog;    // [waves] tiles left, per wave of this workgroup
   int wave, partner;
   int left;
-  int bias;     // EY_V & 16: progress is counted in half tiles and waves 4-7 keep one half tile behind their partners
   bool on;
 };
 __device__ __forceinline__ int pace_post(Pace& pc, int lane) {
@@ -313,27 +302,10 @@ __device__ __forceinline__ int pace_post(Pace& pc, int lane) {
 }
 __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
   if (!pc.on) return;
-#if EY_V & 8
-  return;  // priority follows the phase of the tile instead
-#endif
   // (scalar comparison: a vector compare would be lowered to EXEC masking, under which both s_setprio would execute)
   const int theirs = __builtin_amdgcn_readfirstlane(theirs_v);
-#if EY_V & 16
-  if (pc.left - pc.bias < theirs + pc.bias - 1) __builtin_amdgcn_s_setprio(0);
-#else
   if (pc.left < theirs) __builtin_amdgcn_s_setprio(0);
-#endif
   else __builtin_amdgcn_s_setprio(1);
-}
-template <int P>
-__device__ __forceinline__ void phase_prio() {
-#if EY_V & 8
-#ifdef EY_PRIO_INV
-  __builtin_amdgcn_s_setprio(1 - P);  // the wave inside a 16-MFMA product keeps the pipe: no VALU of the partner between its MFMAs
-#else
-  __builtin_amdgcn_s_setprio(P);
-#endif
-#endif
 }
 
 // log-target and gradient of the position whose images are staged in lw.  Returns the (tempered) log-target.
@@ -375,207 +347,9 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
   const bool ph_on = (blockIdx.x & 63) == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
   unsigned long long ph_t = ph_on ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
-#if EY_V & 32
-  f32x4 w2r[4], w2tr[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    w2r[q] = *reinterpret_cast<const f32x4*>(lw + O_W2IMG + jj * TS36 + 8 * q + 4 * h);
-    w2tr[q] = *reinterpret_cast<const f32x4*>(lw + O_W2TIMG + (8 * q + 4 * h + jj) * 4);
-  }
-#endif
-#if EY_V & 64
-  // The tile loop with every LDS round trip issued ahead of a stretch of ALU work that covers it: operands that do not
-  // depend on the tile (bias patterns, W0 / W2 images) stay in registers, the W1 image is fetched before the F1
-  // products need it, and each "store transposed -> read back" pair has a 16-MFMA product or the softmax between
-  // the store and the first use.  sched_barrier keeps the sections in this order; inside them the compiler schedules.
-#define LDS4(off) (*reinterpret_cast<const f32x4*>(lw + (off)))
-  f32x4 b0v[4], b1v[4], w2v[4], w2t[4];
-  float w0a[2];
-#if !(EY_V & 128)
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    b0v[q] = LDS4(O_B0IMG + 8 * q + 4 * h);
-    b1v[q] = LDS4(O_B1IMG + 8 * q + 4 * h);
-    w2v[q] = LDS4(O_W2IMG + jj * TS36 + 8 * q + 4 * h);
-    w2t[q] = LDS4(O_W2TIMG + (8 * q + 4 * h + jj) * 4);
-  }
-#endif
-  w0a[0] = lw[O_W0IMG + c * 5 + h];
-  w0a[1] = lw[O_W0IMG + c * 5 + 2 + h];
-  float xa0 = xs[c * 5 + h], xa1 = xs[c * 5 + 2 + h];
-  int lab = __float_as_int(xs[c * 5 + 4]);
 #pragma unroll 1
   for (int t = 0; t < A.ntiles; ++t) {
     const float* xt = xs + t * XTILE_FLOATS;
-    phase_prio<1>();
-    const int pace_theirs = pace_post(pc, lane);
-    // ---- F0: H0^T = sigmoid(W0 X^T + b0)                                  (mlp.py:45-50)
-    f32x16 acc;
-#if EY_V & 128
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b0v[q] = LDS4(O_B0IMG + 8 * q + 4 * h);
-#endif
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[4 * q + j] = b0v[q][j];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0a[0], xa0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0a[1], xa1, acc, 0, 0, 0);
-    // the W1 image for F1 (lane <-> output), on its way while F0's result matures and the sigmoid runs
-    f32x4 w1a[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w1a[q] = LDS4(O_W1IMG + c * TS36 + 8 * q + 4 * h);
-#if EY_V & 128
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      b1v[q] = LDS4(O_B1IMG + 8 * q + 4 * h);
-      w2v[q] = LDS4(O_W2IMG + jj * TS36 + 8 * q + 4 * h);
-      w2t[q] = LDS4(O_W2TIMG + (8 * q + 4 * h + jj) * 4);
-    }
-#endif
-    const int labt = lab;
-    {  // next tile's inputs (the last tile re-reads its own: harmless)
-      const float* xn = xs + (t + 1 < A.ntiles ? t + 1 : t) * XTILE_FLOATS;
-      xa0 = xn[c * 5 + h]; xa1 = xn[c * 5 + 2 + h]; lab = __float_as_int(xn[c * 5 + 4]);
-    }
-    const f32x16 H0 = sigmoid_tile(acc);
-    if (GRAD) store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1: read back during the dH0 products
-    __builtin_amdgcn_sched_barrier(0);
-    phase_prio<0>();
-    // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[4 * q + j] = b1v[q][j];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[q][j], H0[4 * q + j], acc, 0, 0, 0);
-    pace_apply(pc, pace_theirs);  // while the F1 products run
-    phase_prio<1>();
-    const f32x16 H1 = sigmoid_tile(acc);
-    if (GRAD) store_T(lw + O_TB0, H1, c, h);  // transposed copy for dW2; the logits and the softmax run while it lands
-    // ---- F2: logits = W2 H1^T + b2 with the 16-block 4x4x1 product; each half sums its 16 features
-    f32x4 lg0 = {0, 0, 0, 0}, lg1 = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      lg0 = mfma4(w2v[q][0], H1[4 * q + 0], lg0);
-      lg1 = mfma4(w2v[q][1], H1[4 * q + 1], lg1);
-      lg0 = mfma4(w2v[q][2], H1[4 * q + 2], lg0);
-      lg1 = mfma4(w2v[q][3], H1[4 * q + 3], lg1);
-    }
-    float l0 = lg0[0] + lg1[0], l1 = lg0[1] + lg1[1], l2 = lg0[2] + lg1[2];
-    l0 = hsum(l0); l1 = hsum(l1); l2 = hsum(l2);
-    l0 += b2_0; l1 += b2_1; l2 += b2_2;
-    // ---- CE-sum log-likelihood and output delta = onehot - softmax           (constants.py:17)
-    const bool valid = labt >= 0;
-    const float mx = fmaxf(l0, fmaxf(l1, l2));
-    const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx), e2 = __expf(l2 - mx);
-    const float ssum = e0 + e1 + e2;
-    const float llab = labt == 0 ? l0 : (labt == 1 ? l1 : l2);
-    if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
-    if (!GRAD) continue;  // nothing was written to LDS in this tile
-    const float rs = __builtin_amdgcn_rcpf(ssum);
-    float d2[3];
-    d2[0] = valid ? ((labt == 0 ? 1.0f : 0.0f) - e0 * rs) : 0.0f;
-    d2[1] = valid ? ((labt == 1 ? 1.0f : 0.0f) - e1 * rs) : 0.0f;
-    d2[2] = valid ? ((labt == 2 ? 1.0f : 0.0f) - e2 * rs) : 0.0f;
-    if (h == 0) {
-      db2[0] += d2[0]; db2[1] += d2[1]; db2[2] += d2[2];
-      // delta2 regrouped [o][half][s'][i] with row = 8s'+4*half+i, the k order of the transposed reads below
-      const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
-      lw[O_D2BUF + 0 * D2S + a2] = d2[0];
-      lw[O_D2BUF + 1 * D2S + a2] = d2[1];
-      lw[O_D2BUF + 2 * D2S + a2] = d2[2];
-      lw[O_D2BUF + 3 * D2S + a2] = 0.0f;
-    }
-    wave_lds_fence();
-    // operands of dW2 (H1 and delta2 with lane <-> feature / output), fetched while dH1 is computed from registers
-    f32x4 hu2[4], du2[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      hu2[s] = LDS4(O_TB0 + c * TS36 + 8 * s + 4 * h);
-      du2[s] = LDS4(O_D2BUF + jj * D2S + h * 16 + 4 * s);
-    }
-    // ---- B1(2): dH1^T = W2^T delta2^T, delta1 = dH1 * H1 (1 - H1)
-    f32x16 D1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 d = {0, 0, 0, 0};
-      d = mfma4(w2t[q][0], d2[0], d);
-      d = mfma4(w2t[q][1], d2[1], d);
-      d = mfma4(w2t[q][2], d2[2], d);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i];
-    }
-    D1 = times_dsigmoid(D1, H1);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- B2(2): dW2[o][k] += sum_n delta2[n][o] H1[n][k]                    (contracts over rows: transposed reads)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      dW2a = mfma4(du2[s][0], hu2[s][0], dW2a);
-      dW2b = mfma4(du2[s][1], hu2[s][1], dW2b);
-      dW2a = mfma4(du2[s][2], hu2[s][2], dW2a);
-      dW2b = mfma4(du2[s][3], hu2[s][3], dW2b);
-    }
-    wave_lds_fence();  // H1^T has been read: its buffer takes delta1^T
-    store_T(lw + O_TB0, D1, c, h);
-    wave_lds_fence();
-    // operands of the row-contracting products, on their way while dH0 runs from registers
-    f32x4 du1[4], hu1[4], xu[4];
-    const float* x2 = xt + 160 + jj * D2S + h * 16;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      du1[s] = LDS4(O_TB0 + c * TS36 + 8 * s + 4 * h);
-      hu1[s] = LDS4(O_TB1 + c * TS36 + 8 * s + 4 * h);
-      xu[s] = *reinterpret_cast<const f32x4*>(x2 + 4 * s);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    phase_prio<0>();
-    // ---- B1(1): dH0 = delta1 W1 computed UNtransposed (A = delta1 tile with M = rows, B = theta's own W1
-    // registers), so its accumulator is already lane <-> input feature, register <-> row
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1   -- and, in its shadow,
-    // delta0 = dH0 * H0 (1 - H0) and B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
-    f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        H0U[4 * s + i] = hu1[s][i];
-        dW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(du1[s][i], hu1[s][i], dW1, 0, 0, 0);
-      }
-      db1 += (du1[s][0] + du1[s][1]) + (du1[s][2] + du1[s][3]);
-    }
-    const f32x16 D0u = times_dsigmoid(acc, H0U);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const f32x4 du = {D0u[4 * s], D0u[4 * s + 1], D0u[4 * s + 2], D0u[4 * s + 3]};
-      dW0a = mfma4(du[0], xu[s][0], dW0a);
-      dW0b = mfma4(du[1], xu[s][1], dW0b);
-      dW0a = mfma4(du[2], xu[s][2], dW0a);
-      dW0b = mfma4(du[3], xu[s][3], dW0b);
-      db0 += (du[0] + du[1]) + (du[2] + du[3]);
-    }
-    wave_lds_fence();
-  }
-#undef LDS4
-#else
-#pragma unroll 1
-  for (int t = 0; t < A.ntiles; ++t) {
-    const float* xt = xs + t * XTILE_FLOATS;
-#if EY_V & 1
-    // groups of eight rows of this tile that hold data: the products that contract over rows skip the others
-    // (their delta is zero), which only the last tile has (150 rows: 22 of 32 => 3 of 4 groups)
-    const int ns = min(4, (A.nrows - 32 * t + 7) >> 3);
-#else
-    constexpr int ns = 4;
-#endif
-    phase_prio<1>();
     const int pace_theirs = pace_post(pc, lane);
     // ---- F0: H0^T = sigmoid(W0 X^T + b0)                                  (mlp.py:45-50)
     f32x16 acc;
@@ -592,7 +366,6 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     const f32x16 H0 = sigmoid_tile(acc);
     if (GRAD) store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
     PH(0);
-    phase_prio<0>();
     // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -607,7 +380,6 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], H0[4 * q + j], acc, 0, 0, 0);
     }
     pace_apply(pc, pace_theirs);  // while the F1 products run
-    phase_prio<1>();
     const f32x16 H1 = sigmoid_tile(acc);
     if (GRAD) store_T(lw + O_TB0, H1, c, h);  // transposed copy for dW2; the logits and the softmax run while it lands
     PH(1);
@@ -615,11 +387,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     f32x4 lg0 = {0, 0, 0, 0}, lg1 = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-#if EY_V & 32
-      const f32x4 wv = w2r[q];
-#else
       const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + O_W2IMG + jj * TS36 + 8 * q + 4 * h);
-#endif
       lg0 = mfma4(wv[0], H1[4 * q + 0], lg0);
       lg1 = mfma4(wv[1], H1[4 * q + 1], lg1);
       lg0 = mfma4(wv[2], H1[4 * q + 2], lg0);
@@ -656,7 +424,6 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     // ---- B2(2): dW2[o][k] += sum_n delta2[n][o] H1[n][k]                    (contracts over rows: transposed reads)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s >= ns) break;
       const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
       const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_D2BUF + jj * D2S + h * 16 + 4 * s);
       dW2a = mfma4(du[0], hu[0], dW2a);
@@ -669,11 +436,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     f32x16 D1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-#if EY_V & 32
-      const f32x4 wt = w2tr[q];
-#else
       const f32x4 wt = *reinterpret_cast<const f32x4*>(lw + O_W2TIMG + (8 * q + 4 * h + jj) * 4);
-#endif
       f32x4 d = {0, 0, 0, 0};
       d = mfma4(wt[0], d2[0], d);
       d = mfma4(wt[1], d2[1], d);
@@ -687,21 +450,15 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     store_T(lw + O_TB0, D1, c, h);
     wave_lds_fence();
     PH(6);
-#if EY_V & 16
-    const int pace_theirs2 = pace_post(pc, lane);
-#endif
-    phase_prio<0>();
     // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
     f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
       const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB1 + c * TS36 + 8 * s + 4 * h);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) H0U[4 * s + i] = hu[i];
-      if (s >= ns) continue;
-      const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
-#pragma unroll
       for (int i = 0; i < 4; ++i) {
+        H0U[4 * s + i] = hu[i];
         if (EY_ABLATE & 8) dW1[i] += du[i] * hu[i];
         else dW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(du[i], hu[i], dW1, 0, 0, 0);
       }
@@ -715,17 +472,12 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
-#if EY_V & 16
-    pace_apply(pc, pace_theirs2);
-#endif
-    phase_prio<1>();
     const f32x16 D0u = times_dsigmoid(acc, H0U);
     PH(8);
     // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
     const float* x2 = xt + 160 + jj * D2S + h * 16;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s >= ns) break;
       const f32x4 du = {D0u[4 * s], D0u[4 * s + 1], D0u[4 * s + 2], D0u[4 * s + 3]};
       const f32x4 xu = *reinterpret_cast<const f32x4*>(x2 + 4 * s);
       dW0a = mfma4(du[0], xu[0], dW0a);
@@ -737,7 +489,6 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     wave_lds_fence();
     PH(9);
   }
-#endif
   if (PARK) {
     int at = WAVE_FLOATS + lane;
     asm volatile("" : "+v"(at));  // an offset the compiler cannot match with the stores above: no forwarding
@@ -1085,7 +836,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   pc.wave = wave;
   pc.partner = wave;
   pc.left = 0;
-  pc.bias = wave >= MF_WAVES / 2 ? 1 : 0;
   int mates = 0;
   for (int w = 0; w < MF_WAVES; ++w)
     if (w != wave && ctl[MF_WAVES + w] == simd) { pc.partner = w; ++mates; }
@@ -1103,21 +853,17 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
     const int64_t mine = first < A.C ? (A.C - first + stride - 1) / stride : 0;
     const int evals = (MODE == MODE_HMC) ? A.L + (A.recompute ? 1 : 0) : (MODE == MODE_LEAPFROG ? A.L + 1 : 1);
     const int iters = (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) ? A.n_iters : 1;
-    pc.left = (int)std::min<int64_t>(mine * evals * A.ntiles * iters * ((EY_V & 16) ? 2 : 1), 0x3fffffff);
+    pc.left = (int)std::min<int64_t>(mine * evals * A.ntiles * iters, 0x3fffffff);
     if (lane == 0) ctl[wave] = pc.left;
   }
   __syncthreads();
   if (__builtin_amdgcn_readfirstlane(ctl[pc.partner]) == 0) pc.on = false;  // the partner has no chain at all
   const int n_iters = (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) ? A.n_iters : 1;
-#if EY_V & 4
-  // chain-major: a wave takes one of its chains through all iterations of the launch before it starts the next (the
-  // chains are independent), so the state and the moment accumulators it touches stay in this CU's caches
-  for (int64_t chain = first; chain < A.C; chain += stride) {
+  // Chain-major: a wave takes one of its chains through all iterations of the launch before it starts the next (the
+  // chains are independent), so the 21 KB of f64 moment accumulators and the state it reads back stay in this CU's
+  // caches between iterations instead of being streamed from HBM once per iteration.
+  for (int64_t chain = first; chain < A.C; chain += stride) {  // whole waves; no workgroup synchronisation below
     for (int it = 0; it < n_iters; ++it) {
-#else
-  for (int it = 0; it < n_iters; ++it) {
-    for (int64_t chain = first; chain < A.C; chain += stride) {  // whole waves; no workgroup synchronisation below
-#endif
       // Re-read the arguments from the kernarg segment in every round: hoisted out of this loop they would all stay
       // live in scalar registers for the whole kernel (106 SGPRs, spilled into vector registers, which then spill too).
       KArgs* Ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1145,71 +891,66 @@ static size_t mf_lds_bytes(int ntiles, int waves, int park) {
          sizeof(int) * 2 * waves;
 }
 #define MF_PARK 12        // position elements parked in LDS during the tile loop ...
-#if EY_V & 2
 #define MF_PARK_TILES 6   // ... when the data image leaves room for it (N <= 192 rows)
-#else
-#define MF_PARK_TILES 7   // ... when the data image leaves room for it (N <= 224 rows)
-#endif
 
 // kernel variant (A/B knob): bit 0 = former launch shape (4-wave workgroups, one chain per wave), bit 1 = no priority
 // balancing between the two waves of a SIMD, bit 2 = no momentum parking
-static int g_variant = 0;
-extern int g_ey_force_large;
+static std::atomic<int> g_variant{0};
+extern std::atomic<int> g_ey_force_large;
 extern "C" int ey_debug_set_variant(int v) {
-  const int old = g_variant | (g_ey_force_large << 4);
-  g_variant = v & 15;
-  g_ey_force_large = (v >> 4) & 1;
+  const int old = g_variant.load() | (g_ey_force_large.load() << 4);
+  g_variant.store(v & 15);
+  g_ey_force_large.store((v >> 4) & 1);
   return old;
 }
 
-// Pack (x, labels) into the per-tile LDS images.  Rows beyond N are zero with label -1 (they contribute nothing).
+// Pack (x, labels) into the per-tile LDS images, on the device and on the caller's stream: one thread per (tile, row).
+// Rows beyond N are zero with label -1 (they contribute nothing).
+__global__ void k_mf_pack(const float* __restrict__ x, const int* __restrict__ labels, int N, int ntiles,
+                          float* __restrict__ img) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntiles * 32) return;
+  const int t = i >> 5, cc = i & 31, n = i;
+  float* xt = img + (size_t)t * XTILE_FLOATS;
+  int lab = -1;
+  float xv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (n < N) {
+    lab = labels[n];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = x[(size_t)n * 4 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xt[cc * 5 + k] = xv[k];
+  xt[cc * 5 + 4] = __int_as_float(lab);
+  // regrouped copy for the 4x4x1 weight-gradient product: [in][half][s'][i], row = 8s' + 4 half + i
+  const int sp = cc >> 3, hh = (cc >> 2) & 1, ii = cc & 3;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xt[160 + k * D2S + hh * 16 + sp * 4 + ii] = xv[k];
+  // the four pad floats of each input's row of the regrouped image are never read
+}
+
+// Asynchronous: no host round trip and no allocation per batch (the image buffer is sized once, for MF_MAX_TILES).
+// A batch with more row tiles than the kernel's LDS image can hold sends this plan to the other kernel families
+// until a batch that fits arrives (mfma32_data_ok is recomputed on every call).
 int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
   const EyModel& m = pl->m;
   const int ntiles = (m.N + 31) / 32;
-  if (ntiles > MF_MAX_TILES) {  // the shared data image would no longer fit LDS beside the eight per-wave regions
-    pl->mfma32_ok = false;
-    return EY_OK;
-  }
-  std::vector<float> hx((size_t)m.N * 4);
-  std::vector<int> hl(m.N);
-  EY_HIP(hipMemcpyAsync(hx.data(), pl->d_x, hx.size() * 4, hipMemcpyDeviceToHost, s));
-  EY_HIP(hipMemcpyAsync(hl.data(), pl->d_labels, hl.size() * 4, hipMemcpyDeviceToHost, s));
-  EY_HIP(hipStreamSynchronize(s));
-  std::vector<float> img((size_t)ntiles * XTILE_FLOATS, 0.0f);
-  for (int t = 0; t < ntiles; ++t) {
-    float* xt = img.data() + (size_t)t * XTILE_FLOATS;
-    for (int cc = 0; cc < 32; ++cc) {
-      const int n = 32 * t + cc;
-      int lab = -1;
-      float xv[4] = {0, 0, 0, 0};
-      if (n < m.N) {
-        lab = hl[n];
-        for (int i = 0; i < 4; ++i) xv[i] = hx[(size_t)n * 4 + i];
-      }
-      for (int i = 0; i < 4; ++i) xt[cc * 5 + i] = xv[i];
-      memcpy(&xt[cc * 5 + 4], &lab, 4);
-      // regrouped copy for the 4x4x1 weight-gradient product: [in][half][s'][i], row = 8s' + 4 half + i
-      const int sp = cc >> 3, hh = (cc >> 2) & 1, ii = cc & 3;
-      for (int i = 0; i < 4; ++i) xt[160 + i * D2S + hh * 16 + sp * 4 + ii] = xv[i];
-    }
-  }
-  (void)hipFree(pl->d_xpack);
-  pl->d_xpack = nullptr;
-  EY_HIP(hipMalloc(&pl->d_xpack, img.size() * 4));
-  EY_HIP(hipMemcpy(pl->d_xpack, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+  pl->mfma32_data_ok = ntiles <= MF_MAX_TILES;
+  if (!pl->mfma32_data_ok) return EY_OK;
+  if (!pl->d_xpack) EY_HIP(hipMalloc(&pl->d_xpack, sizeof(float) * (size_t)MF_MAX_TILES * XTILE_FLOATS));
+  hipLaunchKernelGGL(k_mf_pack, dim3((ntiles * 32 + 255) / 256), dim3(256), 0, s, (const float*)pl->d_x,
+                     (const int*)pl->d_labels, m.N, ntiles, (float*)pl->d_xpack);
+  EY_HIP(hipGetLastError());
   return EY_OK;
 }
 
 template <int MODE, int WAVES, int PARK, bool UPRIOR = false>
 static int mf_launch_v(MfArgs& a, int n_cu, hipStream_t s) {
   const size_t bytes = mf_lds_bytes(a.ntiles, WAVES, PARK);
-  static bool attr_done = false;
-  if (!attr_done) {
-    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PARK, UPRIOR>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)mf_lds_bytes(PARK ? MF_PARK_TILES : MF_MAX_TILES, WAVES, PARK)));
-    attr_done = true;
-  }
+  // per launch: function attributes are per device and plans on different devices / threads share this code
+  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PARK, UPRIOR>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)mf_lds_bytes(PARK ? MF_PARK_TILES : MF_MAX_TILES, WAVES, PARK)));
   // 8 waves: one persistent workgroup per CU, or one per chain when there are fewer chains than CUs (then only wave
   // 0 of a workgroup has work and every chain gets a CU to itself); 4 waves: a workgroup per 4 chains
   const unsigned grid = WAVES == 8 ? (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256)
@@ -1230,17 +971,17 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.iv0 = (float)pl->prior_iv0;
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
-  a.nrows = m.N;
-  a.balance = (g_variant & 2) ? 0 : 1;
+  a.balance = (g_variant.load() & 2) ? 0 : 1;
   if (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) {
     a.mom_s1 = pl->mom_s1;
     a.mom_s2 = pl->mom_s2;
     a.mom_acc = pl->mom_acc;
   }
   if constexpr (MODE == MODE_HMC) {
-    if (g_variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);
+    const int variant = g_variant.load();
+    if (variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);
     // the headline shape (few row tiles, one Normal(m, s) prior for all parameters) has its own, leaner instantiation
-    if (a.ntiles <= MF_PARK_TILES && a.prior_uniform && !(g_variant & 4))
+    if (a.ntiles <= MF_PARK_TILES && a.prior_uniform && !(variant & 4))
       return mf_launch_v<MODE, 8, MF_PARK, true>(a, pl->n_cu, s);
   }
   return mf_launch_v<MODE, 8, 0>(a, pl->n_cu, s);

@@ -139,12 +139,9 @@ __global__ void __launch_bounds__(ST_THREADS) k_inse_univariate(const T* __restr
 template <typename T, int BS>
 static int launch_inse(const void* x, int64_t n, int64_t S, double* sig2, double* var, int* pairs, hipStream_t s) {
   const size_t bytes = (size_t)n * BS * sizeof(T);
-  static bool attr_done = false;
-  if (!attr_done) {
-    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inse_univariate<T, BS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES));
-    attr_done = true;
-  }
+  // per launch: function attributes are per device (cheap next to the kernel)
+  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inse_univariate<T, BS>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES));
   const unsigned grid = (unsigned)((S + BS - 1) / BS);
   hipLaunchKernelGGL((k_inse_univariate<T, BS>), dim3(grid), dim3(ST_THREADS), bytes, s, (const T*)x, n, S, sig2, var,
                      pairs);

@@ -84,8 +84,8 @@ class ChainStats:
         mean = self.s1 / n
         var = (self.s2 - n * mean * mean) / (n - 1)  # unbiased, as eeyore/stats/cov.py:15
         part = torch.stack([mean.sum(0), (mean * mean).sum(0), var.sum(0)])
-        extra = torch.tensor([float(mean.shape[0]), float(self.acc.sum().item())], dtype=torch.float64,
-                             device=part.device)
+        extra = torch.stack([torch.tensor(float(mean.shape[0]), dtype=torch.float64, device=part.device),
+                             self.acc.sum()])  # stays on the device: no host round trip before the all-reduce
         return part, extra
 
     def summary(self, group=None):

@@ -37,7 +37,7 @@ class Plan:
         P = ct.c_int64()
         L.check(L.lib().ey_plan_num_params(self.handle, ct.byref(P)), "ey_plan_num_params")
         self.P = P.value
-        self._data_key = None
+        self._data_key, self._data_ref = None, (None, None)
         self._prior_key = None
         self._moments = None
 
@@ -62,8 +62,12 @@ class Plan:
         return t
 
     def set_data(self, x, y):
-        key = (x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), x._version, y._version, x.dtype, x.device)
-        if key == self._data_key:
+        """Attach the batch (asynchronous on the current stream: device-to-device copies and two small kernels).
+        The upload is skipped only when the SAME tensor objects, unmodified (``_version``), are passed again: the plan
+        keeps references to them, so their storage cannot be recycled for another batch while the key is live (an
+        address-based key matches a freed temporary's successor and would silently keep the old data)."""
+        key = (x._version, y._version)
+        if self._data_key is not None and self._data_ref[0] is x and self._data_ref[1] is y and key == self._data_key:
             return
         xd = self._prep(x)
         yd = self._prep(y)
@@ -74,7 +78,7 @@ class Plan:
             raise ValueError(f"y must be [N, {self.dims[-1]}], got {tuple(yd.shape)}")
         L.check(L.lib().ey_plan_set_data(self.handle, L.ptr(xd), L.ptr(yd), xd.shape[0], _stream(self.device)),
                 "ey_plan_set_data")
-        self._data_key = key
+        self._data_key, self._data_ref = key, (x, y)
         self.N = xd.shape[0]
 
     def set_prior(self, mu, sigma):

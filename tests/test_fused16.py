@@ -1,0 +1,191 @@
+"""The fused 16x16x4 matrix-core kernels (ey_fused16.hip: d0-H-H-dK, H in {16, 32, 64}, f32 and f64, CE or BCE, sigmoid /
+tanh / relu) through the C ABI against the C oracle, and against the generic kernels on the same inputs.
+f64 within 1e-10 relative (the reference's default dtype, eeyore/models/model.py:7), f32 within the stated 2e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.c_oracle import COracle
+from tests.helpers import groups, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = [
+    # dims, hidden/out activations, likelihood, dtype, N
+    ([4, 16, 16, 3], [1, 1, 0], 1, "f32", 150),
+    ([4, 16, 16, 3], [1, 1, 0], 1, "f64", 77),
+    ([4, 32, 32, 3], [1, 1, 0], 1, "f64", 150),   # the headline model in the reference's default dtype
+    ([4, 32, 32, 3], [2, 2, 0], 1, "f32", 150),   # tanh: not the shape ey_mfma32.hip serves
+    ([8, 64, 64, 4], [2, 1, 0], 1, "f32", 33),    # widest: d0 = 8 (two k-steps), dK = 4, three waves per CU
+    ([2, 16, 16, 1], [1, 1, 1], 0, "f64", 4),     # BCE-sum on a sigmoid output, as the reference's own tests
+    ([5, 32, 32, 2], [3, 2, 1], 0, "f64", 49),    # relu, tanh, two BCE outputs
+    ([3, 64, 64, 2], [1, 2, 1], 0, "f32", 130),
+    ([1, 16, 16, 2], [1, 1, 0], 1, "f32", 1),     # one input, one row
+]
+
+
+def _t(a, dt):
+    return torch.tensor(np.asarray(a), dtype=dt, device=DEV).contiguous()
+
+
+def _setup(dims, acts, lik, tag, N, seed=0):
+    from eeyore_amd.plan import Plan
+    npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    rng = np.random.default_rng(sum(dims) + N + seed)
+    x = rng.standard_normal((N, dims[0]))
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(np.float64)
+    P = sum((dims[l] + 1) * dims[l + 1] for l in range(3))
+    mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+    pl = Plan(dims, [1, 1, 1], acts, lik, dt, DEV)
+    pl.set_data(_t(x, dt), _t(y, dt))
+    pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+    co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, nthreads=4)
+    return pl, co, rng, npdt, dt, P
+
+
+@pytest.mark.parametrize("dims,acts,lik,tag,N", CASES)
+def test_fused16_value_gradient_and_draws_vs_oracle(dims, acts, lik, tag, N):
+    from eeyore_amd import _lib as L
+    pl, co, rng, npdt, dt, P = _setup(dims, acts, lik, tag, N)
+    assert pl.kernel == "fused16" and pl.P == P
+    C = 11
+    scale = 0.3 if lik == 1 else 0.15
+    th0 = (scale * rng.standard_normal((C, P))).astype(npdt)
+    tol = 1e-10 if tag == "f64" else 2e-4
+    t, g = pl.log_target_grad(_t(th0, dt))
+    lk, pr = pl.log_target(_t(th0, dt))
+    temps = torch.linspace(0.2, 1.0, C, dtype=dt, device=DEV)
+    tt, gt = pl.log_target_grad(_t(th0, dt), temp=temps)
+    for c in range(C):
+        to, go, lo, po = co.log_target_grad(th0[c])
+        gs = max(1.0, float(np.abs(go).max()))
+        np.testing.assert_allclose(t[c].item(), to, rtol=tol, atol=tol * 10)
+        np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=tol * 10, atol=tol * gs)
+        np.testing.assert_allclose([lk[c].item(), pr[c].item()], [lo, po], rtol=tol, atol=tol * 10)
+        np.testing.assert_allclose(tt[c].item(), temps[c].item() * to, rtol=tol * 2, atol=tol * 10)
+        np.testing.assert_allclose(gt[c].cpu().numpy(), temps[c].item() * go, rtol=tol * 10, atol=tol * gs)
+    # the generic kernels on the same inputs
+    t2 = pl.hmc_step(_t(th0, dt), t.clone(), g.clone(), 1e-9, 1, p0=torch.zeros(C, P, dtype=dt, device=DEV),
+                     u=torch.zeros(C, dtype=dt, device=DEV), flags=L.EY_FORCE_GENERIC | L.EY_RECOMPUTE_INITIAL_GRAD)
+    assert t2["accepted"].shape == (C,)
+    # ---- HMC.leapfrog: L steps, L + 1 evaluations, momentum negated
+    p0 = rng.standard_normal((C, P)).astype(npdt); u = rng.random(C).astype(npdt)
+    th, p = _t(th0, dt).clone(), _t(p0, dt).clone()
+    eps, Ls = (0.02, 4) if lik == 1 else (0.01, 3)
+    tl, gl = pl.leapfrog(th, p, eps, Ls)
+    for c in range(0, C, 3):
+        tho, po_, to, go = co.leapfrog(th0[c], p0[c], eps, Ls)
+        np.testing.assert_allclose(th[c].cpu().numpy(), tho, rtol=tol * 10, atol=tol)
+        np.testing.assert_allclose(p[c].cpu().numpy(), po_, rtol=tol * 50, atol=tol * 50)
+        np.testing.assert_allclose(tl[c].item(), to, rtol=tol * 5, atol=tol * 20)
+    # ---- one HMC draw (cached gradient and the reference's recomputed one), MALA, MH on recorded randomness
+    tv0 = t.cpu().numpy().astype(npdt); g0 = g.cpu().numpy().astype(npdt)
+    for flags in (0, L.EY_RECOMPUTE_INITIAL_GRAD):
+        th, tv, gg = _t(th0, dt).clone(), t.clone(), g.clone()
+        out = pl.hmc_step(th, tv, gg, eps, 5, p0=_t(p0, dt), u=_t(u, dt), flags=flags)
+        tho, tvo, go = th0.copy(), tv0.copy(), g0.copy()
+        acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, eps, 5)
+        rate = np.minimum(np.exp(np.minimum(hc - hp, 0)), 1)
+        decided = np.abs(u - rate) > (1e-8 if tag == "f64" else 5e-3)
+        np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+        np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=tol * 10, atol=tol * 100)
+        np.testing.assert_allclose(out["h_cur"].cpu().numpy(), hc, rtol=tol * 10, atol=tol * 100)
+        same = out["accepted"].cpu().numpy() == acc
+        np.testing.assert_allclose(th.cpu().numpy()[same], tho[same], rtol=tol * 10, atol=tol)
+        np.testing.assert_allclose(tv.cpu().numpy()[same], tvo[same], rtol=tol * 5, atol=tol * 20)
+    th, tv, gg = _t(th0, dt).clone(), t.clone(), g.clone()
+    out = pl.mala_step(th, tv, gg, 0.004, z=_t(p0, dt), u=_t(u, dt))
+    f8 = lambda a_: np.asarray(a_, dtype=np.float64).copy()
+    co64 = COracle(dims, acts, lik, co.x.astype(np.float64), co.y.astype(np.float64), co.mu.astype(np.float64),
+                   co.sigma.astype(np.float64), dtype=np.float64, nthreads=4)
+    acc, lr = co64.mala_draw(f8(th0), f8(tv0), f8(g0), f8(p0), f8(u), 0.004)
+    ltol = (1e-9 if tag == "f64" else 2e-3) * np.maximum(1.0, np.abs(lr))
+    assert (np.abs(out["log_rate"].cpu().numpy() - lr) <= ltol).all()
+    decided = np.abs(np.log(f8(u)) - lr) > ltol
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+    th, tv = _t(th0, dt).clone(), t.clone()
+    out = pl.mh_step(th, tv, torch.full((P,), 0.02, dtype=dt), z=_t(p0, dt), u=_t(u, dt))
+    acc, lr = co64.mh_draw(f8(th0), f8(tv0), f8(p0), f8(u), 0.02)
+    ltol = (1e-9 if tag == "f64" else 2e-3) * np.maximum(1.0, np.abs(lr))
+    assert (np.abs(out["log_rate"].cpu().numpy() - lr) <= ltol).all()
+    decided = np.abs(np.log(f8(u)) - lr) > ltol
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_fused16_philox_and_run_blocks(tag):
+    """In-kernel Philox == the same streams passed in, bit for bit; ey_hmc_run / ey_mala_run / ey_mh_run of n iterations ==
+    n single steps, records included; more chains than resident waves; the generic kernel agrees on accept flags."""
+    pl, co, rng, npdt, dt, P = _setup([4, 32, 32, 3], [2, 1, 0], 1, tag, 60)
+    C = 700 if tag == "f32" else 300
+    th0 = 0.2 * pl.philox_normal(C, seed=9, it=0)
+    t0, g0 = pl.log_target_grad(th0)
+    a = [th0.clone(), t0.clone(), g0.clone()]
+    b = [th0.clone(), t0.clone(), g0.clone()]
+    oa = pl.hmc_step(*a, 0.03, 6, seed=21, it=5, chain_offset=1000)
+    ob = pl.hmc_step(*b, 0.03, 6, p0=pl.philox_normal(C, 21, 5, 1000), u=pl.philox_uniform(C, 21, 5, 1000))
+    for k in ("accepted", "rate", "h_cur", "h_prop"):
+        assert torch.equal(oa[k], ob[k]), k
+    for x_, y_ in zip(a, b):
+        assert torch.equal(x_, y_)
+    assert 0 < oa["accepted"].float().mean() < 1
+    n = 4
+    for kind in ("hmc", "mala", "mh"):
+        a = [th0.clone(), t0.clone(), g0.clone()]
+        b = [th0.clone(), t0.clone(), g0.clone()]
+        smp, tgt, acr = pl.empty(n, C, P), pl.empty(n, C), pl.empty(n, C, dtype=torch.uint8)
+        cnt = torch.zeros(C, dtype=torch.int32, device=DEV)
+        scale = torch.full((P,), 0.01, dtype=dt)
+        if kind == "hmc":
+            pl.hmc_run(*a, 0.03, 6, n, seed=3, it=10, samples=smp, targets=tgt, accepted_rec=acr, accept_count=cnt)
+        elif kind == "mala":
+            pl.mala_run(*a, 0.002, n, seed=3, it=10, samples=smp, targets=tgt, accepted_rec=acr, accept_count=cnt)
+        else:
+            pl.mh_run(a[0], a[1], scale, n, seed=3, it=10, samples=smp, targets=tgt, accepted_rec=acr, accept_count=cnt)
+        total = torch.zeros(C, dtype=torch.int32, device=DEV)
+        for i in range(n):
+            if kind == "hmc":
+                o = pl.hmc_step(*b, 0.03, 6, seed=3, it=10 + i)
+            elif kind == "mala":
+                o = pl.mala_step(*b, 0.002, seed=3, it=10 + i)
+            else:
+                o = pl.mh_step(b[0], b[1], scale, seed=3, it=10 + i)
+            assert torch.equal(smp[i], b[0]) and torch.equal(tgt[i], b[1]) and torch.equal(acr[i], o["accepted"]), (kind, i)
+            total += o["accepted"].to(torch.int32)
+        assert torch.equal(cnt, total) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        if kind != "mh":
+            assert torch.equal(a[2], b[2])
+
+
+def test_fused16_serves_the_reference_models_in_f64():
+    """G2 / G3 of the reference for MLP(4-32-32-3) in f64 -- its default dtype -- now run on the f64 matrix cores."""
+    from eeyore_amd.plan import Plan
+    n = 0
+    for name, rec in groups(load("g2_grads.npz")).items():
+        if not name.startswith("f64/mlp432323"):
+            continue
+        pl = Plan(rec["dims"].tolist(), [1, 1, 1], rec["acts"].tolist(), int(rec["lik"]), torch.float64, DEV)
+        pl.set_data(_t(rec["x"], torch.float64), _t(rec["y"], torch.float64))
+        pl.set_prior(torch.tensor(rec["prior_mu"]), torch.tensor(rec["prior_sigma"]))
+        assert pl.kernel == "fused16"
+        temp = None if np.isnan(rec["temperature"]) else float(rec["temperature"])
+        t, g = pl.log_target_grad(_t(rec["theta"], torch.float64), temp=temp)
+        np.testing.assert_allclose(t.cpu().numpy(), rec["log_target"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(g.cpu().numpy(), rec["grad"], rtol=1e-10, atol=1e-11)
+        n += 1
+    assert n >= 2
+    m = 0
+    for name, rec in groups(load("g3_leapfrog.npz")).items():
+        if not name.startswith("f64/mlp432323"):
+            continue
+        pl = Plan(rec["dims"].tolist(), [1, 1, 1], rec["acts"].tolist(), int(rec["lik"]), torch.float64, DEV)
+        pl.set_data(_t(rec["x"], torch.float64), _t(rec["y"], torch.float64))
+        pl.set_prior(torch.tensor(rec["prior_mu"]), torch.tensor(rec["prior_sigma"]))
+        th, p = _t(rec["theta0"], torch.float64)[None].clone(), _t(rec["p0"], torch.float64)[None].clone()
+        t, g = pl.leapfrog(th, p, float(rec["step"]), int(rec["L"]))
+        np.testing.assert_allclose(th[0].cpu().numpy(), rec["thetaL"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(p[0].cpu().numpy(), rec["pL"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(t.item(), rec["target"], rtol=1e-9)
+        m += 1
+    assert m >= 2

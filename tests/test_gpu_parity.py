@@ -140,7 +140,7 @@ def test_f32_draws_against_the_reference_traces(fixture, kind):
     margin (taken from the f64 evaluation, which the tests above pin bit for bit) exceeds the stated f32 tolerance, the
     new state within f32 tolerance, and the draws inside the margin counted."""
     f32 = torch.float32
-    total = in_margin = 0
+    total = in_margin = saturated = 0
     for name, rec in groups(load(fixture)).items():
         p64, p32 = _plan(rec), _plan(rec, f32)
         k = "hmc" if kind == "hmc" else ("mala" if name.startswith("mala") else "mh")
@@ -171,11 +171,18 @@ def test_f32_draws_against_the_reference_traces(fixture, kind):
             if not np.isfinite(v64) or margin <= F32_DECISION_TOL * max(1.0, s64):
                 in_margin += 1
                 continue
+            if not np.isfinite(v32):
+                # a sigmoid that rounds to exactly 0 or 1 in f32 (|logit| > ~17: the N(0, 100) prior of config 1 allows
+                # it) makes the reference's naive BCE logs NaN (eeyore/stats/loss.py:2), which rejects (hmc.py:148): the
+                # f32 behaviour of the reference itself, not of this kernel (test_saturated_bce_is_nan_and_rejected)
+                assert a32 == 0
+                saturated += 1
+                continue
             assert a32 == a64, (name, it, margin)
             scale = max(1.0, float(np.abs(rec["sample"][it]).max()))
             np.testing.assert_allclose(th32[0].cpu().numpy(), rec["sample"][it], rtol=5e-4, atol=5e-4 * scale)
             np.testing.assert_allclose(tv32.item(), rec["target_val"][it], rtol=5e-4, atol=5e-3)
-    assert total >= 150 and in_margin <= 0.03 * total, (total, in_margin)
+    assert total >= 150 and in_margin <= 0.03 * total and saturated <= 0.05 * total, (total, in_margin, saturated)
 
 
 def test_g6_pt_swap_decide():
@@ -493,13 +500,15 @@ def test_g9_tuned_burn_in_replays_the_reference():
         x, y = next(iter(s.dataloader))
         for i in range(n):
             it["i"] = i
-            np.testing.assert_allclose(s.step, rec["step"][i], rtol=1e-9, err_msg=f"{name} iteration {i}")
+            # (the tuner is fed the kernel's acceptance rates: their ~1e-11 differences from the reference's are multiplied
+            # by sqrt(t) / gamma = up to 130 in the dual-averaging recurrence)
+            np.testing.assert_allclose(s.step, rec["step"][i], rtol=1e-7, err_msg=f"{name} iteration {i}")
             assert s.num_steps == int(rec["num_steps"][i]), (name, i)
             s.draw(x, y, savestate=i >= burn)
             assert s.current["accepted"] == int(rec["accepted"][i]), (name, i)
             np.testing.assert_allclose(s.current["sample"].cpu().numpy(), rec["sample"][i], rtol=1e-7, atol=1e-9)
             s.counter.increment_idx()
-        np.testing.assert_allclose(s.step, float(rec["final_step"]), rtol=1e-9)
+        np.testing.assert_allclose(s.step, float(rec["final_step"]), rtol=1e-7)
         assert s.num_steps == int(rec["final_num_steps"])
         assert len(s.get_chain()) == n - burn
 
@@ -1206,7 +1215,7 @@ def test_inse_univariate_kernel_on_the_reference_chains():
     from eeyore_amd.stats import batched
     from oracle import diagnostics_oracle as do
     z = load("g8_univariate_stats.npz")
-    x = z["chains"]                                    # [4, 999, 3]
+    x = z["chains"]                                    # [4, 1000, 3]
     stacked = np.ascontiguousarray(np.transpose(x, (1, 0, 2)))  # [n, C, P] as a chain buffer stores it
     r = batched.inse_univariate(_t(stacked))
     np.testing.assert_allclose(r["sig2"].cpu().numpy(), z["inse"], rtol=1e-10)
@@ -1214,7 +1223,7 @@ def test_inse_univariate_kernel_on_the_reference_chains():
     r2 = batched.inse_univariate(_t(stacked[:200]))
     np.testing.assert_allclose(r2["sig2"].cpu().numpy(), z["inse_first200"], rtol=1e-10)
     ess = batched.ess(_t(stacked)).cpu().numpy()
-    np.testing.assert_allclose(ess, 999 * z["var"] / z["inse"], rtol=1e-10)
+    np.testing.assert_allclose(ess, x.shape[1] * z["var"] / z["inse"], rtol=1e-10)
     for i in range(4):
         for j in range(3):
             assert r["pairs"][i, j].item() == do.inse_univariate(x[i, :, j])[1]
@@ -1417,3 +1426,142 @@ def test_three_samplers_agree_on_the_posterior():
         mb, sb, _, _ = results[b]
         z = np.abs(ma - mb) / np.sqrt(sa ** 2 + sb ** 2)
         assert z.max() < 5.0, (a, b, z.max())
+
+
+# --------------------------------------------------------------------------------------------- batches that change
+def test_set_data_is_not_fooled_by_recycled_temporaries():
+    """Two same-shaped temporaries (the second usually gets the first one's address back from the caching allocator)
+    must give two different log-targets, each equal to the oracle's on its own data."""
+    from oracle import mlp_oracle as orc
+    rec = groups(load("g2_grads.npz"))["f64/mlp2321/s1/tNone"]
+    pl = _plan(rec)
+    spec = orc.Spec(rec["dims"].tolist(), rec["acts"].tolist(), int(rec["lik"]), mu=rec["prior_mu"], sigma=rec["prior_sigma"])
+    th = _t(rec["theta"][:1])
+    X, Y = _t(rec["x"]), _t(rec["y"])
+    got = []
+    for i in (1.0, 3.0):
+        pl.set_data(X * i, Y * 1.0)  # temporaries: freed as soon as the call returns
+        got.append(pl.log_target_grad(th)[0].item())
+        np.testing.assert_allclose(got[-1], orc.log_target(spec, rec["theta"][0], rec["x"] * i, rec["y"]), rtol=1e-12)
+    assert got[0] != got[1]
+    # in-place edits bump the tensor's version and are seen too
+    Z = X.clone()
+    pl.set_data(Z, Y)
+    a = pl.log_target_grad(th)[0].item()
+    Z.mul_(2.0)
+    pl.set_data(Z, Y)
+    assert pl.log_target_grad(th)[0].item() != a
+
+
+def test_mfma32_serves_again_after_an_oversized_batch():
+    rec, pl = _cfg3_plan()
+    assert pl.kernel == "mfma32"
+    _, big = _cfg3_plan(N=800)  # 25 row tiles: one more than the kernel's LDS image holds
+    assert big.kernel != "mfma32"
+    th = 0.1 * big.philox_normal(3, seed=1, it=0)
+    t_big, _ = big.log_target_grad(th)
+    big.set_data(_t(rec["x"], torch.float32), _t(rec["y"], torch.float32))
+    assert big.kernel == "mfma32"
+    t_small, g_small = big.log_target_grad(th)
+    t_ref, g_ref = pl.log_target_grad(th)
+    assert torch.equal(t_small, t_ref) and torch.equal(g_small, g_ref) and not torch.equal(t_big, t_small)
+
+
+def test_minibatch_hmc_with_a_shuffling_loader_matches_the_oracle():
+    """HMC.run over a DataLoader(shuffle=True) with several batches per epoch (hmc.py:129-131: target and gradient are
+    re-evaluated on every new batch): the batches the sampler was handed and the randomness it drew are recorded and
+    replayed through the numpy oracle."""
+    from torch.utils.data import DataLoader
+    from eeyore_amd.chains import ChainList
+    from eeyore_amd.datasets import XYDataset
+    from eeyore_amd.samplers import HMC
+    from oracle import mlp_oracle as orc
+    rec = dict(groups(load("g4_hmc_traces.npz"))["mlp433"])
+    model = _model_for(rec)
+    data = XYDataset(_t(rec["x"]), _t(rec["y"]))
+    loader = DataLoader(data, batch_size=50, shuffle=True)  # 3 batches per epoch
+    torch.manual_seed(11)
+    s = HMC(model, theta0=_t(rec["theta0"]), dataloader=loader, step=0.05, num_steps=6, chain=ChainList())
+    rng = np.random.default_rng(2)
+    n_iter = 4 * 3
+    zs, us, batches = rng.standard_normal((n_iter, model.num_params())), rng.random(n_iter), []
+    it = {"i": 0}
+    s._randn = lambda C, P: _t(zs[it["i"]])[None]
+    s._rand = lambda C: _t([us[it["i"]]])
+    draw = s.draw
+
+    def recording_draw(x, y, savestate=False):
+        batches.append((x.cpu().numpy().copy(), y.cpu().numpy().copy()))
+        draw(x, y, savestate=savestate)
+        it["i"] += 1
+
+    s.draw = recording_draw
+    s.run(num_epochs=4, num_burnin_epochs=1)
+    assert len(batches) == n_iter and s.counter.num_batches == 3
+    assert not np.array_equal(batches[0][0], batches[3][0])  # shuffled: epochs see different batches
+    spec = orc.Spec(rec["dims"].tolist(), rec["acts"].tolist(), int(rec["lik"]), mu=rec["prior_mu"], sigma=rec["prior_sigma"])
+    th, kept, acc = rec["theta0"].copy(), [], []
+    for i, (x, y) in enumerate(batches):
+        tv, gv = orc.upto_grad_log_target(spec, th, x, y)  # hmc.py:129-131
+        new, info = orc.hmc_draw(spec, dict(sample=th, target_val=tv, grad_val=gv), zs[i], us[i], x, y, 0.05, 6)
+        th = new["sample"]
+        if i >= 3:
+            kept.append(th.copy()); acc.append(info["accepted"])
+    ch = s.get_chain()
+    assert ch.vals["accepted"] == acc and 0 < sum(acc)
+    np.testing.assert_allclose(ch.get_samples().cpu().numpy(), np.array(kept), rtol=1e-8, atol=1e-10)
+
+
+def test_changing_the_batch_every_iteration_costs_little():
+    """ey_plan_set_data is asynchronous (device copies + two small kernels, no allocation): a new batch before every
+    HMC iteration of 4096 chains must cost < 5 % over the fixed-batch iteration."""
+    rec, pl = _cfg3_plan()
+    C = 4096
+    th = 0.1 * pl.philox_normal(C, seed=2, it=0)
+    t, g = pl.log_target_grad(th)
+    X, Y = _t(rec["x"], torch.float32), _t(rec["y"], torch.float32)
+    perm = torch.randperm(X.shape[0], device=DEV)
+    alt = [(X, Y), (X[perm].contiguous(), Y[perm].contiguous())]
+    out = dict(accepted=pl.empty(C, dtype=torch.uint8), rate=pl.empty(C), h_cur=pl.empty(C), h_prop=pl.empty(C))
+
+    def run(n, switch):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for i in range(n):
+            if switch:
+                pl.set_data(*alt[i & 1])
+            pl.hmc_step(th, t, g, 0.02, 20, seed=3, it=i, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    run(30, True)
+    fixed = min(run(30, False) for _ in range(3))
+    moving = min(run(30, True) for _ in range(3))
+    assert moving < 1.05 * fixed, (fixed, moving)
+
+
+def test_generic_run_with_attached_moments_fails_before_it_advances_the_chains():
+    from eeyore_amd.distributed import ChainStats
+    rec = groups(load("g4_hmc_traces.npz"))["mlp2321"]
+    pl = _plan(rec)
+    assert pl.kernel == "generic"
+    C = 6
+    th = 0.3 * pl.philox_normal(C, seed=1, it=0)
+    t, g = pl.log_target_grad(th)
+    before = [th.clone(), t.clone(), g.clone()]
+    st = ChainStats(C, pl.P, DEV)
+    st.attach(pl)
+    with pytest.raises(RuntimeError):
+        pl.hmc_run(th, t, g, 0.3, 5, 4, seed=2, it=1)  # no records: the moments cannot be replayed
+    with pytest.raises(RuntimeError):
+        pl.mala_run(th, t, g, 0.05, 4, seed=2, it=1)
+    assert torch.equal(th, before[0]) and torch.equal(t, before[1]) and torch.equal(g, before[2])
+    assert float(st.s1.abs().sum()) == 0.0
+    # with records the same call goes through and the moments equal the sum over the recorded states
+    smp = pl.empty(4, C, pl.P); acc = pl.empty(4, C, dtype=torch.uint8)
+    pl.hmc_run(th, t, g, 0.3, 5, 4, seed=2, it=1, samples=smp, accepted_rec=acc)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(st.s1.cpu().numpy(), smp.sum(0).cpu().numpy(), rtol=1e-13)
+    pl.detach_moments()

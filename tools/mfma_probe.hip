@@ -26,7 +26,38 @@ __global__ void k16(const float* a, const float* b, float* d) {
   for (int r = 0; r < 4; ++r) d[l * 4 + r] = c[r];
 }
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__global__ void k16d(const double* a, const double* b, double* d) {
+  int l = threadIdx.x;
+  f64x4 c = {0, 0, 0, 0};
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[l], b[l], c, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) d[l * 4 + r] = c[r];
+}
+
+static void probe_f64() {
+  double *a, *b, *d;
+  hipMalloc(&a, 512); hipMalloc(&b, 512); hipMalloc(&d, 64 * 4 * 8);
+  std::vector<double> ha(64), hb(64), hd(256), hd2(256);
+  for (int g = 0; g < 4; ++g) {
+    for (int l = 0; l < 64; ++l) { ha[l] = ((l >> 4) == g) ? (l + 1) : 0; hb[l] = ((l >> 4) == g) ? 1 : 0; }
+    hipMemcpy(a, ha.data(), 512, hipMemcpyHostToDevice); hipMemcpy(b, hb.data(), 512, hipMemcpyHostToDevice);
+    k16d<<<1, 64>>>(a, b, d); hipMemcpy(hd.data(), d, 2048, hipMemcpyDeviceToHost);
+    for (int l = 0; l < 64; ++l) { ha[l] = ((l >> 4) == g) ? 1 : 0; hb[l] = ((l >> 4) == g) ? (l + 1) : 0; }
+    hipMemcpy(a, ha.data(), 512, hipMemcpyHostToDevice); hipMemcpy(b, hb.data(), 512, hipMemcpyHostToDevice);
+    k16d<<<1, 64>>>(a, b, d); hipMemcpy(hd2.data(), d, 2048, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int l = 0; l < 64; ++l)
+      for (int r = 0; r < 4; ++r) {
+        int la = (int)hd[l * 4 + r] - 1, lb = (int)hd2[l * 4 + r] - 1;
+        int row = 4 * (l >> 4) + r;
+        if (la != row + 16 * g || lb != (l & 15) + 16 * g) { if (bad < 4) printf("  f64 16x16x4 MISMATCH lane %d reg %d: A %d B %d\n", l, r, la, lb); ++bad; }
+      }
+    printf("f64 16x16x4 k-slot %d mismatches vs (row=4*(lane>>4)+reg, col=lane&15): %d\n", g, bad);
+  }
+}
+
 int main() {
+  probe_f64();
   float *a, *b, *d;
   hipMalloc(&a, 256); hipMalloc(&b, 256); hipMalloc(&d, 64 * 16 * 4);
   std::vector<float> ha(64), hb(64), hd(64 * 16), hd2(64 * 16);

@@ -30,6 +30,28 @@ __global__ __launch_bounds__(256) void k_mfma_peak(float* out, int iters) {
   if (s == 12345.678f) out[0] = s;  // never true: keeps the accumulators live
 }
 
+// 16x16x4 tiles (the fused kernel for other widths and for f64 is built on them): T = float or double
+typedef double d4v __attribute__((ext_vector_type(4)));
+template <typename T, int NACC>
+__global__ __launch_bounds__(256) void k_mfma16_peak(T* out, int iters) {
+  typedef T v4 __attribute__((ext_vector_type(4)));
+  v4 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) acc[a] = (v4){0, 0, 0, 0};
+  T a = threadIdx.x * (T)1e-3, b = blockIdx.x * (T)1e-3 + (T)1;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      if constexpr (sizeof(T) == 8) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+      else acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k], 0, 0, 0);
+    }
+  }
+  T s = 0;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  if (s == (T)12345.678) out[0] = s;
+}
+
 __global__ __launch_bounds__(256) void k_read(const f4v* __restrict__ x, size_t n, float* out) {
   f4v s = {0, 0, 0, 0};
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -73,6 +95,19 @@ int main() {
   report("mfma 32x32x2 f32, 1 acc", 1, time_ms([&] { k_mfma_peak<1><<<blocks, 256>>>(out, iters); }, 5), blocks);
   report("mfma 32x32x2 f32, 2 acc", 2, time_ms([&] { k_mfma_peak<2><<<blocks, 256>>>(out, iters); }, 5), blocks);
   report("mfma 32x32x2 f32, 4 acc", 4, time_ms([&] { k_mfma_peak<4><<<blocks, 256>>>(out, iters); }, 5), blocks);
+
+  auto report16 = [&](const char* name, int nacc, float ms, int nblocks) {
+    double flops = 2.0 * 16 * 16 * 4 * (double)nacc * iters * 4 /*waves*/ * nblocks;
+    printf("%-28s %8.3f ms  %7.1f TFLOP/s\n", name, ms, flops / ms * 1e-9);
+  };
+  double* outd;
+  CK(hipMalloc(&outd, 64));
+  report16("mfma 16x16x4 f32, 1 acc", 1, time_ms([&] { k_mfma16_peak<float, 1><<<blocks, 256>>>(out, iters); }, 5), blocks);
+  report16("mfma 16x16x4 f32, 4 acc", 4, time_ms([&] { k_mfma16_peak<float, 4><<<blocks, 256>>>(out, iters); }, 5), blocks);
+  report16("mfma 16x16x4 f64, 1 acc", 1, time_ms([&] { k_mfma16_peak<double, 1><<<blocks, 256>>>(outd, iters); }, 5), blocks);
+  report16("mfma 16x16x4 f64, 4 acc", 4, time_ms([&] { k_mfma16_peak<double, 4><<<blocks, 256>>>(outd, iters); }, 5), blocks);
+  report16("mfma 16x16x4 f64, 4 acc, 1 wave/SIMD", 4,
+           time_ms([&] { k_mfma16_peak<double, 4><<<blocks / 2, 256>>>(outd, iters); }, 5), blocks / 2);
 
   size_t bytes = (size_t)4 << 30, n = bytes / 16;
   f4v *x, *y;

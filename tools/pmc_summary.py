@@ -24,7 +24,14 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
     print(f"matrix-pipe busy fraction    {mean['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (mean['GRBM_GUI_ACTIVE'] / 8):18.3f}")
 if len(sys.argv) > 3 and "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     ipl = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-    json.dump({"kernel": "k_mfma32<0,8,12,true> (HMC trajectory)", "FETCH_SIZE_KB": mean["FETCH_SIZE"],
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ("ey_mfma32.hip", "ey_common.h"):  # as bench.py's kernel_source_hash()
+        h.update(open(os.path.join(root, "eeyore_amd", "csrc", name), "rb").read())
+    json.dump({"kernel": "k_mfma32<0,8,12,true> (HMC trajectory)", "kernel_source_sha256": h.hexdigest(),
+               "FETCH_SIZE_KB": mean["FETCH_SIZE"],
                "WRITE_SIZE_KB": mean["WRITE_SIZE"], "dispatches": n, "iterations_per_launch": ipl,
                "source": f"tools/pmc_passes.sh (rocprofv3 --pmc, separate passes), 4096 chains x L=20 x {ipl} "
                          f"iterations per dispatch"},
