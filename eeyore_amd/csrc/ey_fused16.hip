@@ -4,7 +4,7 @@
 // BCE nets, tests/test_binary_classif_mlp2321_log_lik.py) and the reference's default dtype (eeyore/models/model.py:7).
 // CE-sum on logits or BCE-sum on a sigmoid output (eeyore/constants/constants.py:15-18), hidden activations sigmoid /
 // tanh / relu, every layer with a bias.  Same structure as ey_mfma32.hip: one wavefront per chain in a persistent
-// workgroup per CU, the whole draw inside one launch, theta and the gradient in registers, the momentum in LDS.
+// workgroup per CU, the whole draw inside one launch, theta, momentum and gradient in registers.
 //
 // Reference semantics restated (paths relative to papamarkou/eeyore): MLP.forward eeyore/models/mlp.py:45-50,
 // losses eeyore/constants/constants.py:15-18 and eeyore/stats/loss.py:1-11 (naive BCE logs kept), log_target
@@ -102,12 +102,24 @@ struct Nm<double> {
   static __device__ __forceinline__ double tanh(double v) { return ::tanh(v); }
   static __device__ __forceinline__ double sqrt(double v) { return ::sqrt(v); }
 };
-// the same formulas as the generic kernels (ey_generic.hip): both families must agree with the oracle
+// sigmoid and tanh.  f64: the library functions, as the generic kernels (1e-10 parity with the reference's fp64).  f32:
+// one v_exp_f32 and one v_rcp_f32 per element, as ey_mfma32.hip (an IEEE division is ten vector instructions, and f32
+// MFMA shares the vector ALUs with them); both are accurate to ~1 ulp, far inside the stated 2e-4.
+template <typename T>
+__device__ __forceinline__ T f16_sigmoid(T g) {
+  if constexpr (sizeof(T) == 4) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+  else return T(1) / (T(1) + Nm<T>::exp(-g));
+}
+template <typename T>
+__device__ __forceinline__ T f16_tanh(T g) {
+  if constexpr (sizeof(T) == 4) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * g)) - 1.0f;
+  else return Nm<T>::tanh(g);
+}
 template <typename T>
 __device__ __forceinline__ T f16_act(int code, T g) {
   switch (code) {
-    case EY_ACT_SIGMOID: return T(1) / (T(1) + Nm<T>::exp(-g));
-    case EY_ACT_TANH: return Nm<T>::tanh(g);
+    case EY_ACT_SIGMOID: return f16_sigmoid<T>(g);
+    case EY_ACT_TANH: return f16_tanh<T>(g);
     case EY_ACT_RELU: return g > T(0) ? g : T(0);
     default: return g;
   }
@@ -121,6 +133,48 @@ __device__ __forceinline__ T f16_dact(int code, T h) {
     default: return T(1);
   }
 }
+// the activation of whole tiles with the (wave-uniform) switch outside the element loop: one straight-line body per
+// activation instead of a three-way select around every element
+template <typename T, int MT>
+__device__ __forceinline__ void f16_act_tiles(int code, typename V4<T>::type (&h)[MT]) {
+  if (code == EY_ACT_SIGMOID) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[m][r] = f16_sigmoid<T>(h[m][r]);
+  } else if (code == EY_ACT_TANH) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[m][r] = f16_tanh<T>(h[m][r]);
+  } else if (code == EY_ACT_RELU) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[m][r] = h[m][r] > T(0) ? h[m][r] : T(0);
+  }
+}
+// d *= act'(h) for whole tiles
+template <typename T, int MT>
+__device__ __forceinline__ void f16_dact_tiles(int code, typename V4<T>::type (&d)[MT], const typename V4<T>::type (&h)[MT]) {
+  if (code == EY_ACT_SIGMOID) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[m][r] *= h[m][r] * (T(1) - h[m][r]);
+  } else if (code == EY_ACT_TANH) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[m][r] *= T(1) - h[m][r] * h[m][r];
+  } else if (code == EY_ACT_RELU) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[m][r] *= h[m][r] > T(0) ? T(1) : T(0);
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ T f16_wsum(T v) {
 #pragma unroll
@@ -156,9 +210,9 @@ struct F16Cfg {
   static constexpr int O_B0 = O_W2T + MT * 64;          // [H]
   static constexpr int O_B1 = O_B0 + H;                 // [H]
   static constexpr int O_D2 = O_B1 + H;                 // [4][16] delta2[o][row]
-  static constexpr int O_P = O_D2 + 64;                 // [P]: the momentum (HMC) / the standard normals (MALA, MH)
-  static constexpr int PMAX = ((H * H + 14 * H + 4) + 3) & ~3;  // d0 <= 8, dK <= 4
-  static constexpr int WAVE_ELEMS = O_P + PMAX;
+  static constexpr int WAVE_ELEMS = O_D2 + 64;
+  // the N(0,1) stream of a draw is staged in [O_W1A, O_W0A) between evaluations: P <= H^2 + 14 H + 4 <= H^2 + 40 H
+  static_assert(H * H + 14 * H + 4 <= O_W0A, "the staging area must hold P normals");
 };
 
 struct F16Slot {
@@ -167,8 +221,8 @@ struct F16Slot {
 };
 // canonical element k of lane (c, g): its index in theta, whether this lane holds anything there, and whether this
 // lane's copy is the one that enters sums over parameters
-template <int H, typename T>
-__device__ __forceinline__ F16Slot f16_slot(int k, const F16Args<T>& a, int c, int g, int lane) {
+template <int H, typename T, typename A>
+__device__ __forceinline__ F16Slot f16_slot(int k, const A& a, int c, int g, int lane) {
   typedef F16Cfg<H> K;
   if (k < K::S_W0) {
     const int r = k & 3, n = (k >> 2) % K::MT, mo = (k >> 2) / K::MT;
@@ -194,8 +248,8 @@ __device__ __forceinline__ F16Slot f16_slot(int k, const F16Args<T>& a, int c, i
 // stage the operand images of the position `th` in this wave's LDS region (the zero padding of the images was
 // written once at kernel start and is never overwritten).  An element W[out][in] this lane holds goes where the lane
 // that feeds it to the product will read it: A operand lane (i & 15, k-slot), one image row of 64 per k-step.
-template <typename T, int H>
-__device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>::NREG], const F16Args<T>& a, int c, int g) {
+template <typename T, int H, typename A>
+__device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>::NREG], const A& a, int c, int g) {
   typedef F16Cfg<H> K;
   typedef Lay<T> L;
   // the k-step register rk and k-slot gk at which input feature (16n +) c enters a product whose B operand is a T tile
@@ -238,8 +292,8 @@ __device__ __forceinline__ v4<T> f16_ld4(const T* p) {
 // log-target and gradient of the position whose images are staged in lw; returns the (tempered) log-target.
 // GRAD (wave-uniform) = false: the value only (random-walk MH).  Inlined at its three call sites: theta and the gradient
 // are register arrays, which a call would force into scratch memory.
-template <typename T, int H>
-__device__ __forceinline__ T f16_eval(const F16Args<T>& a, T* lw, const T (&th)[F16Cfg<H>::NREG],
+template <typename T, int H, typename A>
+__device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>::NREG],
                                       T (&gr)[F16Cfg<H>::NREG], const bool GRAD, bool has_temp, T temp, int c, int g,
                                       int lane, T* lik_out = nullptr, T* prior_out = nullptr) {
   typedef F16Cfg<H> K;
@@ -273,12 +327,14 @@ __device__ __forceinline__ T f16_eval(const F16Args<T>& a, T* lw, const T (&th)[
       v4<T> acc = f16_ld4(lw + K::O_B0 + 16 * m + 4 * g);
       acc = mfma16<T>(lw[K::O_W0A + (m * 2) * 64 + lane], xb[0], acc);
       if (a.ks0 > 1) acc = mfma16<T>(lw[K::O_W0A + (m * 2 + 1) * 64 + lane], xb[1], acc);
+      H0[m] = acc;
+    }
+    f16_act_tiles<T, MT>(a.act0, H0);
+    if (GRAD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) H0[m][r] = f16_act<T>(a.act0, acc[r]);
-      if (GRAD) {
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) lw[K::O_TB1 + (16 * m + L::fi(g, r)) * F16_TS + pc] = H0[m][r];
-      }
     }
     // ---- F1: H1^T = act1(W1 H0^T + b1)
 #pragma unroll
@@ -288,12 +344,14 @@ __device__ __forceinline__ T f16_eval(const F16Args<T>& a, T* lw, const T (&th)[
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc = mfma16<T>(lw[K::O_W1A + ((mo * MT + m) * 4 + r) * 64 + lane], H0[m][r], acc);
+      H1[mo] = acc;
+    }
+    f16_act_tiles<T, MT>(a.act1, H1);
+    if (GRAD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) H1[mo][r] = f16_act<T>(a.act1, acc[r]);
-      if (GRAD) {
+      for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
         for (int r = 0; r < 4; ++r) lw[K::O_TB0 + (16 * mo + L::fi(g, r)) * F16_TS + pc] = H1[mo][r];
-      }
     }
     // ---- output layer: logits[o][row c] = W2 H1^T + b2 comes out in register r of lane group g with fi(g, r) = o;
     // every lane then fetches the dK logits of its row c, so all four groups carry the same softmax
@@ -362,11 +420,8 @@ __device__ __forceinline__ T f16_eval(const F16Args<T>& a, T* lw, const T (&th)[
     const T d2b = g == 0 ? d2all[0] : (g == 1 ? d2all[1] : (g == 2 ? d2all[2] : d2all[3]));  // delta2[row c][o = g]
     v4<T> D1[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      D1[m] = mfma16<T>(lw[K::O_W2T + m * 64 + lane], d2b, v4<T>{0, 0, 0, 0});
-#pragma unroll
-      for (int r = 0; r < 4; ++r) D1[m][r] *= f16_dact<T>(a.act1, H1[m][r]);
-    }
+    for (int m = 0; m < MT; ++m) D1[m] = mfma16<T>(lw[K::O_W2T + m * 64 + lane], d2b, v4<T>{0, 0, 0, 0});
+    f16_dact_tiles<T, MT>(a.act1, D1, H1);
     // ---- dW2[o][f] += sum_n delta2[n][o] H1[n][f]           (contracts over rows: U tiles)
     {
       const v4<T> d2u = f16_ld4(lw + K::O_D2 + (c & 3) * 16 + 4 * g);  // delta2[rows fi(g, .)][o = c] for c < 4 (zero for o >= dK)
@@ -393,9 +448,9 @@ __device__ __forceinline__ T f16_eval(const F16Args<T>& a, T* lw, const T (&th)[
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc = mfma16<T>(D1[m][r], th[(m * MT + n) * 4 + r], acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d0u[n][r] = acc[r] * f16_dact<T>(a.act0, h0u[n][r]);
+      d0u[n] = acc;
     }
+    f16_dact_tiles<T, MT>(a.act0, d0u, h0u);
     // ---- dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
 #pragma unroll
     for (int mo = 0; mo < MT; ++mo) {
@@ -442,7 +497,7 @@ __device__ __forceinline__ T f16_eval(const F16Args<T>& a, T* lw, const T (&th)[
   // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
   T qsum = T(0);
   F16_EACH(k) {
-    const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+    const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
     if (s.valid) {
       const T d = th[k] - a.mu[s.idx];
       const T iv = a.inv_var[s.idx];
@@ -465,8 +520,8 @@ __device__ __forceinline__ T f16_eval(const F16Args<T>& a, T* lw, const T (&th)[
 }
 
 // One chain of one launch: everything between reading theta and writing the accepted state back.
-template <typename T, int H>
-__device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const int64_t chain, const int it, const int c,
+template <typename T, int H, typename A>
+__device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t chain, const int it, const int c,
                                               const int g, const int lane) {
   typedef F16Cfg<H> K;
   // later iterations of one launch read what this wave's lanes wrote at the end of the previous one
@@ -475,7 +530,6 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
   const int P = a.P;
   T* thg = a.theta + chain * P;
   T* grg = a.grad + chain * P;
-  T* lp = lw + K::O_P;  // the momentum / the normals, indexed like theta
   const bool has_temp = a.temp != nullptr;
   const T temp = has_temp ? a.temp[chain] : T(1);
   const T eps = a.step_vec ? a.step_vec[chain] : a.step;
@@ -483,7 +537,7 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
 
   T th[K::NREG], gr[K::NREG];
   F16_EACH(k) {
-    const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+    const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
     th[k] = s.valid ? thg[s.idx] : T(0);
     gr[k] = T(0);
   }
@@ -494,7 +548,7 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
     const T t = f16_eval<T, H>(a, lw, th, gr, a.grad != nullptr, has_temp, temp, c, g, lane, &lik, &prior);
     if (a.grad) {
       F16_EACH(k) {
-        const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+        const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
         if (s.counts) grg[s.idx] = gr[k];
       }
     }
@@ -506,12 +560,14 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
     return;
   }
 
-  // the chain's N(0,1) stream (or the caller's) into LDS, indexed like theta
-  const bool needs_normals = mode == F16_HMC || mode == F16_MALA || mode == F16_MH;
-  if (needs_normals) {
+  // The chain's N(0,1) stream (or the caller's) for all P elements, indexed like theta, in the image region of this
+  // wave's LDS (free between evaluations: P <= H^2 + 40 H): lane l computes the blocks of four l, l + 64, ... (one
+  // Philox call per block), every lane then picks the elements of its register layout.
+  T* st = lw + K::O_W1A;
+  if (mode != F16_LEAPFROG) {
     if (a.p0) {
       const T* src = a.p0 + chain * P;
-      for (int i = lane; i < P; i += 64) lp[i] = src[i];
+      for (int i = lane; i < P; i += 64) st[i] = src[i];
     } else {
       const EyRng rn = ey_rng_make(a.seed, a.chain_offset + (uint64_t)chain, iter, EY_STREAM_NORMAL);
       for (int b = lane; 4 * b < P; b += 64) {
@@ -519,44 +575,47 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
         ey_rng_normal4<T>(rn, (uint32_t)b, o);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (4 * b + j < P) lp[4 * b + j] = o[j];
+          if (4 * b + j < P) st[4 * b + j] = o[j];
       }
     }
     f16_fence();
   }
 
+  T p[K::NREG];  // HMC: the momentum; MALA / MH: the proposal
+
   if (mode == F16_MALA || mode == F16_MH) {
     // MALA.draw (mala.py:46-82) / MetropolisHastings.draw (metropolis_hastings.py:41-73): one evaluation at the proposal
     const T sc = a.step_vec ? Nm<T>::sqrt(eps) : a.sqrt_step;  // scale = sqrt(step), mala.py:39
-    T pr[K::NREG], gp[K::NREG];
+    T gp[K::NREG];
     T qf = T(0);
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
-      pr[k] = T(0);
+      const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
+      p[k] = T(0);
       gp[k] = T(0);
       if (s.valid) {
-        const T zi = lp[s.idx];
+        const T zi = st[s.idx];
         if (mode == F16_MALA) {
           gr[k] = grg[s.idx];
           const T loc = th[k] + T(0.5) * eps * gr[k];  // kernel_mean, mala.py:35-36
-          pr[k] = loc + sc * zi;
-          const T d = pr[k] - loc;
+          p[k] = loc + sc * zi;
+          const T d = p[k] - loc;
           if (s.counts) qf += d * d;
         } else {
-          pr[k] = th[k] + a.scale[s.idx] * zi;  // NormalKernel(theta, scale).sample()
+          p[k] = th[k] + a.scale[s.idx] * zi;  // NormalKernel(theta, scale).sample()
         }
       }
     }
-    f16_write_images<T, H>(lw, pr, a, c, g);
-    const T tv = f16_eval<T, H>(a, lw, pr, gp, mode == F16_MALA, has_temp, temp, c, g, lane);
+    f16_fence();  // the staged normals have been read; the evaluation reuses that LDS
+    f16_write_images<T, H>(lw, p, a, c, g);
+    const T tv = f16_eval<T, H>(a, lw, p, gp, mode == F16_MALA, has_temp, temp, c, g, lane);
     const T t_old = a.target[chain];
     T log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
     if (mode == F16_MALA) {
       T qb = T(0);
       F16_EACH(k) {
-        const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+        const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
         if (s.counts) {
-          const T d = th[k] - (pr[k] + T(0.5) * eps * gp[k]);
+          const T d = th[k] - (p[k] + T(0.5) * eps * gp[k]);
           qb += d * d;
         }
       }
@@ -568,13 +627,13 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
     const bool acc = Nm<T>::log(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
     T* so = a.rec_samples ? a.rec_samples + ((int64_t)it * a.C + chain) * P : nullptr;
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+      const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
       if (s.counts) {
         if (acc) {
-          thg[s.idx] = pr[k];
+          thg[s.idx] = p[k];
           if (mode == F16_MALA) grg[s.idx] = gp[k];
         }
-        if (so) so[s.idx] = acc ? pr[k] : th[k];
+        if (so) so[s.idx] = acc ? p[k] : th[k];
       }
     }
     if (lane == 0) {
@@ -593,19 +652,20 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
   T t_cur = T(0), kin = T(0);
   if (mode == F16_HMC) {
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
-      if (s.counts) {
-        const T v = lp[s.idx];   // hmc.py:134
-        kin += v * v;
-      }
+      const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
+      p[k] = s.valid ? st[s.idx] : T(0);   // hmc.py:134
+      if (s.counts) kin += p[k] * p[k];
       if (s.valid && !a.recompute) gr[k] = grg[s.idx];
     }
+    f16_fence();  // the staged normals have been read; the evaluations reuse that LDS
     kin = f16_wsum(kin);
     t_cur = a.target[chain];
   } else {
     const T* pin = a.pio + chain * P;
-    for (int i = lane; i < P; i += 64) lp[i] = pin[i];
-    f16_fence();
+    F16_EACH(k) {
+      const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
+      p[k] = s.valid ? pin[s.idx] : T(0);
+    }
   }
   const T h_cur = -t_cur + T(0.5) * kin;  // hmc.py:91-98,137
   T t = t_cur;
@@ -613,37 +673,26 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
   // Step 0 is the evaluation at the starting position (hmc.py:104): skipped when the cached gradient is used.
   const int k_first = (mode == F16_LEAPFROG || a.recompute) ? 0 : 1;
   if (k_first == 1) {
-    F16_EACH(k) {
-      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
-      if (s.valid) lp[s.idx] = lp[s.idx] + T(0.5) * eps * gr[k];
-    }
-    f16_fence();
+    F16_EACH(k) p[k] = p[k] + T(0.5) * eps * gr[k];
   }
 #pragma unroll 1
   for (int kk = k_first; kk <= a.L; ++kk) {
     if (kk > 0) {
-      F16_EACH(k) {
-        const F16Slot s = f16_slot<H>(k, a, c, g, lane);
-        if (s.valid) th[k] = th[k] + eps * lp[s.idx];
-      }
+      F16_EACH(k) th[k] = th[k] + eps * p[k];
     }
     f16_write_images<T, H>(lw, th, a, c, g);
     t = f16_eval<T, H>(a, lw, th, gr, true, has_temp, temp, c, g, lane);
     const T w = (kk > 0 && kk < a.L) ? eps : T(0.5) * eps;
-    F16_EACH(k) {
-      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
-      if (s.valid) lp[s.idx] = lp[s.idx] + w * gr[k];
-    }
-    f16_fence();
+    F16_EACH(k) p[k] = p[k] + w * gr[k];
   }
 
   if (mode == F16_LEAPFROG) {
     T* pout = a.pio + chain * P;
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+      const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
       if (s.counts) {
         thg[s.idx] = th[k];
-        pout[s.idx] = -lp[s.idx];  // hmc.py:122
+        pout[s.idx] = -p[k];  // hmc.py:122
         grg[s.idx] = gr[k];
       }
     }
@@ -653,11 +702,8 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
 
   kin = T(0);
   F16_EACH(k) {
-    const F16Slot s = f16_slot<H>(k, a, c, g, lane);
-    if (s.counts) {
-      const T v = lp[s.idx];
-      kin += v * v;
-    }
+    const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
+    if (s.counts) kin += p[k] * p[k];
   }
   kin = f16_wsum(kin);
   const T h_prop = -t + T(0.5) * kin;
@@ -668,7 +714,7 @@ __device__ __forceinline__ void f16_run_chain(const F16Args<T>& a, T* lw, const 
   const bool acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
   T* so = a.rec_samples ? a.rec_samples + ((int64_t)it * a.C + chain) * P : nullptr;
   F16_EACH(k) {
-    const F16Slot s = f16_slot<H>(k, a, c, g, lane);
+    const F16Slot s = f16_slot<H, T>(k, a, c, g, lane);
     if (s.counts) {
       if (so) so[s.idx] = acc ? th[k] : thg[s.idx];  // the state this chain is left in (chain_list.py:64-67)
       if (acc) {
@@ -707,8 +753,15 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4) k_fused16(F16Args
   f16_fence();
   const int64_t first = (int64_t)blockIdx.x + (int64_t)gridDim.x * wave, stride = (int64_t)gridDim.x * WAVES;
   const int n_iters = (a.mode == F16_HMC || a.mode == F16_MALA || a.mode == F16_MH) ? a.n_iters : 1;
+  typedef const __attribute__((address_space(4))) F16Args<T> KA;
   for (int64_t chain = first; chain < a.C; chain += stride)
-    for (int it = 0; it < n_iters; ++it) f16_run_chain<T, H>(a, lw, chain, it, c, g, lane);
+    for (int it = 0; it < n_iters; ++it) {
+      // the arguments are read in place from the kernarg segment in every round: hoisted out of these loops they would
+      // all stay live in scalar registers for the whole kernel and spill into vector registers
+      KA* ap = (KA*)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ap));
+      f16_run_chain<T, H>(*ap, lw, chain, it, c, g, lane);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------- host side
@@ -808,7 +861,7 @@ static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
   if constexpr (sizeof(T) == 4) {
     if (H == 16) return f16_launch_w<float, 16, 8>(a, pl->n_cu, s);
     if (H == 32) return f16_launch_w<float, 32, 8>(a, pl->n_cu, s);
-    return f16_launch_w<float, 64, 3>(a, pl->n_cu, s);
+    return f16_launch_w<float, 64, 4>(a, pl->n_cu, s);
   } else {
     if (H == 16) return f16_launch_w<double, 16, 8>(a, pl->n_cu, s);
     return f16_launch_w<double, 32, 4>(a, pl->n_cu, s);

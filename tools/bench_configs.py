@@ -75,3 +75,51 @@ for dtype in (torch.float32, torch.float64):
         dt = timed(f2run, 10) / K2
         print(f"     the same, {K2} iterations per launch (ey_mala_run): {dt * 1e6:.1f} us/draw -> {C / dt:.3e} "
               f"draws/s x chains")
+
+# ---- fused 16x16x4 kernels (ey_fused16.hip): the headline model in f64 and other widths / likelihoods in f32,
+# HMC L = 20 on Iris-shaped synthetic data, against the generic VALU kernel on the same plan (EY_FORCE_GENERIC)
+from eeyore_amd import _lib as L  # noqa: E402
+
+PEAK = {torch.float32: (157.3, 146.4), torch.float64: (78.6, 46.4)}  # TFLOP/s: datasheet, measured 16x16x4 (tools/peak_probe.hip)
+
+
+def f_step(dims, n_rows):
+    prods = [dims[i] * dims[i + 1] for i in range(len(dims) - 1)]
+    P = sum((dims[i] + 1) * dims[i + 1] for i in range(len(dims) - 1))
+    return 2 * n_rows * (2 * sum(prods) + sum(prods[1:])) + 6 * P
+
+
+xs, ys = synthetic.iris_shaped_arrays(seed=0)
+for dims, acts, lik, dtype, C in (([4, 32, 32, 3], [1, 1, 0], 1, torch.float64, 4096),
+                                  ([4, 16, 16, 3], [1, 1, 0], 1, torch.float32, 4096),
+                                  ([4, 32, 32, 3], [2, 2, 0], 1, torch.float32, 4096),
+                                  ([4, 64, 64, 3], [1, 1, 0], 1, torch.float32, 4096),
+                                  ([4, 16, 16, 3], [1, 1, 0], 1, torch.float64, 4096),
+                                  ([4, 32, 32, 1], [1, 1, 1], 0, torch.float32, 4096)):
+    y = ys if lik == 1 else ys[:, :1]
+    pl = Plan(dims, [1, 1, 1], acts, lik, dtype, dev)
+    pl.set_data(torch.tensor(xs, dtype=dtype, device=dev), torch.tensor(y, dtype=dtype, device=dev))
+    pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), float(np.sqrt(3.0))))
+    th = 0.1 * pl.philox_normal(C, seed=0, it=0)
+    t, g = pl.log_target_grad(th)
+    Ls, step = 20, 0.02
+    res = {}
+    for name, flags, n, Cn in (("fused16", 0, 10, C), ("generic", L.EY_FORCE_GENERIC, 2, min(C, 1024))):
+        thn, tn, gn = th[:Cn].clone(), t[:Cn].clone(), g[:Cn].clone()
+        acc = []
+        def fs():
+            it[0] += 1
+            acc.append(pl.hmc_step(thn, tn, gn, step, Ls, seed=3, it=it[0], flags=flags)["accepted"])
+        dt = timed(fs, n)
+        res[name] = Cn * Ls / dt
+        a = torch.stack(acc[-n:]).float().mean().item()
+        if name == "fused16":
+            fl = f_step(dims, xs.shape[0]) * res[name] / 1e12
+            pk = PEAK[dtype]
+            print(f"{pl.kernel} HMC L={Ls} {Cn} chains MLP({'-'.join(map(str, dims))}) acts {acts} "
+                  f"{'CE' if lik else 'BCE'} {str(dtype)[6:]}: {dt * 1e3:.3f} ms/draw -> {res[name]:.3e} leapfrog-steps/s x "
+                  f"chains = {fl:.1f} TFLOP/s ({100 * fl / pk[0]:.1f}% of the {pk[0]} datasheet matrix peak, "
+                  f"{100 * fl / pk[1]:.1f}% of the {pk[1]} measured), acceptance {a:.2f}")
+        else:
+            print(f"     generic kernel on {Cn} chains: {res[name]:.3e} leapfrog-steps/s x chains -> fused16 is "
+                  f"{res['fused16'] / res[name]:.1f}x")
