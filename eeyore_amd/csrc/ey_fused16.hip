@@ -90,8 +90,8 @@ template <typename T>
 struct Nm;
 template <>
 struct Nm<float> {
-  static __device__ __forceinline__ float exp(float v) { return expf(v); }
-  static __device__ __forceinline__ float log(float v) { return logf(v); }
+  static __device__ __forceinline__ float exp(float v) { return __expf(v); }  // v_exp_f32 / v_log_f32, as ey_mfma32.hip
+  static __device__ __forceinline__ float log(float v) { return __logf(v); }
   static __device__ __forceinline__ float tanh(float v) { return tanhf(v); }
   static __device__ __forceinline__ float sqrt(float v) { return sqrtf(v); }
 };

@@ -170,3 +170,184 @@ extern "C" int ey_inse_univariate(const void* x, int64_t n, int64_t S, int dtype
   if (dtype == EY_F32) return dispatch_inse<float>(x, n, S, (double*)sig2, (double*)var, (int*)num_pairs, s);
   return dispatch_inse<double>(x, n, S, (double*)sig2, (double*)var, (int*)num_pairs, s);
 }
+
+// ----------------------------------------------------------------------------------------------- multivariate (p > 1)
+// The reference's estimator as it stands (eeyore/stats/inse_mc_cov.py:9-83, adjust = False) for C chains at once, one
+// 256-thread workgroup per chain: the chain's n x p centred samples are staged in LDS; for every lag pair m the
+// workgroup forms gam(2m) and gam(2m+1) together (thread (a, b, slice) sums its slice of i for the p^2 entries of both
+// matrices, wave shuffles + one LDS exchange combine the slices), then one thread runs the reference's p x p logic:
+// symmetrise (:33-34), accumulate (:36-39, :62), positive definiteness as a Cholesky attempt on an exactly symmetric
+// matrix (:41, eeyore/linalg/is_pos_def.py:3-11), determinant by elimination with partial pivoting (:48, :63).
+// Also returns the unbiased sample covariance (eeyore/stats/cov.py:5-15), so that multi_ess (eeyore/stats/multi_ess.py:
+// 6-14) and the within-chain part W of multi_rhat (eeyore/stats/multi_rhat.py:14-22) need nothing else.
+// Layout: x [n, C, p] (a chain buffer as stored) with element strides (sn, sc); sums in double whatever the input.
+#define MV_PMAX 16
+
+__device__ inline bool mv_chol_ok(const double* a, int p) {  // is_pos_def: symmetric (exactly) and Cholesky succeeds
+  double l[MV_PMAX * MV_PMAX];
+  for (int i = 0; i < p; ++i)
+    for (int j = 0; j < i; ++j)
+      if (a[i * p + j] != a[j * p + i]) return false;
+  for (int j = 0; j < p; ++j) {
+    double d = a[j * p + j];
+    for (int k = 0; k < j; ++k) d -= l[j * p + k] * l[j * p + k];
+    if (!(d > 0.0)) return false;
+    const double dj = sqrt(d);
+    l[j * p + j] = dj;
+    for (int i = j + 1; i < p; ++i) {
+      double v = a[i * p + j];
+      for (int k = 0; k < j; ++k) v -= l[i * p + k] * l[j * p + k];
+      l[i * p + j] = v / dj;
+    }
+  }
+  return true;
+}
+__device__ inline double mv_det(const double* a, int p) {  // LU with partial pivoting, as torch.det
+  double m[MV_PMAX * MV_PMAX];
+  for (int i = 0; i < p * p; ++i) m[i] = a[i];
+  double det = 1.0;
+  for (int k = 0; k < p; ++k) {
+    int piv = k;
+    double best = fabs(m[k * p + k]);
+    for (int i = k + 1; i < p; ++i)
+      if (fabs(m[i * p + k]) > best) { best = fabs(m[i * p + k]); piv = i; }
+    if (best == 0.0) return 0.0;
+    if (piv != k) {
+      for (int j = 0; j < p; ++j) { const double t = m[k * p + j]; m[k * p + j] = m[piv * p + j]; m[piv * p + j] = t; }
+      det = -det;
+    }
+    det *= m[k * p + k];
+    for (int i = k + 1; i < p; ++i) {
+      const double f = m[i * p + k] / m[k * p + k];
+      for (int j = k + 1; j < p; ++j) m[i * p + j] -= f * m[k * p + j];
+    }
+  }
+  return det;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(ST_THREADS) k_inse_multivariate(const T* __restrict__ x, int64_t n, int64_t C, int p,
+                                                                  int64_t sn, int64_t sc, double* __restrict__ sig,
+                                                                  double* __restrict__ cov, double* __restrict__ mean_o,
+                                                                  int* __restrict__ pairs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* xs = reinterpret_cast<double*>(smem_raw);  // [n][p] centred
+  __shared__ double gsh[2][MV_PMAX * MV_PMAX];
+  __shared__ double mean_s[MV_PMAX];
+  __shared__ int go_on;
+  const int tid = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const int ni = (int)n, pp = p * p;
+  const T* xc = x + c * sc;
+  // ---- stage, mean (inse_mc_cov.py:10), centre
+  for (int i = tid; i < ni * p; i += ST_THREADS) xs[i] = (double)xc[(int64_t)(i / p) * sn + (i % p)];
+  __syncthreads();
+  if (tid < p) {
+    double s = 0.0;
+    for (int i = 0; i < ni; ++i) s += xs[i * p + tid];
+    mean_s[tid] = s / (double)ni;
+    if (mean_o) mean_o[c * p + tid] = mean_s[tid];
+  }
+  __syncthreads();
+  for (int i = tid; i < ni * p; i += ST_THREADS) xs[i] -= mean_s[i % p];
+  __syncthreads();
+  // thread -> (entry e = a p + b, slice): slices of i are spread over the threads that share an entry
+  const int nsl = ST_THREADS / pp > 0 ? ST_THREADS / pp : 1;   // slices per entry (pp <= 256)
+  const int e = tid % pp, sl = tid / pp;
+  const bool worker = sl < nsl;
+  const int a = e / p, b = e % p;
+  // gam(l0) and gam(l0 + 1) of every entry into gsh[0..1]
+  auto lag_pair = [&](int l0) {
+    double g0 = 0.0, g1 = 0.0;
+    if (worker) {
+      for (int i = sl; i < ni - l0; i += nsl) {
+        const double xa = xs[i * p + a];
+        g0 += xa * xs[(i + l0) * p + b];
+        if (i + l0 + 1 < ni) g1 += xa * xs[(i + l0 + 1) * p + b];
+      }
+    }
+    // combine the slices in a fixed order (reproducible): every worker leaves its partial, the entry's first thread adds
+    __syncthreads();
+    __shared__ double part[2][ST_THREADS];
+    part[0][tid] = worker ? g0 : 0.0;
+    part[1][tid] = worker ? g1 : 0.0;
+    __syncthreads();
+    if (tid < pp) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = 0; k < nsl; ++k) { s0 += part[0][k * pp + tid]; s1 += part[1][k * pp + tid]; }
+      gsh[0][tid] = s0 / (double)ni;
+      gsh[1][tid] = s1 / (double)ni;
+    }
+    __syncthreads();
+  };
+
+  const int ub = ni / 2;
+  // thread 0's state of the reference's loops
+  double Sig[MV_PMAX * MV_PMAX], Cand[MV_PMAX * MV_PMAX];
+  double last = 0.0;
+  int state = 0, used = 0;  // 0: looking for the first positive definite Sig, 1: extending, 2: stopped
+  for (int m = 0; m < ub; ++m) {
+    lag_pair(2 * m);
+    if (tid == 0) {
+      if (m == 0 && cov) {  // unbiased sample covariance: gam(0) n / (n - 1)
+        for (int k = 0; k < pp; ++k) cov[c * pp + k] = gsh[0][k] * (double)ni / (double)(ni - 1);
+      }
+      for (int i = 0; i < p; ++i)
+        for (int j = 0; j < p; ++j) {
+          const double Gij = gsh[0][i * p + j] + gsh[1][i * p + j], Gji = gsh[0][j * p + i] + gsh[1][j * p + i];
+          const double G = (Gij + Gji) / 2.0;                                                   // :33-34
+          Cand[i * p + j] = (m == 0) ? (-gsh[0][i * p + j] + 2.0 * G) : (Sig[i * p + j] + 2.0 * G);  // :36-39 / :62
+        }
+      if (state == 0) {
+        for (int k = 0; k < pp; ++k) Sig[k] = Cand[k];
+        if (mv_chol_ok(Sig, p)) {  // :41-43
+          state = 1;
+          last = mv_det(Sig, p);   // :48
+          used = m + 1;
+        }
+      } else {
+        const double dtm = mv_det(Cand, p);  // :63
+        if (dtm <= last) {                   // :64-65
+          state = 2;
+        } else {
+          for (int k = 0; k < pp; ++k) Sig[k] = Cand[k];
+          last = dtm;
+          used = m + 1;
+        }
+      }
+      go_on = state != 2;
+    }
+    __syncthreads();
+    if (!go_on) break;
+  }
+  if (tid == 0) {
+    const bool enough = state != 0;  // 'Not enough samples' (:45-46)
+    for (int k = 0; k < pp; ++k) sig[c * pp + k] = enough ? Sig[k] : __builtin_nan("");
+    if (pairs) pairs[c] = enough ? used : -1;
+  }
+}
+
+extern "C" int ey_inse_multivariate(const void* x, int64_t n, int64_t C, int64_t p, int64_t stride_n, int64_t stride_c,
+                                    int dtype, void* sig, void* cov, void* mean, void* num_pairs, void* stream) {
+  if (!x || !sig) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: null argument");
+  if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: bad dtype");
+  if (n < 2) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: at least two iterations are needed");
+  if (p < 1 || p > MV_PMAX) EY_FAIL(EY_ERR_UNSUPPORTED, "ey_inse_multivariate: 1 <= p <= 16 (use ey_inse_univariate per parameter beyond)");
+  const size_t bytes = (size_t)n * (size_t)p * sizeof(double);
+  if (bytes > ST_LDS_BYTES) EY_FAIL(EY_ERR_UNSUPPORTED, "ey_inse_multivariate: a chain of n x p doubles must fit 144 KiB of LDS");
+  if (C <= 0) return EY_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EY_F32) {
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inse_multivariate<float>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES));
+    hipLaunchKernelGGL(k_inse_multivariate<float>, dim3((unsigned)C), dim3(ST_THREADS), bytes, s, (const float*)x, n, C,
+                       (int)p, stride_n, stride_c, (double*)sig, (double*)cov, (double*)mean, (int*)num_pairs);
+  } else {
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inse_multivariate<double>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES));
+    hipLaunchKernelGGL(k_inse_multivariate<double>, dim3((unsigned)C), dim3(ST_THREADS), bytes, s, (const double*)x, n, C,
+                       (int)p, stride_n, stride_c, (double*)sig, (double*)cov, (double*)mean, (int*)num_pairs);
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}

@@ -124,6 +124,35 @@ def reduce_ess(ess, group=None):
                 not_enough=int((chains * used.numel() - used.sum()).item()))
 
 
+def multi_rhat_sharded(samples_local, layout="ncp", group=None):
+    """multi_rhat (eeyore/stats/multi_rhat.py:10-40) over the chains of ALL ranks (collective 1): every
+    rank reduces its own chains on its device (``ey_inse_multivariate``: per-chain MC covariance and mean), then the
+    sum of the MC covariances is all-reduced ([p,p] doubles) and the chain means are all-gathered ([C_local,p] doubles
+    per rank; ranks may hold different numbers of chains).  Every rank returns the same
+    (rhat, imag, W, B, is_w_pd, is_b_pd)."""
+    from .stats import batched
+    r = batched.inse_multivariate(samples_local, layout)
+    return multi_rhat_from_local_parts(r["sig"].sum(0), r["mean"], r["n"], group=group)
+
+
+def multi_rhat_from_local_parts(w_sum_local, means_local, n, group=None):
+    """The collective half of ``multi_rhat_sharded`` (on whatever device / backend the tensors live on)."""
+    from .stats import batched
+    w_sum, means = w_sum_local.clone(), means_local
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        dist.all_reduce(w_sum, op=dist.ReduceOp.SUM, group=group)
+        counts = [torch.zeros(1, dtype=torch.int64, device=means.device) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([means.shape[0]], dtype=torch.int64, device=means.device), group=group)
+        cmax = int(max(c.item() for c in counts))
+        padded = torch.zeros(cmax, means.shape[1], dtype=means.dtype, device=means.device)
+        padded[:means.shape[0]] = means
+        gathered = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(gathered, padded, group=group)
+        means = torch.cat([g[:int(c.item())] for g, c in zip(gathered, counts)])
+    return batched.multi_rhat_from_parts(w_sum, means, n)
+
+
 class TemperingExchange:
     """Parallel tempering across ranks by exchanging temperature LABELS, never states (collective 2).
 
@@ -148,18 +177,43 @@ class TemperingExchange:
         self.seed = int(seed)
         self.labels = torch.full((num_replicas,), rank, dtype=torch.int64, device=device)
         self.attempts = 0
-        self.num_swaps = 0
+        self._swaps = torch.zeros((), dtype=torch.int64, device=device)  # accepted exchanges so far, kept on the device
         if decide is None:
             from .plan import pt_swap_decide as decide
         self.decide = decide
+
+    @property
+    def num_swaps(self):
+        """Accepted exchanges so far over the whole ladder (reading it synchronises; the sweep itself does not)."""
+        return int(self._swaps.item())
 
     def temperature_vector(self, dtype):
         """Per-chain temperatures to pass to the step kernels."""
         return self.temps.to(self.labels.device)[self.labels].to(dtype)
 
-    def _uniform(self, n):
-        g = torch.Generator(device="cpu").manual_seed(self.seed * 1000003 + self.attempts)
-        return torch.rand(n, generator=g, dtype=torch.float64)
+    def _uniform(self, n, device, attempt):
+        """u[pair] for pair = k * R + r (ladder pair k, replica r) of this attempt, from the library's Philox4x32-10
+        stream keyed by (seed, pair id, attempt) (``ey_philox_uniform``: the accept-variate stream with the pair id in
+        the chain slot), so every rank draws the same numbers with no communication.  On the device: one small launch.
+        For CPU tensors (gloo rehearsals of the exchange logic) the same blocks come from the host entry point
+        ``ey_philox_block``."""
+        import ctypes as ct
+        from . import _lib as L
+        if torch.device(device).type == "cuda":
+            out = torch.empty(n, dtype=torch.float64, device=device)
+            L.check(L.lib().ey_philox_uniform(L.ptr(out), n, self.seed, attempt, 0, L.EY_F64,
+                                              ct.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                    "ey_philox_uniform")
+            return out
+        key = (ct.c_uint32 * 2)(self.seed & 0xffffffff, (self.seed >> 32) & 0xffffffff)
+        words = (ct.c_uint32 * 4)()
+        out = torch.empty(n, dtype=torch.float64)
+        it_lo, it_hi = attempt & 0xffffffff, (attempt >> 32) & 0xffffffff
+        for pair in range(n):  # counter = (block 0, chain_lo, iter_lo, iter_hi << 8 | stream 1 | chain_hi << 20)
+            ctr = (ct.c_uint32 * 4)(0, pair & 0xffffffff, it_lo, ((it_hi << 8) | 1 | ((pair >> 32) << 20)) & 0xffffffff)
+            L.check(L.lib().ey_philox_block(ctr, key, words), "ey_philox_block")
+            out[pair] = float((words[0] << 21) | (words[1] >> 11)) * 2.0 ** -53
+        return out
 
     def _gather(self, t):
         if self.world == 1:
@@ -170,30 +224,36 @@ class TemperingExchange:
 
     def exchange(self, ell_local):
         """One even/odd neighbour sweep.  ``ell_local`` [R]: untempered log-targets of this rank's chains.  Returns the
-        number of accepted exchanges over the whole ladder; ``self.labels`` is updated in place."""
+        number of accepted exchanges over the whole ladder as a 0-d tensor (no host synchronisation here);
+        ``self.labels`` is updated in place.  All pairs of the sweep go through ONE swap-decision call."""
         ell = self._gather(ell_local.detach().to(torch.float64))          # [world, R] by rank
         lab = self._gather(self.labels)                                   # [world, R]
+        dev = ell.device
         # rank_of[k, r]: which rank holds ladder position k of replica r; ell_at[k, r] its log-target
         rank_of = torch.empty_like(lab)
-        ar = torch.arange(self.R, device=lab.device)
-        rank_of[lab, ar[None].expand_as(lab)] = torch.arange(self.world, device=lab.device)[:, None].expand_as(lab)
+        ar = torch.arange(self.R, device=dev)
+        rank_of[lab, ar[None].expand_as(lab)] = torch.arange(self.world, device=dev)[:, None].expand_as(lab)
         ell_at = ell[rank_of, ar[None].expand_as(rank_of)]
-        parity = self.attempts % 2
-        u = self._uniform(self.R * self.world).view(self.world, self.R)
-        temps = self.temps.to(ell.device)
-        accepted = 0
-        new_lab = lab.clone()
-        for k in range(parity, self.world - 1, 2):
-            t_lo = temps[k].expand(self.R).contiguous()
-            t_hi = temps[k + 1].expand(self.R).contiguous()
-            swap, _ = self.decide(ell_at[k].contiguous(), ell_at[k + 1].contiguous(), t_lo, t_hi,
-                                  u[k].to(ell.device).contiguous())
-            m = swap.bool()
-            lo_rank, hi_rank = rank_of[k][m], rank_of[k + 1][m]
-            new_lab[lo_rank, ar[m]] = k + 1
-            new_lab[hi_rank, ar[m]] = k
-            accepted += int(m.sum().item())
-        self.labels = new_lab[self.rank].clone()
+        attempt = self.attempts
         self.attempts += 1
-        self.num_swaps += accepted
+        ks = torch.arange(attempt % 2, self.world - 1, 2, device=dev)   # the lower positions of this sweep's pairs
+        if ks.numel() == 0:
+            return torch.zeros((), dtype=torch.int64, device=dev)
+        u = self._uniform(self.R * self.world, dev, attempt).view(self.world, self.R)
+        temps = self.temps.to(dev)
+        n = ks.numel()
+        swap, _ = self.decide(ell_at[ks].reshape(-1).contiguous(), ell_at[ks + 1].reshape(-1).contiguous(),
+                              temps[ks][:, None].expand(n, self.R).reshape(-1).contiguous(),
+                              temps[ks + 1][:, None].expand(n, self.R).reshape(-1).contiguous(),
+                              u[ks].reshape(-1).contiguous())
+        m = swap.bool().view(n, self.R)
+        # the two holders of an accepted pair trade ladder positions
+        lo_rank, hi_rank = rank_of[ks], rank_of[ks + 1]                      # [n, R]
+        cols = ar[None].expand(n, self.R)
+        new_lab = lab.clone()
+        new_lab[lo_rank[m], cols[m]] = (ks[:, None] + 1).expand(n, self.R)[m]
+        new_lab[hi_rank[m], cols[m]] = ks[:, None].expand(n, self.R)[m]
+        self.labels = new_lab[self.rank].clone()
+        accepted = m.sum()
+        self._swaps = self._swaps + accepted.to(self._swaps.device)
         return accepted

@@ -50,8 +50,70 @@ def mc_se(samples):
 
 
 # ---------------------------------------------------------------------------------------------- multivariate, many chains
+def inse_multivariate(samples, layout="ncp"):
+    """The reference's multivariate initial-sequence estimator (eeyore/stats/inse_mc_cov.py:9-83, adjust=False) for
+    every chain at once on the device (``ey_inse_multivariate``: one workgroup per chain, p <= 16 parameters).
+    ``samples``: [n, C, p] as a chain buffer stores a run (``layout="ncp"``) or [C, n, p] (``layout="cnp"``).
+    Returns dict(sig [C,p,p], cov [C,p,p], mean [C,p], pairs [C]): the MC covariance (NaN where the reference raises
+    'Not enough samples'), the unbiased sample covariance (cov.py:5-15), the chain means and the lag pairs used."""
+    if not samples.is_cuda:
+        raise RuntimeError("eeyore_amd.stats.batched: the samples must be on the ROCm device (no CPU fallback)")
+    if samples.dtype not in _DT or samples.dim() != 3:
+        raise ValueError("samples must be a 3-d float32 / float64 tensor")
+    x = samples.contiguous()
+    if layout == "ncp":
+        n, C, p = x.shape
+        sn, sc = C * p, p
+    elif layout == "cnp":
+        C, n, p = x.shape
+        sn, sc = p, n * p
+    else:
+        raise ValueError("layout must be 'ncp' or 'cnp'")
+    kw = dict(dtype=torch.float64, device=x.device)
+    sig, cov, mean = torch.empty(C, p, p, **kw), torch.empty(C, p, p, **kw), torch.empty(C, p, **kw)
+    pairs = torch.empty(C, dtype=torch.int32, device=x.device)
+    L.check(L.lib().ey_inse_multivariate(L.ptr(x), n, C, p, sn, sc, _DT[x.dtype], L.ptr(sig), L.ptr(cov), L.ptr(mean),
+                                         L.ptr(pairs), ct.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+            "ey_inse_multivariate")
+    return dict(sig=sig, cov=cov, mean=mean, pairs=pairs, n=n)
+
+
+def multi_ess_device(samples, layout="ncp"):
+    """multi_ess (eeyore/stats/multi_ess.py:6-14) of every chain: n (det cov / det mc_cov)^(1/p) -> [C]."""
+    r = inse_multivariate(samples, layout)
+    p = r["sig"].shape[-1]
+    return r["n"] * (torch.linalg.det(r["cov"]) / torch.linalg.det(r["sig"])) ** (1.0 / p)
+
+
+def multi_rhat_from_parts(w_sum, means, n):
+    """multi_rhat (eeyore/stats/multi_rhat.py:10-40) from its sufficient parts: ``w_sum`` [p,p] the SUM over chains of
+    their MC covariances, ``means`` [m,p] the chain means, n iterations per chain.  This is the form the sharded
+    statistic takes: ranks all-reduce w_sum and all-gather means.
+    Returns (rhat, imag part of the leading eigenvalue, W, B, is_w_pd, is_b_pd) as the reference does."""
+    from .diagnostics import cov as _cov, is_pos_def, nearest_pd
+    m = means.shape[0]
+    w = w_sum / m
+    is_w_pd = is_pos_def(w)
+    if not is_w_pd:
+        w = nearest_pd(w)
+    b = _cov(means, rowvar=False)
+    is_b_pd = is_pos_def(b)
+    if not is_b_pd:
+        b = nearest_pd(b)
+    eigvals = torch.linalg.eigvals(torch.matmul(torch.inverse(w), b))
+    k = eigvals.real.argmax().item()
+    rhat = ((n - 1) / n) + ((m + 1) / m) * eigvals.real[k].item()
+    return rhat, eigvals.imag[k].item(), w, b, is_w_pd, is_b_pd
+
+
+def multi_rhat_device(samples, layout="ncp"):
+    """multi_rhat of the chains of one device: per-chain MC covariances and means from one launch."""
+    r = inse_multivariate(samples, layout)
+    return multi_rhat_from_parts(r["sig"].sum(0), r["mean"], r["n"])
+
+
 def inse_mc_cov_chains(x):
-    """The reference's multivariate initial-sequence estimator (eeyore/stats/inse_mc_cov.py:9-83, adjust=False) for C
+    """(torch-batched form, any device; the HIP form is ``inse_multivariate``.)  The reference's multivariate initial-sequence estimator (eeyore/stats/inse_mc_cov.py:9-83, adjust=False) for C
     chains at once: x [C, n, p] -> [C, p, p].  Every lag pair is ONE batched product over all chains (the reference's
     torch.ger double loop, :24-31), the positive-definiteness test (:41, a Cholesky attempt on a symmetric matrix,
     eeyore/linalg/is_pos_def.py:3-11) and the determinant test (:62-65) are batched too; chains leave the loop one by

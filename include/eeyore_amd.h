@@ -174,6 +174,16 @@ int ey_stats_update(const void* theta, const void* accepted, int64_t C, int64_t 
 int ey_inse_univariate(const void* x, int64_t n, int64_t S, int dtype, void* sig2, void* var, void* num_pairs,
                        void* stream);
 
+/* The reference's MULTIVARIATE initial-sequence estimator (eeyore/stats/inse_mc_cov.py:9-83, adjust=False) for C
+ * chains of p <= 16 parameters at once: x is addressed as x[i * stride_n + c * stride_c + j] (elements; a chain buffer
+ * [iterations, C, P] has stride_n = C*P, stride_c = P; [C, n, p] has stride_n = p, stride_c = n*p).  sig [C,p,p]
+ * double: the estimate (NaN where the reference raises 'Not enough samples'); cov [C,p,p] double or NULL: the unbiased
+ * sample covariance (eeyore/stats/cov.py:5-15); mean [C,p] double or NULL; num_pairs [C] int32 or NULL.  With these,
+ * multi_ess (eeyore/stats/multi_ess.py:6-14) and both parts of multi_rhat (eeyore/stats/multi_rhat.py:10-40: W = the
+ * mean of sig over chains, B = the covariance of the chain means) follow from [C,p,p]- and [C,p]-sized arrays. */
+int ey_inse_multivariate(const void* x, int64_t n, int64_t C, int64_t p, int64_t stride_n, int64_t stride_c, int dtype,
+                         void* sig, void* cov, void* mean, void* num_pairs, void* stream);
+
 /* Attach running-moment accumulators to a plan: from now on every ey_hmc_step / ey_mala_step / ey_mh_step on it also
  * performs, for the state each chain is left in, exactly what ey_stats_update does (s1 += theta, s2 += theta^2,
  * acc += accepted) -- inside the fused kernel where there is one (no extra pass over [C,P]), as a trailing pass on

@@ -155,5 +155,55 @@ def test_tempering_exchange_keeps_a_permutation_and_agrees_across_ranks():
 def test_tempering_exchange_single_process_matches_rule():
     from eeyore_amd.distributed import TemperingExchange
     ex = TemperingExchange([1.0], 4, 0, 1, "cpu", decide=_torch_decide)
-    assert ex.exchange(torch.zeros(4, dtype=torch.float64)) == 0 and ex.labels.tolist() == [0, 0, 0, 0]
+    assert int(ex.exchange(torch.zeros(4, dtype=torch.float64))) == 0 and ex.labels.tolist() == [0, 0, 0, 0]
     assert ex.temperature_vector(torch.float32).tolist() == [1.0] * 4
+
+
+def test_tempering_exchange_uniforms_are_the_library_philox_stream():
+    """The shared accept variates of a sweep are ey_philox_uniform's stream keyed by (seed, pair id, attempt): checked
+    against the numpy Philox twin (itself pinned by Random123's vectors), bit for bit."""
+    from eeyore_amd.distributed import TemperingExchange
+    from oracle import philox_oracle as po
+    ex = TemperingExchange([0.1, 0.4, 1.0], 5, 0, 3, "cpu", seed=77, decide=_torch_decide)
+    for attempt in (0, 1, 9):
+        u = ex._uniform(15, "cpu", attempt)
+        assert np.array_equal(u.numpy(), po.uniform(15, 77, attempt, 0, np.float64))
+
+
+# ------------------------------------------------------------------------------------------------ sharded multi_rhat
+def _rhat_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import eeyore_amd.stats as st
+    from eeyore_amd.distributed import multi_rhat_from_local_parts
+    from tests.helpers import load
+    z = load("g7_stats.npz")
+    x = torch.tensor(z["chains"])                     # [4, 1000, 3]
+    mine = x[:3] if rank == 0 else x[3:]              # uneven shards: 3 chains and 1
+    w_sum = sum(st.inse_mc_cov(c) for c in mine)      # (on a GPU rank ey_inse_multivariate gives these in one launch)
+    r = multi_rhat_from_local_parts(w_sum, mine.mean(1), x.shape[1])
+    q.put((rank, r[0], r[2].numpy(), r[3].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_multi_rhat_equals_the_reference_value():
+    """W all-reduced, chain means all-gathered: two ranks with 3 + 1 of the reference's example chains give
+    the reference's published multi_rhat on both ranks."""
+    from tests.helpers import load
+    z = load("g7_stats.npz")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rhat_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, rhat, W, B in got:
+        np.testing.assert_allclose(rhat, float(z["multi_rhat"]), rtol=1e-10)
+        np.testing.assert_allclose(W, z["W"], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(B, z["B"], rtol=1e-10)

@@ -1565,3 +1565,38 @@ def test_generic_run_with_attached_moments_fails_before_it_advances_the_chains()
     torch.cuda.synchronize()
     np.testing.assert_allclose(st.s1.cpu().numpy(), smp.sum(0).cpu().numpy(), rtol=1e-13)
     pl.detach_moments()
+
+
+# --------------------------------------------------------------------------------------------- multivariate diagnostics
+def test_multivariate_inse_ess_rhat_on_the_device_match_the_reference():
+    """ey_inse_multivariate (one workgroup per chain) against the reference's own numbers on its examples/stats chains
+    (G7: inse_mc_cov, cov, multi_ess per chain, multi_rhat with W and B), in both storage layouts and in f32 storage."""
+    from eeyore_amd.stats import batched
+    z = load("g7_stats.npz")
+    x = _t(z["chains"])                                  # [C = 4, n = 1000, p = 3]
+    for layout, xs in (("cnp", x), ("ncp", x.permute(1, 0, 2).contiguous())):
+        r = batched.inse_multivariate(xs, layout)
+        np.testing.assert_allclose(r["sig"].cpu().numpy(), z["inse_mc_cov"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r["cov"].cpu().numpy(), z["cov"], rtol=1e-11)
+        np.testing.assert_allclose(r["mean"].cpu().numpy(), z["chains"].mean(1), rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(batched.multi_ess_device(xs, layout).cpu().numpy(), z["multi_ess"], rtol=1e-8)
+        rhat, imag, W, B, wpd, bpd = batched.multi_rhat_device(xs, layout)
+        np.testing.assert_allclose(rhat, float(z["multi_rhat"]), rtol=1e-9)
+        np.testing.assert_allclose(W.cpu().numpy(), z["W"], rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(B.cpu().numpy(), z["B"], rtol=1e-10)
+        assert wpd and bpd and imag == 0
+    assert float(z["multi_rhat"]) == 1.0134832973360262  # the reference's published value (SURVEY section 4)
+    # many chains of different lengths of memory, against the torch-batched form and the per-chain function
+    import eeyore_amd.stats as st
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((37, 240, 5)).cumsum(1) * 0.1 + rng.standard_normal((37, 240, 5))
+    y[3] = 1.5  # a constant chain: the reference raises 'Not enough samples'
+    r = batched.inse_multivariate(_t(y), "cnp")
+    sig = r["sig"].cpu().numpy()
+    assert np.isnan(sig[3]).all() and int(r["pairs"][3]) == -1
+    for i in (0, 1, 2, 4, 17, 36):
+        np.testing.assert_allclose(sig[i], st.inse_mc_cov(torch.tensor(y[i])).numpy(), rtol=1e-9, atol=1e-12)
+    r32 = batched.inse_multivariate(_t(y, torch.float32), "cnp")
+    np.testing.assert_allclose(r32["sig"].cpu().numpy()[0], sig[0], rtol=1e-4)
+    with pytest.raises(RuntimeError):
+        batched.inse_multivariate(_t(rng.standard_normal((2, 50, 17))), "cnp")  # p > 16
