@@ -47,6 +47,7 @@ SYMBOLS = {
     "ey_mh_run": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _u64, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ey_log_lik_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "ey_inse_univariate": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
+    "ey_plan_attach_da": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _i]),
     "ey_inse_multivariate": (_i, [_vp, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
     "ey_debug_set_variant": (_i, [_i]),
 }

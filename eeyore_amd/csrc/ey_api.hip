@@ -230,6 +230,32 @@ static int moments_trailing(ey_plan* pl, int rc, const void* theta, const void* 
   return ey_stats_update(theta, accepted, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2, pl->mom_acc, stream);
 }
 
+// The window of the attached dual averaging that a launch of n_iters HMC iterations covers (nothing once the table is
+// used up); `advance` moves the plan's position in the table past it.
+static EyDA da_window(ey_plan* pl, int n_iters) {
+  EyDA w;
+  if (!pl->da_state || pl->da_done >= pl->da_n) return w;
+  w.state = pl->da_state;
+  w.step = pl->da_step;
+  w.table = pl->da_table + 3 * pl->da_done;
+  w.n = (int)std::min<int64_t>(n_iters, pl->da_n - pl->da_done);
+  w.final_it = (pl->da_final_avg && pl->da_done + n_iters >= pl->da_n) ? (int)(pl->da_n - 1 - pl->da_done) : -1;
+  w.d = pl->da_d;
+  w.logeub = pl->da_logeub;
+  w.has_eub = pl->da_has_eub ? 1 : 0;
+  return w;
+}
+static int da_check(const ey_plan* pl, int64_t C, bool fused, const char* who) {
+  if (!pl->da_state) return EY_OK;
+  if (pl->da_C != C)
+    EY_FAIL(EY_ERR_INVALID, std::string(who) + ": the attached dual averaging was sized for " + std::to_string(pl->da_C) +
+                            " chains, called with " + std::to_string(C));
+  if (!fused && pl->da_done < pl->da_n)
+    EY_FAIL(EY_ERR_UNSUPPORTED, std::string(who) + ": in-kernel dual averaging needs one of the fused kernel families "
+                                                   "(mfma32, fused16); detach it and adapt on the host for this plan");
+  return EY_OK;
+}
+
 static int check_ready(const ey_plan* pl, int64_t C, const char* who) {
   if (!pl) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": null plan");
   if (!pl->has_data) EY_FAIL(EY_ERR_STATE, std::string(who) + ": ey_plan_set_data has not been called");
@@ -291,13 +317,17 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: num_steps must be >= 1");
   if (C == 0) return EY_OK;
   if ((rc = moments_check(pl, C, "ey_hmc_step"))) return rc;
+  const bool fused = (use_mfma32(pl) || use_fused16(pl)) && !(flags & EY_FORCE_GENERIC);
+  if ((rc = da_check(pl, C, fused, "ey_hmc_step"))) return rc;
   EY_HIP(hipSetDevice(pl->device));
+  const EyDA da = da_window(pl, 1);
+  if (fused && da.state) pl->da_done += 1;
   if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC))  // accumulates attached moments itself
     return ey_mfma32_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
-                         accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
+                         accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream, nullptr, &da);
   if (use_fused16(pl) && !(flags & EY_FORCE_GENERIC))
     rc = ey_fused16_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
-                        accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
+                        accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream, nullptr, &da);
   else if (use_large(pl))
     rc = ey_large_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                       accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
@@ -323,13 +353,17 @@ int ey_hmc_run(ey_plan* pl, void* theta, void* target, void* grad, double step, 
   if (n_iters < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_run: n_iters must be >= 1");
   if (C == 0) return EY_OK;
   if ((rc = moments_check(pl, C, "ey_hmc_run"))) return rc;
+  const bool f16 = use_fused16(pl) && !(flags & EY_FORCE_GENERIC);
+  const bool m32 = use_mfma32(pl) && !(flags & EY_FORCE_GENERIC);
+  if ((rc = da_check(pl, C, f16 || m32, "ey_hmc_run"))) return rc;
   EY_HIP(hipSetDevice(pl->device));
   hipStream_t s = (hipStream_t)stream;
   EyRun run = {n_iters, samples, targets, accepted_rec, (int*)accept_count};
-  if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC))
+  const EyDA da = da_window(pl, n_iters);
+  if ((f16 || m32) && da.state) pl->da_done += da.n;
+  if (m32)
     return ey_mfma32_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
-                         flags, accepted, nullptr, nullptr, nullptr, s, &run);
-  const bool f16 = use_fused16(pl) && !(flags & EY_FORCE_GENERIC);
+                         flags, accepted, nullptr, nullptr, nullptr, s, &run, &da);
   if (f16 || !use_large(pl)) {
     // the generic kernels do not fuse the moments: they are replayed from the recorded samples, which must then exist
     // (checked BEFORE the launch: a failure must leave the chains where they were)
@@ -338,7 +372,7 @@ int ey_hmc_run(ey_plan* pl, void* theta, void* target, void* grad, double step, 
                                   "on this kernel family");
     if (f16)
       rc = ey_fused16_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
-                          flags, accepted, nullptr, nullptr, nullptr, s, &run);
+                          flags, accepted, nullptr, nullptr, nullptr, s, &run, &da);
     else
       rc = ey_generic_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter,
                           chain_offset, flags, accepted, nullptr, nullptr, nullptr, s, &run);
@@ -677,6 +711,30 @@ extern "C" int ey_stats_update(const void* theta, const void* accepted, int64_t 
     hipLaunchKernelGGL(k_acc_update, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s,
                        (const unsigned char*)accepted, (double*)acc, C);
   EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+extern "C" int ey_plan_attach_da(ey_plan* pl, void* state, void* step_vec, const void* table, int64_t n, int64_t C,
+                                 double d, double log_eub, int final_avg) {
+  if (!pl) EY_FAIL(EY_ERR_INVALID, "ey_plan_attach_da: null plan");
+  if (!state) {
+    pl->da_state = nullptr; pl->da_step = nullptr; pl->da_table = nullptr;
+    pl->da_n = pl->da_done = pl->da_C = 0;
+    return EY_OK;
+  }
+  if (!step_vec || !table || n <= 0 || C <= 0)
+    EY_FAIL(EY_ERR_INVALID, "ey_plan_attach_da: state, step_vec, table, n > 0 and C > 0 are required");
+  if (!(d > 0.0 && d < 1.0)) EY_FAIL(EY_ERR_INVALID, "ey_plan_attach_da: the target acceptance must lie in (0, 1)");
+  pl->da_state = (double*)state;
+  pl->da_step = step_vec;
+  pl->da_table = (const double*)table;
+  pl->da_n = n;
+  pl->da_done = 0;
+  pl->da_C = C;
+  pl->da_d = d;
+  pl->da_has_eub = log_eub == log_eub;  // NaN = no upper bound
+  pl->da_logeub = pl->da_has_eub ? log_eub : 0.0;
+  pl->da_final_avg = final_avg != 0;
   return EY_OK;
 }
 

@@ -60,6 +60,13 @@ struct ey_plan {
   // running moments attached with ey_plan_attach_moments (caller-owned device memory)
   double *mom_s1 = nullptr, *mom_s2 = nullptr, *mom_acc = nullptr;
   int64_t mom_C = 0;
+  // per-chain dual averaging of the HMC step size, attached with ey_plan_attach_da (caller-owned device memory)
+  double* da_state = nullptr;        // [C,3]: barh, logbare, mu
+  void* da_step = nullptr;           // [C] of the plan's dtype: the step of the next iteration
+  const double* da_table = nullptr;  // [da_n,3]: d_w, sqrt(t)/gamma, e_w of the k-th adapting iteration
+  int64_t da_n = 0, da_done = 0, da_C = 0;
+  double da_d = 0.65, da_logeub = 0.0;
+  bool da_has_eub = false, da_final_avg = false;
   int* d_labels;
   // mfma32 path (4-32-32-3-like models, f32): padded/packed data image
   bool mfma32_ok;        // the model is one the fused kernel serves
@@ -75,6 +82,34 @@ struct ey_plan {
   void* d_work;
   size_t work_bytes;
 };
+
+// what a launch needs of the attached dual averaging: the rows of the table for its iterations
+struct EyDA {
+  double* state = nullptr;
+  void* step = nullptr;
+  const double* table = nullptr;  // first row = this launch's first iteration
+  int n = 0;                      // adapting iterations in this launch (the rest of the launch keeps the last step)
+  int final_it = -1;              // launch-local iteration that stores exp(logbare) instead of exp(loge); -1 = none
+  double d = 0.65, logeub = 0.0;
+  int has_eub = 0;
+};
+
+// One update of the recurrence of eeyore/tuners/hmcda_tuner.py:43-59 for one chain (Hoffman & Gelman 2014, algorithm 5):
+// returns the step of the next iteration.  row = (d_w, sqrt(t)/gamma, e_w), worked out on the host for iteration t.
+__host__ __device__ inline double ey_da_update(double* st, const double* row, double rate, double d, bool has_eub,
+                                               double logeub, bool averaged) {
+#pragma clang fp contract(off)  // separate multiplies and adds, as the host form of the recurrence rounds them
+  double barh = st[0], logbare = st[1];
+  const double m = st[2];
+  const double r = rate == rate ? rate : 0.0;  // a NaN rate (a rejected non-finite trajectory) counts as 0
+  barh += row[0] * ((d - r) - barh);
+  double loge = m - row[1] * barh;
+  if (has_eub && loge > logeub) loge = logeub;
+  logbare += row[2] * (loge - logbare);
+  st[0] = barh;
+  st[1] = logbare;
+  return exp(averaged ? logbare : loge);
+}
 
 // ey_hmc_run: n_iters consecutive draws inside one launch, with optional per-iteration records
 struct EyRun {
@@ -124,7 +159,7 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s);
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                  hipStream_t s, const EyRun* run = nullptr);
+                  hipStream_t s, const EyRun* run = nullptr, const EyDA* da = nullptr);
 int ey_mfma32_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,
                               hipStream_t s);
 int ey_mfma32_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
@@ -142,7 +177,7 @@ int ey_fused16_set_data(ey_plan* pl, hipStream_t s);
 int ey_fused16_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                    const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                    uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                   hipStream_t s, const EyRun* run = nullptr);
+                   hipStream_t s, const EyRun* run = nullptr, const EyDA* da = nullptr);
 int ey_fused16_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                     const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                     uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run = nullptr);

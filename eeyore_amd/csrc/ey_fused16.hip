@@ -64,6 +64,12 @@ struct F16Args {
   T* rec_targets;
   unsigned char* rec_accepted;
   int* accept_count;
+  // attached per-chain dual averaging (ey_plan_attach_da)
+  double* da_state;
+  const double* da_tab;
+  T* da_step;
+  int da_n, da_final_it, da_has_eub;
+  double da_d, da_logeub;
 };
 
 template <typename T>
@@ -729,6 +735,9 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     if (a.rate) a.rate[chain] = rate;
     if (a.hcur) a.hcur[chain] = h_cur;
     if (a.hprop) a.hprop[chain] = h_prop;
+    if (a.da_state && it < a.da_n)  // the tuner step of hmc.py:158-163, per chain, without leaving the launch
+      a.da_step[chain] = (T)ey_da_update(a.da_state + 3 * chain, a.da_tab + 3 * it, (double)rate, a.da_d,
+                                         a.da_has_eub != 0, a.da_logeub, it == a.da_final_it);
     if (a.rec_targets) a.rec_targets[(int64_t)it * a.C + chain] = acc ? t : t_cur;
     if (a.rec_accepted) a.rec_accepted[(int64_t)it * a.C + chain] = acc ? 1 : 0;
     if (a.accept_count && acc) a.accept_count[chain] += 1;
@@ -884,9 +893,14 @@ template <typename T>
 static int f16_hmc_t(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                      const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                      uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                     hipStream_t s, const EyRun* run) {
+                     hipStream_t s, const EyRun* run, const EyDA* da) {
   F16Args<T> a = {};
   a.mode = F16_HMC;
+  if (da && da->state) {
+    a.da_state = da->state; a.da_tab = da->table; a.da_step = (T*)da->step; a.da_n = da->n;
+    a.da_final_it = da->final_it; a.da_has_eub = da->has_eub; a.da_d = da->d; a.da_logeub = da->logeub;
+    step_vec = da->step;
+  }
   a.C = C; a.theta = (T*)theta; a.target = (T*)target; a.grad = (T*)grad; a.p0 = (const T*)p0; a.u = (const T*)u;
   a.step = (T)step; a.step_vec = (const T*)step_vec; a.L = L; a.temp = (const T*)temp; a.seed = seed; a.iter = iter;
   a.chain_offset = chain_offset; a.recompute = (flags & EY_RECOMPUTE_INITIAL_GRAD) ? 1 : 0;
@@ -897,12 +911,12 @@ static int f16_hmc_t(ey_plan* pl, void* theta, void* target, void* grad, const v
 int ey_fused16_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                    const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                    uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                   hipStream_t s, const EyRun* run) {
+                   hipStream_t s, const EyRun* run, const EyDA* da) {
   if (pl->dtype == EY_F32)
     return f16_hmc_t<float>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
-                            accepted, rate, hcur, hprop, s, run);
+                            accepted, rate, hcur, hprop, s, run, da);
   return f16_hmc_t<double>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
-                           accepted, rate, hcur, hprop, s, run);
+                           accepted, rate, hcur, hprop, s, run, da);
 }
 
 template <typename T>

@@ -95,6 +95,12 @@ struct MfArgs {
   float* rec_targets;          // [n_iters, C]
   unsigned char* rec_accepted; // [n_iters, C]
   int* accept_count;           // [C], +=
+  // attached per-chain dual averaging (ey_plan_attach_da): state [C,3], table rows of this launch's iterations
+  double* da_state;
+  const double* da_tab;
+  float* da_step;              // [C]: the step of the next iteration (the same array step_vec reads)
+  int da_n, da_final_it, da_has_eub;
+  double da_d, da_logeub;
 };
 
 // The arguments as the kernels read them: in place in the kernarg segment (constant address space, scalar loads).
@@ -775,6 +781,9 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     if (A.rate) A.rate[chain] = rate;
     if (A.hcur) A.hcur[chain] = h_cur;
     if (A.hprop) A.hprop[chain] = h_prop;
+    if (A.da_state && it < A.da_n)  // the tuner step of hmc.py:158-163, per chain, without leaving the launch
+      A.da_step[chain] = (float)ey_da_update(A.da_state + 3 * chain, A.da_tab + 3 * it, (double)rate, A.da_d,
+                                             A.da_has_eub != 0, A.da_logeub, it == A.da_final_it);
   }
   if (A.mom_s1) add_moments(A, chain, th, thg, !acc, acc, c, h, lane);
   if (A.rec_samples) {  // the state this chain is left in (what ChainList.update stores, chain_list.py:64-67)
@@ -1001,8 +1010,13 @@ static void mf_set_run(MfArgs& a, const EyRun* run) {
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                   uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
-                  hipStream_t s, const EyRun* run) {
+                  hipStream_t s, const EyRun* run, const EyDA* da) {
   MfArgs a = {};
+  if (da && da->state) {
+    a.da_state = da->state; a.da_tab = da->table; a.da_step = (float*)da->step; a.da_n = da->n;
+    a.da_final_it = da->final_it; a.da_has_eub = da->has_eub; a.da_d = da->d; a.da_logeub = da->logeub;
+    step_vec = da->step;  // the kernel reads each iteration's step where the previous one's update left it
+  }
   a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)grad;
   a.p0 = (const float*)p0; a.u = (const float*)u; a.step = (float)step; a.step_vec = (const float*)step_vec;
   a.L = L; a.temp = (const float*)temp; a.seed = seed; a.iter = iter; a.chain_offset = chain_offset;

@@ -136,9 +136,21 @@ class SingleChainSerialSampler(SerialSampler):
         x, y = next(iter(self.dataloader))
         if not hasattr(self.model._plan(x, y), 'hmc_run'):  # a plan without the block entry points
             return super().run(num_epochs, num_burnin_epochs, verbose=verbose, verbose_step=verbose_step)
+        plan = self.model._plan(x, y)
+        tuner = getattr(self, 'tuner', None)
+        # a per-chain dual-averaging tuner can run inside the fused kernels' epilogue (ey_plan_attach_da): burn-in is
+        # then blocks of iterations per launch too
+        in_kernel_da = (hasattr(tuner, 'attach') and plan.kernel in ('mfma32', 'fused16')
+                        and counter.num_burnin_iters > counter.idx)
+        if in_kernel_da:
+            tuner.attach(plan, counter.num_burnin_iters - counter.idx, idx0=counter.idx)
+            self.step = tuner.step
         while counter.idx < counter.num_iters:
             burning = counter.idx < counter.num_burnin_iters
-            if burning and getattr(self, 'tuner', None) is not None:
+            if in_kernel_da and not burning:
+                tuner.detach()
+                self.step, in_kernel_da = tuner.step, False
+            if burning and tuner is not None and not in_kernel_da:
                 self.draw(x, y, savestate=False)  # the tuner looks at every iteration's acceptance rates
                 counter.increment_idx()
                 continue
@@ -146,6 +158,9 @@ class SingleChainSerialSampler(SerialSampler):
             self._draw_block(x, y, k, savestate=not burning)
             for _ in range(k):
                 counter.increment_idx()
+        if in_kernel_da:  # a run that ends inside burn-in
+            tuner.detach()
+            self.step = tuner.step
 
     def _draw_block(self, x, y, k, savestate):
         plan = self.model._plan(x, y)

@@ -37,7 +37,7 @@ class HMC(SingleChainSerialSampler):
                 self.step = tuner.e0
             self.num_steps = tuner.num_steps(self.step)
         elif isinstance(tuner, PerChainDATuner):
-            self.step, self.num_steps = tuner.e0.clone(), tuner.num_steps()
+            self.step, self.num_steps = tuner.step, tuner.num_steps()
         if theta0 is not None:
             self.set_current(theta0.clone().detach(), data=data0)
 

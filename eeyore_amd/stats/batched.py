@@ -126,7 +126,10 @@ def inse_mc_cov_chains(x):
     ub = n // 2                                                          # :14
 
     def gam(lag):                                                        # :24-31 for every chain
-        return torch.matmul(xc[:, :n - lag].transpose(1, 2), xc[:, lag:]) / n
+        g = torch.matmul(xc[:, :n - lag].transpose(1, 2), xc[:, lag:]) / n
+        if lag == 0:  # exactly symmetric, as the reference's sum of x_i x_i^T is (see diagnostics._gam)
+            g = torch.triu(g) + torch.triu(g, 1).transpose(1, 2)
+        return g
 
     def pos_def(m):
         sym = (m == m.transpose(1, 2)).flatten(1).all(1)

@@ -60,8 +60,14 @@ def cor(x, rowvar=False):
 
 
 def _gam(x_ctr, lag, n):
-    """(1/n) sum_i x_ctr[i] (outer) x_ctr[i+lag]  --  inse_mc_cov.py:24-29 as one matmul."""
-    return x_ctr[:x_ctr.shape[0] - lag].t() @ x_ctr[lag:] / n
+    """(1/n) sum_i x_ctr[i] (outer) x_ctr[i+lag]  --  inse_mc_cov.py:24-29 as one matmul.
+    At lag 0 the reference's sum of outer products x_i x_i^T is symmetric to the last bit, and its positive-definiteness
+    test demands exactly that (is_pos_def.py:4, torch.equal(x, x.t())); a BLAS product need not be, so the upper
+    triangle is mirrored."""
+    g = x_ctr[:x_ctr.shape[0] - lag].t() @ x_ctr[lag:] / n
+    if lag == 0:
+        g = torch.triu(g) + torch.triu(g, 1).t()
+    return g
 
 
 def inse_mc_cov(x, adjust=False):

@@ -192,6 +192,20 @@ int ey_inse_multivariate(const void* x, int64_t n, int64_t C, int64_t p, int64_t
  * eeyore/chains/chain_list.py:64-67, chain_lists.py:65-66; with thousands of chains the moments are kept instead.) */
 int ey_plan_attach_moments(ey_plan* plan, void* s1, void* s2, void* acc, int64_t C);
 
+/* Per-chain dual averaging of the HMC step size INSIDE the step kernels (Hoffman & Gelman 2014, algorithm 5: the
+ * recurrence of eeyore/tuners/hmcda_tuner.py:43-59, which HMC.draw runs on the host after every burn-in iteration,
+ * eeyore/samplers/hmc.py:158-163), so that burn-in too can run as blocks of iterations per launch (ey_hmc_run).
+ * state [C,3] double, in/out: (barh, logbare, mu = log(10 e0)) per chain.  step_vec [C] of the plan's dtype: the step
+ * every chain takes in its next iteration -- the kernels read it and, after each adapting iteration, write the next
+ * one (it replaces the step / step_vec arguments of ey_hmc_step / ey_hmc_run while attached).  table [n,3] double on
+ * the device: (1/(t + t0), sqrt(t)/gamma, t^-kappa) for the t = 1st..n-th adapting iteration, worked out by the caller
+ * so that host and device agree to the last bit; the plan counts the iterations it has adapted and stops after n.
+ * d: target acceptance; log_eub: log of the upper bound on the step or NaN; final_avg != 0: the n-th iteration leaves
+ * the AVERAGED step exp(logbare) (hmcda_tuner.py's return_e=False).  The number of leapfrog steps stays what the calls
+ * pass.  state = NULL detaches.  Served by the fused kernel families (mfma32, fused16); EY_ERR_UNSUPPORTED otherwise. */
+int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* table, int64_t n, int64_t C, double d,
+                      double log_eub, int final_avg);
+
 /* Tuning knob for the MFMA kernel family (not part of the drop-in surface): selects the workgroup shape /
  * issue-priority variant of the fused trajectory kernel; returns the previous value.  Results do not depend on it. */
 int ey_debug_set_variant(int variant);
