@@ -8,7 +8,7 @@
 #include "../../include/eeyore_amd.h"
 
 #define EY_MAX_LAYERS 8
-#define EY_VERSION 100  // 0.1.0
+#define EY_VERSION 200  // 0.2.0
 
 // ----------------------------------------------------------------------------------------------- errors
 void ey_set_error(const std::string& msg);

@@ -11,11 +11,16 @@
 // eeyore/models/log_target_model.py:15-23, HMC eeyore/samplers/hmc.py:100-156).  One GEMM kernel serves the three
 // products through element strides; 128x128x16 tiles through double-buffered LDS, each wave a 64x64 quadrant of
 // v_mfma_f32_32x32x2_f32 tiles.
+#include <atomic>
 #include <vector>
 
 #include "ey_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ey_debug_set_variant bit 5 (A/B runs): 0 = LDS-DMA staging where the operands allow it, 1 = the register-staged kernel
+std::atomic<int> g_ey_no_dma{0};
+#define g_bgemm_dma (!g_ey_no_dma.load())
 
 #define BK 16
 #ifndef BG_ABL
@@ -150,6 +155,42 @@ struct Fetcher {
   }
 };
 
+// Epilogue shared by the GEMM kernels: bias + activation (forward), act'(H) (input gradient) or the prior gradient
+// and the temperature (weight gradient), and the bias gradient from the A-tile row sums.
+template <int TM, int TN, int WGM, int WGN>
+__device__ __forceinline__ void bg_epilogue(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
+                                            int h, long b, float rsum, bool do_rowsum, int tid) {
+  const float tscale = g.pr_temp ? g.pr_temp[b] : 1.0f;
+  if (do_rowsum && m0 + tid < g.M) {
+    const int mm = m0 + tid;
+    if (g.pr_theta_b) rsum = (rsum - (g.pr_theta_b[b * g.bRow + mm] - g.pr_mu_b[mm]) * g.pr_iv_b[mm]) * tscale;
+    g.rowsum[b * g.bRow + mm] = rsum;
+  }
+  float* C = g.C + b * g.bC;
+  const float* Hm = g.Hm ? g.Hm + b * g.bH : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (32 * TN) + 32 * j + c;
+    if (n >= g.N) continue;
+    const float bias = g.bias ? g.bias[b * g.bBias + n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (32 * TM) + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (m < g.M) {
+          float v = acc[i][j][r];
+          if (Hm) v *= l_dact(g.act_h, Hm[m * g.sHm + n * g.sHn]);
+          else v = l_act(g.act, v + bias);
+          const long ci = m * g.sCm + n * g.sCn;
+          if (g.pr_theta) v = (v - (g.pr_theta[b * g.bC + ci] - g.pr_mu[ci]) * g.pr_iv[ci]) * tscale;
+          C[ci] = v;
+        }
+      }
+    }
+  }
+}
+
 // C[b] = epilogue(A[b] B[b]).  Block tile BMT x BNT x 16 with two LDS buffers; the 4 waves form a WGM x WGN grid and
 // each owns TM x TN MFMA tiles of 32x32 (v_mfma_f32_32x32x2_f32), so one operand register feeds TN (or TM) MFMAs.
 //   <2,2,2,2>: 128 x 128 (the big products)   <1,1,4,1>: 128 x 32 (narrow N)   <1,1,1,4>: 32 x 128 (narrow M)
@@ -216,35 +257,157 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
     }
     __syncthreads();
   }
-  const float tscale = g.pr_temp ? g.pr_temp[b] : 1.0f;
-  if (do_rowsum && m0 + tid < g.M) {
-    const int mm = m0 + tid;
-    if (g.pr_theta_b) rsum = (rsum - (g.pr_theta_b[b * g.bRow + mm] - g.pr_mu_b[mm]) * g.pr_iv_b[mm]) * tscale;
-    g.rowsum[b * g.bRow + mm] = rsum;
+  bg_epilogue<TM, TN, WGM, WGN>(g, acc, m0, n0, wm, wn, c, h, b, rsum, do_rowsum, tid);
+}
+
+// ---- the 128 x 128 x 16 product with the operand tiles moved HBM -> LDS by the DMA path (global_load_lds_dwordx4: no
+// vector registers and, above all, no vector-ALU instructions for the staging -- f32 MFMA shares the vector ALUs, and
+// the register-staged version above spends a fifth of its time on fetch arithmetic and transposing LDS stores).
+// Both operands must have the same contiguous direction:
+//   KFAST (k contiguous: the forward products): a 16-byte piece is 4 consecutive k of one row.  The LDS image is
+//     [row][4 pieces], the piece at position p of row r being k-quad p ^ ((r >> 2) & 3) (the DMA writes 64 lanes x 16 B
+//     in lane order, so the swizzle is on the SOURCE address).  Lane (c, h) fetches the quads 2q + h of its row with
+//     one ds_read_b128 each (conflict-free through the swizzle): MFMA step (q, j) contracts k = 8q + 4h + j.
+//   !KFAST (m / n contiguous: the weight-gradient products): a piece is 4 consecutive rows at one k, the image is
+//     [k][128 rows] as it streams in, a fragment is one ds_read_b32 per step (lanes <-> consecutive rows), step s
+//     contracts k = 2s + h.
+// Three LDS stages; a wave waits for its own pieces of tile t with a counted s_waitcnt (the next tile's stay in flight
+// across the barrier), the barrier makes every wave's pieces visible, then tile t + 2 is issued into the stage that
+// was read two iterations ago.  Requires K % 16 == 0 and 16-byte-divisible leading strides; rows beyond M / N are not
+// fetched (their products land in outputs the epilogue discards).
+#define DMA_STAGES 3
+template <bool KFAST>
+__global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
+  __shared__ __attribute__((aligned(16))) float As[DMA_STAGES][BK * 128];
+  __shared__ __attribute__((aligned(16))) float Bs[DMA_STAGES][BK * 128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const long b = blockIdx.z;
+  const float* A = g.A + b * g.bA;
+  const float* B = g.B + b * g.bB;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int ktiles = g.K / BK;
+  const bool do_rowsum = g.rowsum != nullptr && blockIdx.x == 0 && tid < 128;
+  float rsum = 0.0f;
+
+  // this lane's two pieces of every A tile and of every B tile: wave-instruction w2 = 2 wave + i covers slots 64 w2 ..
+  const float* srcA[2];
+  const float* srcB[2];
+  bool okA[2], okB[2];
+  long stepA, stepB;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int slot = 64 * (2 * wave + i) + lane;
+    if (KFAST) {
+      const int r = slot >> 2, p = slot & 3, kq = p ^ ((r >> 2) & 3);
+      okA[i] = m0 + r < g.M;
+      okB[i] = n0 + r < g.N;
+      srcA[i] = A + (long)(m0 + r) * g.sAm + 4 * kq;
+      srcB[i] = B + (long)(n0 + r) * g.sBn + 4 * kq;
+    } else {
+      const int k = slot >> 5, rq = slot & 31;
+      okA[i] = m0 + 4 * rq < g.M;   // M, N are multiples of 4 here (checked on the host)
+      okB[i] = n0 + 4 * rq < g.N;
+      srcA[i] = A + (long)k * g.sAk + m0 + 4 * rq;
+      srcB[i] = B + (long)k * g.sBk + n0 + 4 * rq;
+    }
   }
-  float* C = g.C + b * g.bC;
-  const float* Hm = g.Hm ? g.Hm + b * g.bH : nullptr;
+  stepA = KFAST ? BK : (long)BK * g.sAk;
+  stepB = KFAST ? BK : (long)BK * g.sBk;
+  auto issue = [&](int kt, int st) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (32 * TN) + 32 * j + c;
-    if (n >= g.N) continue;
-    const float bias = g.bias ? g.bias[b * g.bBias + n] : 0.0f;
+    for (int i = 0; i < 2; ++i) {
+      const int w2 = 2 * wave + i;
+      if (okA[i])
+        __builtin_amdgcn_global_load_lds(srcA[i] + (long)kt * stepA,
+                                         (__attribute__((address_space(3))) void*)(As[st] + 256 * w2), 16, 0, 0);
+      if (okB[i])
+        __builtin_amdgcn_global_load_lds(srcB[i] + (long)kt * stepB,
+                                         (__attribute__((address_space(3))) void*)(Bs[st] + 256 * w2), 16, 0, 0);
+    }
+  };
+  issue(0, 0);
+  if (ktiles > 1) issue(1, 1);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int st = kt % DMA_STAGES;
+    // this wave's pieces of tile kt have landed (those of tile kt + 1, issued later, may still be in flight)
+    if (kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < ktiles) issue(kt + 2, (kt + 2) % DMA_STAGES);
+    const float* Ac = As[st];
+    const float* Bc = Bs[st];
+    if (KFAST) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 av[2][2], bv[2][2];  // [tile][q]
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + 32 * i + c, rb = wn * 64 + 32 * i + c;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (32 * TM) + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
-        if (m < g.M) {
-          float v = acc[i][j][r];
-          if (Hm) v *= l_dact(g.act_h, Hm[m * g.sHm + n * g.sHn]);
-          else v = l_act(g.act, v + bias);
-          const long ci = m * g.sCm + n * g.sCn;
-          if (g.pr_theta) v = (v - (g.pr_theta[b * g.bC + ci] - g.pr_mu[ci]) * g.pr_iv[ci]) * tscale;
-          C[ci] = v;
+        for (int q = 0; q < 2; ++q) {
+          av[i][q] = *reinterpret_cast<const f4*>(Ac + ra * 16 + 4 * ((2 * q + h) ^ ((ra >> 2) & 3)));
+          bv[i][q] = *reinterpret_cast<const f4*>(Bc + rb * 16 + 4 * ((2 * q + h) ^ ((rb >> 2) & 3)));
         }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q][j4], bv[j][q][j4], acc[i][j], 0, 0, 0);
+      if (do_rowsum) {  // sum over the tile's k of A[m = tid][k]: the four pieces of row tid, whatever their order
+#pragma unroll
+        for (int k = 0; k < BK; ++k) rsum += Ac[tid * 16 + k];
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < BK / 2; ++s2) {
+        float av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          av[i] = Ac[(2 * s2 + h) * 128 + wm * 64 + 32 * i + c];
+          bv[i] = Bc[(2 * s2 + h) * 128 + wn * 64 + 32 * i + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+      if (do_rowsum) {
+#pragma unroll
+        for (int k = 0; k < BK; ++k) rsum += Ac[k * 128 + tid];
       }
     }
   }
+  bg_epilogue<2, 2, 2, 2>(g, acc, m0, n0, wm, wn, c, h, b, rsum, do_rowsum, tid);
+}
+
+static bool dma_ok(const BG& g, bool& kfast) {
+  if (g.K % BK != 0 || g.M <= 32 || g.N <= 32) return false;
+  const bool a_k = g.sAk == 1, b_k = g.sBk == 1, a_m = g.sAm == 1, b_n = g.sBn == 1;
+  // The 16-byte pieces only need dword alignment (a chain's theta starts at a multiple of P floats: 8-byte aligned for
+  // P = 101 770), as any global load on this device; what must hold is that a piece never straddles a row.
+  if (a_k && b_k) {
+    kfast = true;
+    return true;
+  }
+  if (a_m && b_n) {
+    kfast = false;
+    return g.M % 4 == 0 && g.N % 4 == 0;
+  }
+  return false;
 }
 
 static int bgemm(const BG& g, int batch, hipStream_t s) {
@@ -257,7 +420,13 @@ static int bgemm(const BG& g, int batch, hipStream_t s) {
     hipLaunchKernelGGL((k_bgemm<1, 1, 1, 4>), grid, dim3(256), 0, s, g);
   } else {
     dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
-    hipLaunchKernelGGL((k_bgemm<2, 2, 2, 2>), grid, dim3(256), 0, s, g);
+    bool kfast = false;
+    if (g_bgemm_dma && dma_ok(g, kfast)) {
+      if (kfast) hipLaunchKernelGGL(k_bgemm_dma<true>, grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL(k_bgemm_dma<false>, grid, dim3(256), 0, s, g);
+    } else {
+      hipLaunchKernelGGL((k_bgemm<2, 2, 2, 2>), grid, dim3(256), 0, s, g);
+    }
   }
   EY_HIP(hipGetLastError());
   return EY_OK;

@@ -1683,3 +1683,36 @@ def test_in_kernel_dual_averaging_equals_the_host_recurrence(shape):
     with pytest.raises(RuntimeError):
         small.hmc_step(th, tt, gg, 0.0, 3, step_vec=tun.step, seed=1, it=0)
     tun.detach()
+
+
+def test_full_size_cfg5_share_reversibility_and_energy():
+    """One GPU's share of BASELINE config 5 (one temperature: 4096 chains, MLP(784-128-10), N = 1024 rows; 1.67 GB per
+    state vector), size-independent properties on the layerwise path: the leapfrog is time-reversible (the momentum flip
+    is built in, hmc.py:122), the log-target returns, and the energy error of a short trajectory is small; a
+    per-chain temperature scales value and gradient exactly."""
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(0)
+    N, C = 1024, 4096
+    x = (rng.random((N, 784)) * (rng.random((N, 784)) < 0.19)).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[np.arange(N) % 10]
+    pl = Plan([784, 128, 10], [1, 1], [1, 0], 1, torch.float32, DEV)
+    assert pl.kernel == "bgemm"
+    pl.set_data(_t(x, torch.float32), _t(y, torch.float32))
+    pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
+    th0 = 0.05 * pl.philox_normal(C, seed=2, it=0)
+    p0 = pl.philox_normal(C, seed=2, it=1)
+    t0, g0 = pl.log_target_grad(th0)
+    assert torch.isfinite(t0).all() and torch.isfinite(g0).all()
+    th, p = th0.clone(), p0.clone()
+    t1, _ = pl.leapfrog(th, p, 0.001, 3)
+    h0 = -t0 + 0.5 * (p0 ** 2).sum(1)
+    h1 = -t1 + 0.5 * (p ** 2).sum(1)
+    assert ((h1 - h0).abs() / h0.abs()).max().item() < 1e-4
+    t2, _ = pl.leapfrog(th, p, 0.001, 3)  # and back
+    assert (th - th0).abs().max().item() < 2e-5
+    assert (p - p0).abs().max().item() < 2e-3
+    np.testing.assert_allclose(t2.cpu().numpy(), t0.cpu().numpy(), rtol=2e-5)
+    temps = torch.linspace(0.05, 1.0, 64, device=DEV)
+    tt, gt = pl.log_target_grad(th0[:64], temp=temps)
+    np.testing.assert_allclose(tt.cpu().numpy(), (temps * t0[:64]).cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(gt.cpu().numpy(), (temps[:, None] * g0[:64]).cpu().numpy(), rtol=1e-4, atol=1e-4)

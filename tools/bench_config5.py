@@ -26,6 +26,9 @@ torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+if os.environ.get("EY_NO_DMA"):  # A/B: the register-staged GEMM instead of the LDS-DMA one
+    from eeyore_amd import _lib as L
+    L.lib().ey_debug_set_variant(32)
 N, L, eps, between = 1024, 20, 0.001, 10
 
 rng = np.random.default_rng(0)

@@ -15,6 +15,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define STAMP() __builtin_amdgcn_s_memtime()
 
+// Elapsed cycles of the SLOWEST wave of block 0: with two waves per SIMD the arbiter favours the older one, whose own
+// stamps would look like a stand-alone run.
+__device__ __forceinline__ void report(unsigned long long t0, unsigned long long t1, unsigned long long* cyc) {
+  __shared__ unsigned long long t_wave[16];
+  if ((threadIdx.x & 63) == 0) t_wave[threadIdx.x >> 6] = t1 - t0;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long m = 0;
+    for (unsigned w = 0; w < blockDim.x / 64; ++w) m = t_wave[w] > m ? t_wave[w] : m;
+    *cyc = m;
+  }
+}
+
 enum { OP_FMA = 0, OP_EXP = 1, OP_PKFMA = 2 };
 
 template <int OP>
@@ -51,7 +64,7 @@ __global__ void __launch_bounds__(256 * W, W) k_valu(int iters, float* out, unsi
   float s = 0;
   for (int r = 0; r < 8; ++r) s += v[r];
   out[blockIdx.x * 256 * W + threadIdx.x] = s;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
+  report(t0, t1, cyc);
 }
 
 // (b) one wave per SIMD (W = 1) or two (W = 2): 16 dependent MFMAs per iteration, K fillers after each
@@ -79,7 +92,7 @@ __global__ void __launch_bounds__(256 * W, W) k_mix(int iters, float* out, unsig
   for (int r = 0; r < 16; ++r) s += c[r];
   for (int r = 0; r < 8; ++r) s += v[r];
   out[blockIdx.x * 256 * W + threadIdx.x] = s;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
+  report(t0, t1, cyc);
 }
 
 // (c) waves 0-3 (one per SIMD): MFMA chain of n_mfma; waves 4-7 (their partners): n_valu VALU instructions.
@@ -137,7 +150,7 @@ __global__ void __launch_bounds__(256 * W, W) k44(int iters, float* out, unsigne
   }
   const unsigned long long t1 = STAMP();
   out[blockIdx.x * 256 * W + threadIdx.x] = d[0][0] + d[1][0] + d[2][0] + d[3][0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
+  report(t0, t1, cyc);
 }
 
 static float* g_out;
@@ -158,8 +171,9 @@ int main() {
   hipMalloc(&g_out, 256 * 512 * sizeof(float));
   hipMalloc(&g_cyc, 8);
   const int it = 2000;
-  printf("(a) cycles per instruction of one wave's stream (128 instr per iteration), all CUs busy\n");
-  printf("  v_fma_f32    1 wave/SIMD %.2f   2 waves/SIMD %.2f (per wave)\n",
+  printf("(a) cycles per instruction of one wave's stream (128 instr per iteration), all CUs busy; with 2 waves per SIMD\n"
+         "    the time until BOTH have finished their stream, per instruction of one stream\n");
+  printf("  v_fma_f32    1 wave/SIMD %.2f   2 waves/SIMD %.2f\n",
          run([&] { hipLaunchKernelGGL((k_valu<1, OP_FMA>), dim3(256), dim3(256), 0, 0, it, g_out, g_cyc); }) / it / 128,
          run([&] { hipLaunchKernelGGL((k_valu<2, OP_FMA>), dim3(256), dim3(512), 0, 0, it, g_out, g_cyc); }) / it / 128);
   printf("  v_exp_f32    1 wave/SIMD %.2f   2 waves/SIMD %.2f\n",
