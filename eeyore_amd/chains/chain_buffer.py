@@ -3,6 +3,20 @@ import torch
 from .storage import Chain, ChainList, ChainLists
 
 
+class _Offload:
+    """A device-to-host copy in flight (ChainBuffer.offload_async)."""
+
+    def __init__(self, host, event):
+        self._host, self._event = host, event
+
+    def done(self):
+        return self._event.query()
+
+    def wait(self):
+        self._event.synchronize()
+        return self._host
+
+
 class ChainBuffer(Chain):
     """Chain storage for C chains advanced together: device buffers ``sample [iters, C, P]``,
     ``target_val [iters, C]``, ``accepted [iters, C]`` grown geometrically, written by one ``copy_`` per saved
@@ -98,6 +112,50 @@ class ChainBuffer(Chain):
     def acceptance_rate(self):
         """Per-chain acceptance [C] = sum(accepted) / num_samples (chain_list.py:94-96)."""
         return self.get_accepted().to(torch.float64).mean(0)
+
+    # ---- off the device without stalling the sampler (SURVEY.md 8f row 2)
+    def offload_async(self, start=0, stop=None, stream=None):
+        """Start copying iterations [start, stop) of every stored key to pinned host memory on a side stream and return
+        a handle; the step kernels keep running on the sampler's stream meanwhile (the copy only waits for what was
+        recorded before this call).  ``handle.wait()`` returns {key: host tensor}; ``handle.done()`` polls.
+        A chain of 1000 x 4096 x 1315 floats is 21.5 GB: offloading block by block while the next block is sampled keeps
+        the device buffer small (``handle.wait()`` then ``drop_front(stop)``)."""
+        stop = self.n if stop is None else min(stop, self.n)
+        dev = self.bufs['sample'].device
+        side = stream or torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))   # what has been recorded so far
+        host = {}
+        with torch.cuda.stream(side):
+            for k in self.keys:
+                src = self.bufs[k][start:stop]
+                dst = torch.empty(src.shape, dtype=src.dtype, device='cpu', pin_memory=True)
+                dst.copy_(src, non_blocking=True)
+                src.record_stream(side)
+                host[k] = dst
+            event = torch.cuda.Event()
+            event.record(side)
+        return _Offload(host, event)
+
+    def drop_front(self, count):
+        """Forget the first ``count`` stored iterations (after they have been offloaded): the rest moves to the front."""
+        count = min(count, self.n)
+        for k in self.keys:
+            self.bufs[k][:self.n - count] = self.bufs[k][count:self.n].clone()
+        self.n -= count
+
+    def to_chainfiles(self, path, mode='w', chains=None):
+        """``runNN``-style directories of the reference's CSV files, one per chain (eeyore/chains/chain_file.py:21-45):
+        the whole buffer goes to the host in one asynchronous copy, the files are written from there."""
+        from pathlib import Path
+        host = self.offload_async().wait()
+        cs = range(self.num_chains()) if chains is None else chains
+        width = len(str(self.num_chains()))
+        for c in cs:
+            vals = {}
+            for k in self.keys:
+                col = host[k][:, c]
+                vals[k] = [int(a) for a in col.tolist()] if k == 'accepted' else list(col.unbind(0))
+            ChainList(keys=self.keys, vals=vals).to_chainfile(path=Path(path) / f'run{str(c + 1).zfill(width)}', mode=mode)
 
     def get_chain(self, c):
         """Chain c as a reference-style ChainList (host-visible python lists of tensors)."""

@@ -578,30 +578,42 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
   // (a pointer the compiler cannot identify with the one theta was first read through: otherwise it keeps those 29
   // values in registers through the whole trajectory instead of reading them again here)
   asm volatile("" : "+s"(thg));
-  // every load of the read-modify-write is issued before the first use (sched_barrier), so the wave waits for one
-  // memory round trip, not for one per group of loads
-  double a1[29], a2[29];
+  // In two halves (the 16 W1 elements, then the 13 others): inside a half every load of the read-modify-write is issued
+  // before the first use (sched_barrier), so the wave waits for two memory round trips per draw, not for one per group
+  // of loads -- and not for one only, which would take 145 registers at once and push the values that live across the
+  // whole iteration (addresses, lane constants) into scratch, from where every leapfrog step then reloads them.
   float x[29];
-  int k = 0;
-  for_each(now, c, h, lane, [&](float& v, int idx, bool counts) {
-    x[k] = v;
-    if (counts) {
-      a1[k] = m1[idx];
-      a2[k] = m2[idx];
-      if (from_memory) x[k] = thg[idx];
-    }
-    ++k;
-  });
-  __builtin_amdgcn_sched_barrier(0);
-  k = 0;
-  for_each(now, c, h, lane, [&](float&, int idx, bool counts) {
-    if (counts) {
-      const double t = (double)x[k];
-      m1[idx] = a1[k] + t;
-      m2[idx] = a2[k] + t * t;
-    }
-    ++k;
-  });
+  {
+    int k = 0;
+    for_each(now, c, h, lane, [&](float& v, int idx, bool counts) {
+      x[k] = (counts && from_memory) ? thg[idx] : v;
+      ++k;
+    });
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int k0 = half == 0 ? 0 : 16, k1 = half == 0 ? 16 : 29;
+    double a1[16], a2[16];
+    int k = 0;
+    for_each(now, c, h, lane, [&](float&, int idx, bool counts) {
+      if (k >= k0 && k < k1 && counts) {
+        a1[k - k0] = m1[idx];
+        a2[k - k0] = m2[idx];
+      }
+      ++k;
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    k = 0;
+    for_each(now, c, h, lane, [&](float&, int idx, bool counts) {
+      if (k >= k0 && k < k1 && counts) {
+        const double t = (double)x[k];
+        m1[idx] = a1[k - k0] + t;
+        m2[idx] = a2[k - k0] + t * t;
+      }
+      ++k;
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (lane == 0) A.mom_acc[chain] += accepted ? 1.0 : 0.0;
 }
 

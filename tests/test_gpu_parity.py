@@ -1716,3 +1716,32 @@ def test_full_size_cfg5_share_reversibility_and_energy():
     tt, gt = pl.log_target_grad(th0[:64], temp=temps)
     np.testing.assert_allclose(tt.cpu().numpy(), (temps * t0[:64]).cpu().numpy(), rtol=2e-5)
     np.testing.assert_allclose(gt.cpu().numpy(), (temps[:, None] * g0[:64]).cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_chain_buffer_offloads_asynchronously_and_writes_reference_files(tmp_path):
+    """ChainBuffer.offload_async: the [iterations, C, P] records go to pinned host memory on a side stream while the
+    sampler's stream keeps running; the host copy equals the device buffer, and the per-chain CSV directories read back
+    through the reference-format reader (ChainLists.from_file)."""
+    from eeyore_amd.chains import ChainBuffer, ChainLists
+    rec, pl = _cfg3_plan()
+    C, n = 64, 12
+    th = 0.1 * pl.philox_normal(C, seed=1, it=0)
+    t, g = pl.log_target_grad(th)
+    buf = ChainBuffer()
+    views = buf.block(n, dict(sample=th, target_val=t, accepted=torch.empty(C, dtype=torch.uint8, device=DEV)))
+    pl.hmc_run(th, t, g, 0.02, 8, n, seed=2, it=1, samples=views['sample'], targets=views['target_val'],
+               accepted_rec=views['accepted'])
+    buf.commit(n)
+    h = buf.offload_async(0, 8)                     # starts behind the launch above ...
+    pl.hmc_run(th, t, g, 0.02, 8, 4, seed=2, it=1 + n)   # ... while the sampler goes on
+    host = h.wait()
+    assert h.done() and host['sample'].is_pinned() and host['sample'].shape == (8, C, pl.P)
+    assert torch.equal(host['sample'], buf.get_samples()[:8].cpu())
+    assert torch.equal(host['accepted'], buf.get_accepted()[:8].cpu())
+    before = buf.get_samples()[8:].clone()
+    buf.drop_front(8)
+    assert len(buf) == 4 and torch.equal(buf.get_samples(), before)
+    buf.to_chainfiles(tmp_path, chains=[0, 5])
+    cl = ChainLists.from_file([tmp_path / 'run01', tmp_path / 'run06'], dtype=torch.float32)
+    assert tuple(cl.get_samples().shape) == (2, 4, pl.P)
+    assert torch.equal(cl.get_samples()[1], buf.get_samples()[:, 5].cpu())
