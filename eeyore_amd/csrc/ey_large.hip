@@ -335,6 +335,21 @@ __global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
                                          (__attribute__((address_space(3))) void*)(Bs[st] + 256 * w2), 16, 0, 0);
     }
   };
+  // LDS byte addresses of this lane's fragments inside a stage (see the layouts above)
+  const uint32_t lds_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)&As[0][0];
+  const uint32_t lds_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)&Bs[0][0];
+  uint32_t offA[2], offB[2];
+  if (KFAST) {
+    const int ra = wm * 64 + c, rb = wn * 64 + c;  // the second 32-row tile is 2048 bytes further (same swizzle)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      offA[q] = 4 * (ra * 16 + 4 * ((2 * q + h) ^ ((ra >> 2) & 3)));
+      offB[q] = 4 * (rb * 16 + 4 * ((2 * q + h) ^ ((rb >> 2) & 3)));
+    }
+  } else {
+    offA[0] = offA[1] = 4 * (h * 128 + wm * 64 + c);
+    offB[0] = offB[1] = 4 * (h * 128 + wn * 64 + c);
+  }
   issue(0, 0);
   if (ktiles > 1) issue(1, 1);
   for (int kt = 0; kt < ktiles; ++kt) {
@@ -344,20 +359,20 @@ __global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < ktiles) issue(kt + 2, (kt + 2) % DMA_STAGES);
-    const float* Ac = As[st];
-    const float* Bc = Bs[st];
+    // The fragment reads are written as instructions with their own wait: the compiler cannot tell that a read of
+    // stage st does not touch the stage a DMA load issued above is still filling, and would put s_waitcnt vmcnt(0)
+    // in front of every compiler-visible LDS read -- serialising the fetch of tile kt + 2 with the products of tile kt.
+    const uint32_t a_st = lds_a + st * (BK * 128 * 4), b_st = lds_b + st * (BK * 128 * 4);
     if (KFAST) {
       typedef float f4 __attribute__((ext_vector_type(4)));
       f4 av[2][2], bv[2][2];  // [tile][q]
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + 32 * i + c, rb = wn * 64 + 32 * i + c;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          av[i][q] = *reinterpret_cast<const f4*>(Ac + ra * 16 + 4 * ((2 * q + h) ^ ((ra >> 2) & 3)));
-          bv[i][q] = *reinterpret_cast<const f4*>(Bc + rb * 16 + 4 * ((2 * q + h) ^ ((rb >> 2) & 3)));
-        }
-      }
+      asm volatile(
+          "ds_read_b128 %0, %8\n\tds_read_b128 %4, %10\n\tds_read_b128 %1, %8 offset:2048\n\t"
+          "ds_read_b128 %5, %10 offset:2048\n\tds_read_b128 %2, %9\n\tds_read_b128 %6, %11\n\t"
+          "ds_read_b128 %3, %9 offset:2048\n\tds_read_b128 %7, %11 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(av[0][0]), "=&v"(av[1][0]), "=&v"(av[0][1]), "=&v"(av[1][1]), "=&v"(bv[0][0]), "=&v"(bv[1][0]),
+            "=&v"(bv[0][1]), "=&v"(bv[1][1])
+          : "v"(a_st + offA[0]), "v"(a_st + offA[1]), "v"(b_st + offB[0]), "v"(b_st + offB[1]));
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -368,26 +383,59 @@ __global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
             for (int j = 0; j < 2; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q][j4], bv[j][q][j4], acc[i][j], 0, 0, 0);
       if (do_rowsum) {  // sum over the tile's k of A[m = tid][k]: the four pieces of row tid, whatever their order
-#pragma unroll
-        for (int k = 0; k < BK; ++k) rsum += Ac[tid * 16 + k];
+        f4 r0, r1, r2, r3;
+        asm volatile(
+            "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+            "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+            : "v"(a_st + tid * 64));
+        // the order the compiler-visible loop had: k-positions 0..15 of the image, left to right
+        rsum += r0[0]; rsum += r0[1]; rsum += r0[2]; rsum += r0[3];
+        rsum += r1[0]; rsum += r1[1]; rsum += r1[2]; rsum += r1[3];
+        rsum += r2[0]; rsum += r2[1]; rsum += r2[2]; rsum += r2[3];
+        rsum += r3[0]; rsum += r3[1]; rsum += r3[2]; rsum += r3[3];
       }
     } else {
 #pragma unroll
-      for (int s2 = 0; s2 < BK / 2; ++s2) {
-        float av[2], bv[2];
+      for (int half = 0; half < 2; ++half) {  // 4 k-steps (16 single-dword fragments) per wait
+        float av[4][2], bv[4][2];
+        const uint32_t ra = a_st + offA[0] + half * 4096, rb = b_st + offB[0] + half * 4096;
+        asm volatile(
+            "ds_read_b32 %0, %16\n\tds_read_b32 %1, %16 offset:128\n\tds_read_b32 %8, %17\n\t"
+            "ds_read_b32 %9, %17 offset:128\n\t"
+            "ds_read_b32 %2, %16 offset:1024\n\tds_read_b32 %3, %16 offset:1152\n\tds_read_b32 %10, %17 offset:1024\n\t"
+            "ds_read_b32 %11, %17 offset:1152\n\t"
+            "ds_read_b32 %4, %16 offset:2048\n\tds_read_b32 %5, %16 offset:2176\n\tds_read_b32 %12, %17 offset:2048\n\t"
+            "ds_read_b32 %13, %17 offset:2176\n\t"
+            "ds_read_b32 %6, %16 offset:3072\n\tds_read_b32 %7, %16 offset:3200\n\tds_read_b32 %14, %17 offset:3072\n\t"
+            "ds_read_b32 %15, %17 offset:3200\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(av[0][0]), "=&v"(av[0][1]), "=&v"(av[1][0]), "=&v"(av[1][1]), "=&v"(av[2][0]), "=&v"(av[2][1]),
+              "=&v"(av[3][0]), "=&v"(av[3][1]), "=&v"(bv[0][0]), "=&v"(bv[0][1]), "=&v"(bv[1][0]), "=&v"(bv[1][1]),
+              "=&v"(bv[2][0]), "=&v"(bv[2][1]), "=&v"(bv[3][0]), "=&v"(bv[3][1])
+            : "v"(ra), "v"(rb));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          av[i] = Ac[(2 * s2 + h) * 128 + wm * 64 + 32 * i + c];
-          bv[i] = Bc[(2 * s2 + h) * 128 + wn * 64 + 32 * i + c];
-        }
+        for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2][i], bv[s2][j], acc[i][j], 0, 0, 0);
       }
       if (do_rowsum) {
+        float r[BK];
+        asm volatile(
+            "ds_read_b32 %0, %16\n\tds_read_b32 %1, %16 offset:512\n\tds_read_b32 %2, %16 offset:1024\n\t"
+            "ds_read_b32 %3, %16 offset:1536\n\tds_read_b32 %4, %16 offset:2048\n\tds_read_b32 %5, %16 offset:2560\n\t"
+            "ds_read_b32 %6, %16 offset:3072\n\tds_read_b32 %7, %16 offset:3584\n\tds_read_b32 %8, %16 offset:4096\n\t"
+            "ds_read_b32 %9, %16 offset:4608\n\tds_read_b32 %10, %16 offset:5120\n\tds_read_b32 %11, %16 offset:5632\n\t"
+            "ds_read_b32 %12, %16 offset:6144\n\tds_read_b32 %13, %16 offset:6656\n\tds_read_b32 %14, %16 offset:7168\n\t"
+            "ds_read_b32 %15, %16 offset:7680\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+              "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]),
+              "=&v"(r[15])
+            : "v"(a_st + tid * 4));
 #pragma unroll
-        for (int k = 0; k < BK; ++k) rsum += Ac[k * 128 + tid];
+        for (int k = 0; k < BK; ++k) rsum += r[k];
       }
     }
   }
@@ -410,7 +458,80 @@ static bool dma_ok(const BG& g, bool& kfast) {
   return false;
 }
 
+// Input gradient of a narrow layer, delta_l = (delta_{l+1} W_l) * act'(H_l) with K = d_{l+1} <= 16 (the 10-class output
+// layer of config 5): ten multiply-adds per output do not need the matrix cores or a 128 x 128 tile -- the product is
+// HBM-bound on reading H_l and writing delta_l.  One thread per four consecutive outputs of a row; the chain's W_l
+// (K x N) is staged in LDS, the row's delta_{l+1} comes through the scalar path.
+#define DH_ROWS 128  // rows of delta_l per workgroup (the staged W_l is reused across them)
+__global__ void __launch_bounds__(256) k_dh_smallk(BG g) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [K][N]
+  const long b = blockIdx.z;
+  const float* A = g.A + b * g.bA;
+  const float* B = g.B + b * g.bB;
+  const float* Hm = g.Hm + b * g.bH;
+  float* C = g.C + b * g.bC;
+  const int N4 = g.N >> 2;
+  for (int i = threadIdx.x; i < g.K * g.N; i += 256) wsm[i] = B[(long)(i / g.N) * g.sBk + (i % g.N)];
+  __syncthreads();
+  const int rows_per_pass = 256 / N4;
+  const int n = (threadIdx.x % N4) * 4;
+  if (threadIdx.x >= rows_per_pass * N4) return;
+  const int m_end = min(g.M, ((int)blockIdx.x + 1) * DH_ROWS);
+  for (int m = blockIdx.x * DH_ROWS + threadIdx.x / N4; m < m_end; m += rows_per_pass) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < g.K; ++k) {
+      const float a = A[(long)m * g.sAm + k];
+      const float4 w = *reinterpret_cast<const float4*>(wsm + k * g.N + n);
+      acc[0] += a * w.x; acc[1] += a * w.y; acc[2] += a * w.z; acc[3] += a * w.w;
+    }
+    const float4 hv = *reinterpret_cast<const float4*>(Hm + (long)m * g.sHm + n);
+    float4 o;
+    o.x = acc[0] * l_dact(g.act_h, hv.x);
+    o.y = acc[1] * l_dact(g.act_h, hv.y);
+    o.z = acc[2] * l_dact(g.act_h, hv.z);
+    o.w = acc[3] * l_dact(g.act_h, hv.w);
+    *reinterpret_cast<float4*>(C + (long)m * g.sCm + n) = o;
+  }
+}
+static bool dh_smallk_ok(const BG& g) {
+  return g.Hm && !g.bias && !g.pr_theta && !g.rowsum && g.K <= 16 && g.N % 4 == 0 && g.N <= 1024 && g.sAk == 1 &&
+         g.sBn == 1 && g.sCn == 1 && g.sHn == 1 && g.sCm % 4 == 0 && g.sHm % 4 == 0 && g.bC % 4 == 0 && g.bH % 4 == 0 &&
+         (size_t)g.K * g.N * 4 <= 48 * 1024 && g.N >= 4 &&
+         (((uintptr_t)g.C | (uintptr_t)g.Hm) & 15) == 0;
+}
+
+static int bgemm_one(const BG& g, int batch, hipStream_t s);
+
+// One product, split where that saves padded work: a weight gradient whose N is a few columns past a multiple of 128
+// (784 = 6 x 128 + 16 in config 5: the seventh 128-wide block would be 12 % full) runs its remainder through the
+// 32-wide kernel.
 static int bgemm(const BG& g, int batch, hipStream_t s) {
+  if (dh_smallk_ok(g)) {
+    if (256 / (g.N >> 2) >= 1) {
+      dim3 grid((g.M + DH_ROWS - 1) / DH_ROWS, 1, batch);
+      hipLaunchKernelGGL(k_dh_smallk, grid, dim3(256), (size_t)g.K * g.N * sizeof(float), s, g);
+      EY_HIP(hipGetLastError());
+      return EY_OK;
+    }
+  }
+  const int rem = g.N % 128;
+  if (g.M > 32 && g.N > 128 && rem > 0 && rem <= 32 && !g.bias && !g.Hm) {
+    BG body = g, tail = g;
+    body.N = g.N - rem;
+    int rc = bgemm_one(body, batch, s);
+    if (rc) return rc;
+    const long off = (long)body.N * g.sCn;  // the tail's columns: B, C and everything indexed like C move along n
+    tail.N = rem;
+    tail.B = g.B + (long)body.N * g.sBn;
+    tail.C = g.C + off;
+    tail.rowsum = nullptr;  // the body's first block column has written the row sums
+    if (g.pr_theta) { tail.pr_theta = g.pr_theta + off; tail.pr_mu = g.pr_mu + off; tail.pr_iv = g.pr_iv + off; }
+    return bgemm_one(tail, batch, s);
+  }
+  return bgemm_one(g, batch, s);
+}
+
+static int bgemm_one(const BG& g, int batch, hipStream_t s) {
   // pick the tile shape by the narrow dimension: a 32-wide tile wastes 4x less on N (or M) <= 32
   if (g.N <= 32) {
     dim3 grid((g.N + 31) / 32, (g.M + 127) / 128, batch);
@@ -536,22 +657,40 @@ __global__ void __launch_bounds__(256) k_hmc_begin(const float* theta, const flo
 // Also leaves, per block, the partial sum of (theta - mu)^2 / sigma^2 over the block's slice of the NEW position in
 // qpart[c][blockIdx.x]: the next evaluation's log-prior then needs no pass over theta (summed in a fixed order, so the
 // result is reproducible).
+#define LEAP_EPT 8                 // elements per thread: eight independent load chains in flight
+#define LEAP_BLOCK (256 * LEAP_EPT)
+static inline int leap_blocks(int P) { return (P + LEAP_BLOCK - 1) / LEAP_BLOCK; }
 __global__ void __launch_bounds__(256) k_leap(float* thp, float* p, const float* gp, int P, float step,
                                               const float* step_vec, float wp, float wt, const float* __restrict__ mu,
                                               const float* __restrict__ iv, float* __restrict__ qpart) {
   __shared__ float red[4];
   const long c = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  float q = 0.0f;
-  if (i < P) {
-    const float eps = step_vec ? step_vec[c] : step;
+  const int i0 = blockIdx.x * LEAP_BLOCK + threadIdx.x;
+  const float eps = step_vec ? step_vec[c] : step;
+  const float ep = wp * eps, et = wt * eps;
+  float pv[LEAP_EPT], tv[LEAP_EPT], gv[LEAP_EPT], mv[LEAP_EPT], vv[LEAP_EPT];
+#pragma unroll
+  for (int j = 0; j < LEAP_EPT; ++j) {
+    const int i = i0 + j * 256;
     const long k = c * P + i;
-    float pv = p[k];
-    if (wp != 0.0f) { pv = pv + wp * eps * gp[k]; p[k] = pv; }
-    float tv = thp[k];
-    if (wt != 0.0f) { tv = tv + wt * eps * pv; thp[k] = tv; }
-    const float d = tv - mu[i];
-    q = d * d * iv[i];
+    const bool in = i < P;
+    pv[j] = in ? p[k] : 0.0f;
+    gv[j] = in && wp != 0.0f ? gp[k] : 0.0f;
+    tv[j] = in ? thp[k] : 0.0f;
+    mv[j] = in ? mu[i] : 0.0f;
+    vv[j] = in ? iv[i] : 0.0f;
+  }
+  float q = 0.0f;
+#pragma unroll
+  for (int j = 0; j < LEAP_EPT; ++j) {
+    const int i = i0 + j * 256;
+    const long k = c * P + i;
+    if (i < P) {
+      if (wp != 0.0f) { pv[j] = pv[j] + ep * gv[j]; p[k] = pv[j]; }
+      if (wt != 0.0f) { tv[j] = tv[j] + et * pv[j]; thp[k] = tv[j]; }
+      const float d = tv[j] - mv[j];
+      q += d * d * vv[j];
+    }
   }
   q = block_sum(q, red);
   if (threadIdx.x == 0) qpart[c * gridDim.x + blockIdx.x] = q;
@@ -707,7 +846,7 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     }
   }
   if (qpart)
-    hipLaunchKernelGGL(k_target, dim3((C + 3) / 4), dim3(256), 0, s, qpart, (P + 255) / 256, (float)m.prior_const,
+    hipLaunchKernelGGL(k_target, dim3((C + 3) / 4), dim3(256), 0, s, qpart, leap_blocks(P), (float)m.prior_const,
                        temp, (const float*)lik_tmp, C, lik_o, prior_o, target_o);
   else
     hipLaunchKernelGGL(k_prior, dim3(C), dim3(256), 0, s, theta, (const float*)m.mu, (const float*)m.inv_var,
@@ -753,7 +892,7 @@ int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void*
   const int cc = chunk_size(pl, C);
   const size_t af = act_floats_per_chain(m);
   // workspace: activations for a chunk + lik + [thp, p, gp] for the chunk + tprop, hcur
-  const int nblk = (P + 255) / 256;
+  const int nblk = leap_blocks(P);
   const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc + (size_t)cc * nblk;
   int rc = ensure_work(pl, ws_floats * sizeof(float));
   if (rc) return rc;
@@ -767,7 +906,7 @@ int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void*
   float* qpart = hc + cc;
   const float* mu = (const float*)m.mu;
   const float* iv = (const float*)m.inv_var;
-  const dim3 eg((P + 255) / 256, 1);
+  const dim3 eg(nblk, 1);
   for (int64_t c0 = 0; c0 < C; c0 += cc) {
     const int n = (int)((C - c0) < cc ? (C - c0) : cc);
     float* th_c = (float*)theta + c0 * P;
@@ -923,7 +1062,7 @@ int ey_large_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void
   const int P = m.P;
   const int cc = chunk_size(pl, C);
   const size_t af = act_floats_per_chain(m);
-  const int nblk = (P + 255) / 256;
+  const int nblk = leap_blocks(P);
   const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + (size_t)cc * nblk;
   int rc = ensure_work(pl, ws_floats * sizeof(float));
   if (rc) return rc;
