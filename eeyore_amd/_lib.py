@@ -50,6 +50,7 @@ SYMBOLS = {
     "ey_plan_attach_da": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _i]),
     "ey_inse_multivariate": (_i, [_vp, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
     "ey_debug_set_variant": (_i, [_i]),
+    "ey_debug_bgemm": (_i, [_vp, _vp, _vp, _i, _i, _i] + [_i64] * 9 + [_vp, _i64, _i, _i, _vp]),
 }
 
 

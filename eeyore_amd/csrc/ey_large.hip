@@ -157,6 +157,83 @@ struct Fetcher {
 
 // Epilogue shared by the GEMM kernels: bias + activation (forward), act'(H) (input gradient) or the prior gradient
 // and the temperature (weight gradient), and the bias gradient from the A-tile row sums.
+// f32 MFMA shares the vector ALUs, so every epilogue instruction is matrix time lost: the element loop is specialised
+// per kind (no per-element switch), full tiles skip the bounds tests, offsets inside one batch item are 32-bit
+// (checked on the host) from a per-(i, j) base plus a scalar multiple of the row stride, and sigmoid / tanh use the
+// hardware exp2 and reciprocal (1 ulp each) as the fused kernels do.
+__device__ __forceinline__ float l_sigmoid_fast(float g) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+}
+__device__ __forceinline__ float l_tanh_fast(float g) {
+  return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * g)) - 1.0f;
+}
+#define EPI_AT(base, byte_off) (*(decltype(base))((const char*)(base) + (byte_off)))
+template <int TM, int TN, bool FULL, class F>
+__device__ __forceinline__ void epi_loop(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
+                                         int h, F f) {
+  const unsigned sCm = 4u * (unsigned)g.sCm, sCn = 4u * (unsigned)g.sCn;  // BYTE offsets: base + zext(u32) addressing
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (32 * TN) + 32 * j + c;
+    if (!FULL && n >= g.N) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + wm * (32 * TM) + 32 * i + 4 * h;
+      const unsigned cb = (unsigned)mb * sCm + (unsigned)n * sCn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dm = 8 * (r >> 2) + (r & 3);  // compile-time row offset: dm * sCm is a scalar product
+        if (FULL || mb + dm < g.M) f(acc[i][j][r], mb + dm, n, cb + (unsigned)dm * sCm);
+      }
+    }
+  }
+}
+template <int TM, int TN, bool FULL>
+__device__ __forceinline__ void epi_kind(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
+                                         int h, long b, float tscale) {
+  float* C = g.C + b * g.bC;
+  if (g.pr_theta) {  // weight gradient: minus the prior gradient, times the temperature
+    const float* th = g.pr_theta + b * g.bC;
+    const float* mu = g.pr_mu;
+    const float* iv = g.pr_iv;
+    epi_loop<TM, TN, FULL>(g, acc, m0, n0, wm, wn, c, h, [&](float v, int, int, unsigned ci) {
+      EPI_AT(C, ci) = (v - (EPI_AT(th, ci) - EPI_AT(mu, ci)) * EPI_AT(iv, ci)) * tscale;
+    });
+  } else if (g.Hm) {  // input gradient: times act'(H)
+    const float* Hm = g.Hm + b * g.bH;
+    const unsigned sHm = 4u * (unsigned)g.sHm, sHn = 4u * (unsigned)g.sHn;
+    const int act_h = g.act_h;
+    epi_loop<TM, TN, FULL>(g, acc, m0, n0, wm, wn, c, h, [&](float v, int m, int n, unsigned ci) {
+      EPI_AT(C, ci) = v * l_dact(act_h, EPI_AT(Hm, (unsigned)m * sHm + (unsigned)n * sHn));
+    });
+  } else {  // forward: bias, activation
+    float bias[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (32 * TN) + 32 * j + c;
+      bias[j] = g.bias && n < g.N ? g.bias[b * g.bBias + n] : 0.0f;
+    }
+    const int nb = n0 + wn * (32 * TN) + c;
+    auto bj = [&](int n) { return bias[TN == 1 ? 0 : ((n - nb) >> 5)]; };
+    switch (g.act) {
+      case EY_ACT_SIGMOID:
+        epi_loop<TM, TN, FULL>(g, acc, m0, n0, wm, wn, c, h,
+                               [&](float v, int, int n, unsigned ci) { EPI_AT(C, ci) = l_sigmoid_fast(v + bj(n)); });
+        break;
+      case EY_ACT_TANH:
+        epi_loop<TM, TN, FULL>(g, acc, m0, n0, wm, wn, c, h,
+                               [&](float v, int, int n, unsigned ci) { EPI_AT(C, ci) = l_tanh_fast(v + bj(n)); });
+        break;
+      case EY_ACT_RELU:
+        epi_loop<TM, TN, FULL>(g, acc, m0, n0, wm, wn, c, h,
+                               [&](float v, int, int n, unsigned ci) { EPI_AT(C, ci) = fmaxf(v + bj(n), 0.0f); });
+        break;
+      default:
+        epi_loop<TM, TN, FULL>(g, acc, m0, n0, wm, wn, c, h,
+                               [&](float v, int, int n, unsigned ci) { EPI_AT(C, ci) = v + bj(n); });
+    }
+  }
+}
 template <int TM, int TN, int WGM, int WGN>
 __device__ __forceinline__ void bg_epilogue(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
                                             int h, long b, float rsum, bool do_rowsum, int tid) {
@@ -166,29 +243,26 @@ __device__ __forceinline__ void bg_epilogue(const BG& g, const f32x16 (&acc)[TM]
     if (g.pr_theta_b) rsum = (rsum - (g.pr_theta_b[b * g.bRow + mm] - g.pr_mu_b[mm]) * g.pr_iv_b[mm]) * tscale;
     g.rowsum[b * g.bRow + mm] = rsum;
   }
-  float* C = g.C + b * g.bC;
-  const float* Hm = g.Hm ? g.Hm + b * g.bH : nullptr;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (32 * TN) + 32 * j + c;
-    if (n >= g.N) continue;
-    const float bias = g.bias ? g.bias[b * g.bBias + n] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (32 * TM) + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
-        if (m < g.M) {
-          float v = acc[i][j][r];
-          if (Hm) v *= l_dact(g.act_h, Hm[m * g.sHm + n * g.sHn]);
-          else v = l_act(g.act, v + bias);
-          const long ci = m * g.sCm + n * g.sCn;
-          if (g.pr_theta) v = (v - (g.pr_theta[b * g.bC + ci] - g.pr_mu[ci]) * g.pr_iv[ci]) * tscale;
-          C[ci] = v;
-        }
-      }
-    }
-  }
+  if (m0 + 32 * TM * WGM <= g.M && n0 + 32 * TN * WGN <= g.N) epi_kind<TM, TN, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale);
+  else epi_kind<TM, TN, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale);
+}
+
+// Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD has its own L2: the
+// blocks of one batch item (one chain), which share that chain's operand, would land on 8 different L2s.  Remap the
+// dispatch index so that consecutive LOGICAL blocks run on the same XCD: logical = (id % 8) * (total / 8) + id / 8.
+struct BlockId { int x, y; long z; };
+__device__ __forceinline__ BlockId xcd_block() {
+  const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+  const unsigned total = gx * gy * gz;
+  unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const unsigned body = total & ~7u;
+  if (id < body) id = (id & 7u) * (total >> 3) + (id >> 3);
+  BlockId r;
+  r.x = id % gx;
+  const unsigned t = id / gx;
+  r.y = t % gy;
+  r.z = t / gy;
+  return r;
 }
 
 // C[b] = epilogue(A[b] B[b]).  Block tile BMT x BNT x 16 with two LDS buffers; the 4 waves form a WGM x WGN grid and
@@ -202,8 +276,9 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int m0 = blockIdx.y * BMT, n0 = blockIdx.x * BNT;
-  const long b = blockIdx.z;
+  const BlockId bid = xcd_block();
+  const int m0 = bid.y * BMT, n0 = bid.x * BNT;
+  const long b = bid.z;
   const float* A = g.A + b * g.bA;
   const float* B = g.B + b * g.bB;
   const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
@@ -215,7 +290,7 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int ktiles = (g.K + BK - 1) / BK;
-  const bool do_rowsum = g.rowsum != nullptr && blockIdx.x == 0 && tid < BMT;
+  const bool do_rowsum = g.rowsum != nullptr && bid.x == 0 && tid < BMT;
   float rsum = 0.0f;
   Fetcher<BMT> FA;
   Fetcher<BNT> FB;
@@ -273,8 +348,8 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
 //     contracts k = 2s + h.
 // Three LDS stages; a wave waits for its own pieces of tile t with a counted s_waitcnt (the next tile's stay in flight
 // across the barrier), the barrier makes every wave's pieces visible, then tile t + 2 is issued into the stage that
-// was read two iterations ago.  Requires K % 16 == 0 and 16-byte-divisible leading strides; rows beyond M / N are not
-// fetched (their products land in outputs the epilogue discards).
+// was read two iterations ago.  Requires K % 16 == 0; rows beyond M / N fetch the last row again (their products land
+// in outputs the epilogue discards).
 #define DMA_STAGES 3
 template <bool KFAST>
 __global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
@@ -284,8 +359,9 @@ __global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-  const long b = blockIdx.z;
+  const BlockId bid = xcd_block();
+  const int m0 = bid.y * 128, n0 = bid.x * 128;
+  const long b = bid.z;
   const float* A = g.A + b * g.bA;
   const float* B = g.B + b * g.bB;
   f32x16 acc[2][2];
@@ -296,29 +372,27 @@ __global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int ktiles = g.K / BK;
-  const bool do_rowsum = g.rowsum != nullptr && blockIdx.x == 0 && tid < 128;
+  const bool do_rowsum = g.rowsum != nullptr && bid.x == 0 && tid < 128;
   float rsum = 0.0f;
 
   // this lane's two pieces of every A tile and of every B tile: wave-instruction w2 = 2 wave + i covers slots 64 w2 ..
+  // Rows beyond M / N are CLAMPED to the last row, not skipped: every wave then issues exactly four loads per tile (the
+  // counted s_waitcnt below relies on that -- a wave whose rows are all out of range would otherwise issue fewer and
+  // stop waiting for its own tile), and the loop carries no predicates.  The duplicates feed outputs the epilogue drops.
   const float* srcA[2];
   const float* srcB[2];
-  bool okA[2], okB[2];
   long stepA, stepB;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int slot = 64 * (2 * wave + i) + lane;
     if (KFAST) {
       const int r = slot >> 2, p = slot & 3, kq = p ^ ((r >> 2) & 3);
-      okA[i] = m0 + r < g.M;
-      okB[i] = n0 + r < g.N;
-      srcA[i] = A + (long)(m0 + r) * g.sAm + 4 * kq;
-      srcB[i] = B + (long)(n0 + r) * g.sBn + 4 * kq;
+      srcA[i] = A + (long)min(m0 + r, g.M - 1) * g.sAm + 4 * kq;
+      srcB[i] = B + (long)min(n0 + r, g.N - 1) * g.sBn + 4 * kq;
     } else {
-      const int k = slot >> 5, rq = slot & 31;
-      okA[i] = m0 + 4 * rq < g.M;   // M, N are multiples of 4 here (checked on the host)
-      okB[i] = n0 + 4 * rq < g.N;
-      srcA[i] = A + (long)k * g.sAk + m0 + 4 * rq;
-      srcB[i] = B + (long)k * g.sBk + n0 + 4 * rq;
+      const int k = slot >> 5, rq = slot & 31;  // M, N are multiples of 4 here (checked on the host)
+      srcA[i] = A + (long)k * g.sAk + min(m0 + 4 * rq, g.M - 4);
+      srcB[i] = B + (long)k * g.sBk + min(n0 + 4 * rq, g.N - 4);
     }
   }
   stepA = KFAST ? BK : (long)BK * g.sAk;
@@ -327,12 +401,10 @@ __global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int w2 = 2 * wave + i;
-      if (okA[i])
-        __builtin_amdgcn_global_load_lds(srcA[i] + (long)kt * stepA,
-                                         (__attribute__((address_space(3))) void*)(As[st] + 256 * w2), 16, 0, 0);
-      if (okB[i])
-        __builtin_amdgcn_global_load_lds(srcB[i] + (long)kt * stepB,
-                                         (__attribute__((address_space(3))) void*)(Bs[st] + 256 * w2), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(srcA[i] + (long)kt * stepA,
+                                       (__attribute__((address_space(3))) void*)(As[st] + 256 * w2), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(srcB[i] + (long)kt * stepB,
+                                       (__attribute__((address_space(3))) void*)(Bs[st] + 256 * w2), 16, 0, 0);
     }
   };
   // LDS byte addresses of this lane's fragments inside a stage (see the layouts above)
@@ -532,6 +604,10 @@ static int bgemm(const BG& g, int batch, hipStream_t s) {
 }
 
 static int bgemm_one(const BG& g, int batch, hipStream_t s) {
+  // the epilogue indexes one batch item's output (and H) with 32-bit byte offsets
+  if ((g.M - 1) * g.sCm + (g.N - 1) * g.sCn >= (1L << 30) ||
+      (g.Hm && (g.M - 1) * g.sHm + (g.N - 1) * g.sHn >= (1L << 30)))
+    return EY_ERR_UNSUPPORTED;
   // pick the tile shape by the narrow dimension: a 32-wide tile wastes 4x less on N (or M) <= 32
   if (g.N <= 32) {
     dim3 grid((g.N + 31) / 32, (g.M + 127) / 128, batch);
@@ -761,6 +837,237 @@ bool ey_large_needed(const ey_plan* pl, int nvec) {
   return generic_bytes > 160 * 1024;
 }
 
+
+// ---- the narrow last layer, fused (d_K <= 10 outputs, d = d_{K-1} in {16, 32, 64, 128} inputs): logits, loss, output
+// delta, dW_{K-1}, db_{K-1} and delta_{K-1} = (delta_K W_{K-1}) * act'(H_{K-1}) from ONE pass over H_{K-1}.  As separate
+// launches (narrow forward GEMM, k_loss, narrow dW GEMM, input-gradient product) H_{K-1} is read three times; every one
+// of those is HBM-bound, so this kernel's cost is reading H_{K-1} and writing delta_{K-1} once each.
+// One workgroup per chain.  Thread (rs = tid / 16, q = tid % 16) owns features F q .. F q + F - 1 of row 16 t + rs in pass
+// t: a wave reads 4 consecutive rows (contiguous in memory), 3 passes ahead.  W_{K-1} (d_K x F per thread) and the
+// dW accumulators stay in registers; the 16 lanes of a row combine their partial logits with DPP rotations so that
+// all of them hold the row's logits and compute the (cheap) loss redundantly.  Sums over rows are combined in a fixed
+// order (slots inside a wave, then waves): reproducible.
+#define TAIL_DK 10
+#define TAIL_PF 3
+struct TailArgs {
+  const float* H; float* Dout; const float* theta; float* grad; const float* mu; const float* iv;
+  const float* y; const int* labels; const float* temp; float* lik_o; float* rows_o;
+  long P; int woff, boff, N, d, dK, lik, act_last, act_prev, rows_temp;
+};
+__device__ __forceinline__ float l_act_fast(int code, float g) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return l_sigmoid_fast(g);
+    case EY_ACT_TANH: return l_tanh_fast(g);
+    case EY_ACT_RELU: return g > 0.0f ? g : 0.0f;
+    default: return g;
+  }
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, result in every lane (row_ror 8, 4, 2, 1)
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0x128>(v); v = dpp_add<0x124>(v); v = dpp_add<0x122>(v); v = dpp_add<0x121>(v);
+  return v;
+}
+template <int F>
+__device__ __forceinline__ void tail_load(const float* p, bool ok, float (&h)[F]) {
+  if (!ok) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) h[f] = 0.0f;
+    return;
+  }
+  if constexpr (F >= 4) {
+#pragma unroll
+    for (int f = 0; f < F; f += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + f);
+      h[f] = v.x; h[f + 1] = v.y; h[f + 2] = v.z; h[f + 3] = v.w;
+    }
+  } else if constexpr (F == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    h[0] = v.x; h[1] = v.y;
+  } else {
+    h[0] = p[0];
+  }
+}
+template <int F>
+__device__ __forceinline__ void tail_store(float* p, const float (&h)[F]) {
+  if constexpr (F >= 4) {
+#pragma unroll
+    for (int f = 0; f < F; f += 4) *reinterpret_cast<float4*>(p + f) = make_float4(h[f], h[f + 1], h[f + 2], h[f + 3]);
+  } else if constexpr (F == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(h[0], h[1]);
+  } else {
+    p[0] = h[0];
+  }
+}
+template <int F, bool GRAD>
+__global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
+  __shared__ float red[4][TAIL_DK * 16 * F];
+  __shared__ float redb[4][TAIL_DK];
+  __shared__ float redl[4];
+  const int tid = threadIdx.x, q = tid & 15, rs = tid >> 4, wave = tid >> 6, lane = tid & 63;
+  const long c = blockIdx.x;
+  const int N = a.N, d = a.d, dK = a.dK;
+  const float* Hc = a.H + c * (long)N * d + F * q;
+  const float* th = a.theta + c * a.P;
+  float w[TAIL_DK][F], bias[TAIL_DK];
+#pragma unroll
+  for (int j = 0; j < TAIL_DK; ++j) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) w[j][f] = j < dK ? th[a.woff + j * d + F * q + f] : 0.0f;
+    bias[j] = (j < dK && a.boff >= 0) ? th[a.boff + j] : 0.0f;
+  }
+  float acc[TAIL_DK][F], dbacc[TAIL_DK];
+#pragma unroll
+  for (int j = 0; j < TAIL_DK; ++j) {
+    dbacc[j] = 0.0f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[j][f] = 0.0f;
+  }
+  float lik = 0.0f;
+  const float rowscale = a.rows_temp && a.temp ? a.temp[c] : 1.0f;
+  const int passes = (N + 15) >> 4;
+  float hb[TAIL_PF][F];
+#pragma unroll
+  for (int u = 0; u < TAIL_PF; ++u) {
+    const int n = 16 * u + rs;
+    tail_load<F>(Hc + (long)n * d, u < passes && n < N, hb[u]);
+  }
+  for (int t0 = 0; t0 < passes; t0 += TAIL_PF) {
+#pragma unroll
+    for (int u = 0; u < TAIL_PF; ++u) {
+      const int t = t0 + u;
+      if (t >= passes) break;  // uniform
+      const int n = 16 * t + rs;
+      const bool live = n < N;
+      float h[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) h[f] = hb[u][f];
+      {  // refill this slot with the row TAIL_PF passes ahead
+        const int n2 = n + 16 * TAIL_PF;
+        tail_load<F>(Hc + (long)n2 * d, t + TAIL_PF < passes && n2 < N, hb[u]);
+      }
+      float z[TAIL_DK];
+#pragma unroll
+      for (int j = 0; j < TAIL_DK; ++j) {
+        float pz = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) pz += h[f] * w[j][f];
+        z[j] = j < dK ? l_act_fast(a.act_last, row16_sum(pz) + bias[j]) : 0.0f;
+      }
+      // the row's loss term and dL/dz (same arithmetic as k_loss), in every lane of the row
+      float row = 0.0f, dl[TAIL_DK];
+      if (a.lik == EY_LIK_BCE_SUM) {
+#pragma unroll
+        for (int j = 0; j < TAIL_DK; ++j) {
+          dl[j] = 0.0f;
+          if (j < dK && live) {
+            const float p = z[j], yy = a.y[(long)n * dK + j];
+            row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
+            dl[j] = (yy / p - (1.0f - yy) / (1.0f - p)) * l_dact(a.act_last, p);
+          }
+        }
+      } else {
+        const int lab = live ? a.labels[n] : 0;
+        float mx = z[0];
+#pragma unroll
+        for (int j = 1; j < TAIL_DK; ++j)
+          if (j < dK) mx = fmaxf(mx, z[j]);
+        float e[TAIL_DK], ssum = 0.0f, zlab = 0.0f;
+#pragma unroll
+        for (int j = 0; j < TAIL_DK; ++j) {
+          e[j] = j < dK ? __expf(z[j] - mx) : 0.0f;
+          ssum += e[j];
+          if (j == lab) zlab = z[j];
+        }
+        row = zlab - (mx + __logf(ssum));
+        const float rsum = 1.0f / ssum;
+#pragma unroll
+        for (int j = 0; j < TAIL_DK; ++j)
+          dl[j] = (j < dK && live) ? ((j == lab ? 1.0f : 0.0f) - e[j] * rsum) * l_dact(a.act_last, z[j]) : 0.0f;
+      }
+      if (live) {
+        lik += row;
+        if (a.rows_o && q == 0) a.rows_o[c * (long)N + n] = row * rowscale;
+      }
+      if (GRAD) {
+        float dh[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) dh[f] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < TAIL_DK; ++j) {
+          dbacc[j] += dl[j];
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            acc[j][f] += dl[j] * h[f];
+            dh[f] += dl[j] * w[j][f];
+          }
+        }
+        if (a.Dout && live) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) dh[f] *= l_dact(a.act_prev, h[f]);
+          tail_store<F>(a.Dout + c * (long)N * d + (long)n * d + F * q, dh);
+        }
+      }
+    }
+  }
+  // ---- reductions over rows: slots of a wave (lane bits 4, 5), then the four waves, in that order
+  float lv = q == 0 ? lik : 0.0f;
+  lv += __shfl_xor(lv, 16, 64);
+  lv += __shfl_xor(lv, 32, 64);
+  if (lane == 0) redl[wave] = lv;
+  if (GRAD) {
+#pragma unroll
+    for (int j = 0; j < TAIL_DK; ++j) {
+      float b = dbacc[j];
+      b += __shfl_xor(b, 16, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (lane == 0) redb[wave][j] = b;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        float v = acc[j][f];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) red[wave][j * (16 * F) + F * q + f] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) a.lik_o[c] = ((redl[0] + redl[1]) + redl[2]) + redl[3];
+  if (GRAD) {
+    const float tscale = a.temp ? a.temp[c] : 1.0f;
+    float* gc = a.grad + c * a.P;
+    for (int e = tid; e < dK * d; e += 256) {
+      const int j = e / d, i = e - j * d;
+      const float v = ((red[0][j * (16 * F) + i] + red[1][j * (16 * F) + i]) + red[2][j * (16 * F) + i]) +
+                      red[3][j * (16 * F) + i];
+      const int k = a.woff + e;
+      gc[k] = (v - (th[k] - a.mu[k]) * a.iv[k]) * tscale;
+    }
+    if (a.boff >= 0 && tid < dK) {
+      const float v = ((redb[0][tid] + redb[1][tid]) + redb[2][tid]) + redb[3][tid];
+      const int k = a.boff + tid;
+      gc[k] = (v - (th[k] - a.mu[k]) * a.iv[k]) * tscale;
+    }
+  }
+}
+static bool tail_ok(const EyModel& m) {
+  const int K = m.nl, d = m.dims[K - 1];
+  return K >= 2 && m.dims[K] <= TAIL_DK && (d == 16 || d == 32 || d == 64 || d == 128);
+}
+template <bool GRAD>
+static void tail_launch(const TailArgs& a, int C, hipStream_t s) {
+  switch (a.d / 16) {
+    case 1: hipLaunchKernelGGL((k_tail<1, GRAD>), dim3(C), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_tail<2, GRAD>), dim3(C), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_tail<4, GRAD>), dim3(C), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_tail<8, GRAD>), dim3(C), dim3(256), 0, s, a); break;
+  }
+}
+std::atomic<int> g_ey_no_tail{0};  // ey_debug_set_variant bit 6: the last layer as separate launches (A/B, tests)
+
 void ey_large_free(ey_plan* pl) {
   (void)hipFree(pl->d_work);
   pl->d_work = nullptr;
@@ -803,7 +1110,8 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     }
   }
   int rc;
-  for (int l = 0; l < K; ++l) {
+  const bool tail = tail_ok(m) && !g_ey_no_tail.load();
+  for (int l = 0; l < (tail ? K - 1 : K); ++l) {
     BG g = {};
     g.A = l == 0 ? (const float*)m.x : H[l];
     g.B = theta + m.woff[l];
@@ -816,9 +1124,20 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     g.act = m.act[l];
     if ((rc = bgemm(g, C, s))) return rc;
   }
-  hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
-                     m.dims[K], m.lik, m.act[K - 1], lik_tmp, rows_o, rows_o ? temp : nullptr);
-  const int ltop = K - 1;
+  if (tail) {
+    TailArgs t = {};
+    t.H = H[K - 1]; t.Dout = grad ? D[K - 1] : nullptr; t.theta = theta; t.grad = grad;
+    t.mu = (const float*)m.mu; t.iv = (const float*)m.inv_var; t.y = (const float*)m.y; t.labels = m.labels;
+    t.temp = temp; t.lik_o = lik_tmp; t.rows_o = rows_o; t.P = P; t.woff = m.woff[K - 1]; t.boff = m.boff[K - 1];
+    t.N = N; t.d = m.dims[K - 1]; t.dK = m.dims[K]; t.lik = m.lik; t.act_last = m.act[K - 1]; t.act_prev = m.act[K - 2];
+    t.rows_temp = rows_o != nullptr;
+    if (grad) tail_launch<true>(t, C, s);
+    else tail_launch<false>(t, C, s);
+  } else {
+    hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
+                       m.dims[K], m.lik, m.act[K - 1], lik_tmp, rows_o, rows_o ? temp : nullptr);
+  }
+  const int ltop = tail ? K - 2 : K - 1;
   if (grad) {
     for (int l = ltop; l >= 0; --l) {
       BG g = {};  // dW_l = delta_{l+1}^T H_l, db_l = row sums of delta_{l+1}^T
@@ -1112,4 +1431,16 @@ int ey_large_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int6
     if (rc) return rc;
   }
   return EY_OK;
+}
+
+// Test / measurement entry (not part of the sampler surface): C[b] = act(A[b] B[b] + bias[b]) through the same
+// dispatcher the evaluation uses.  Strides in elements; bias may be null; act is an EY_ACT_* code.
+extern "C" int ey_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int K, long sAm, long sAk, long sBk,
+                              long sBn, long sCm, long sCn, long bA, long bB, long bC, const float* bias, long bBias,
+                              int act, int batch, void* stream) {
+  BG g = {};
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+  g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.sCm = sCm; g.sCn = sCn;
+  g.bA = bA; g.bB = bB; g.bC = bC; g.bias = bias; g.bBias = bBias; g.act = act;
+  return bgemm(g, batch, (hipStream_t)stream);
 }
