@@ -862,6 +862,44 @@ __device__ __forceinline__ float l_act_fast(int code, float g) {
     default: return g;
   }
 }
+template <int n>
+__device__ __forceinline__ void act_vec(int code, float (&v)[n]) {
+  switch (code) {
+    case EY_ACT_SIGMOID:
+#pragma unroll
+      for (int i = 0; i < n; ++i) v[i] = l_sigmoid_fast(v[i]);
+      break;
+    case EY_ACT_TANH:
+#pragma unroll
+      for (int i = 0; i < n; ++i) v[i] = l_tanh_fast(v[i]);
+      break;
+    case EY_ACT_RELU:
+#pragma unroll
+      for (int i = 0; i < n; ++i) v[i] = fmaxf(v[i], 0.0f);
+      break;
+    default: break;
+  }
+}
+template <int n>
+__device__ __forceinline__ void dact_vec(int code, const float (&h)[n], float (&o)[n]) {
+  switch (code) {
+    case EY_ACT_SIGMOID:
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i] = h[i] * (1.0f - h[i]);
+      break;
+    case EY_ACT_TANH:
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i] = 1.0f - h[i] * h[i];
+      break;
+    case EY_ACT_RELU:
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i] = h[i] > 0.0f ? 1.0f : 0.0f;
+      break;
+    default:
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i] = 1.0f;
+  }
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -902,9 +940,25 @@ __device__ __forceinline__ void tail_store(float* p, const float (&h)[F]) {
     p[0] = h[0];
   }
 }
+template <int F>
+__device__ __forceinline__ void tail_wrow(const float* wl, int j, int q, float (&w)[F]) {
+  if constexpr (F >= 4) {
+#pragma unroll
+    for (int p = 0; p < F / 4; ++p) {
+      const float4 v = *reinterpret_cast<const float4*>(wl + (p * TAIL_DK + j) * 64 + 4 * q);
+      w[4 * p] = v.x; w[4 * p + 1] = v.y; w[4 * p + 2] = v.z; w[4 * p + 3] = v.w;
+    }
+  } else if constexpr (F == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(wl + j * 64 + 2 * q);
+    w[0] = v.x; w[1] = v.y;
+  } else {
+    w[0] = wl[j * 64 + q];
+  }
+}
 template <int F, bool GRAD>
 __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
   __shared__ float red[4][TAIL_DK * 16 * F];
+  __shared__ __attribute__((aligned(16))) float wl[(F >= 4 ? F / 4 : 1) * TAIL_DK * 64];
   __shared__ float redb[4][TAIL_DK];
   __shared__ float redl[4];
   const int tid = threadIdx.x, q = tid & 15, rs = tid >> 4, wave = tid >> 6, lane = tid & 63;
@@ -912,13 +966,18 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
   const int N = a.N, d = a.d, dK = a.dK;
   const float* Hc = a.H + c * (long)N * d + F * q;
   const float* th = a.theta + c * a.P;
-  float w[TAIL_DK][F], bias[TAIL_DK];
-#pragma unroll
-  for (int j = 0; j < TAIL_DK; ++j) {
-#pragma unroll
-    for (int f = 0; f < F; ++f) w[j][f] = j < dK ? th[a.woff + j * d + F * q + f] : 0.0f;
-    bias[j] = (j < dK && a.boff >= 0) ? th[a.boff + j] : 0.0f;
+  // W_{K-1} in LDS (rows beyond d_K zero), laid out so that the 16 lanes of a row read consecutive 16-byte pieces:
+  // plane p holds features F q + 4 p .. + 3 of lane q.  (In registers it would cost 10 F of them next to the 10 F
+  // accumulators; the reads are broadcasts over the wave's four rows and cost a few LDS cycles per pass.)
+  for (int idx = tid; idx < TAIL_DK * 16 * F; idx += 256) {
+    const int j = idx / (16 * F), i = idx - j * (16 * F), qq = i / F, f = i - qq * F;
+    const int dst = F >= 4 ? ((f >> 2) * TAIL_DK + j) * 64 + 4 * qq + (f & 3) : j * 64 + F * qq + f;
+    wl[dst] = j < dK ? th[a.woff + j * d + i] : 0.0f;
   }
+  float bias[TAIL_DK];
+#pragma unroll
+  for (int j = 0; j < TAIL_DK; ++j) bias[j] = (j < dK && a.boff >= 0) ? th[a.boff + j] : 0.0f;
+  __syncthreads();
   float acc[TAIL_DK][F], dbacc[TAIL_DK];
 #pragma unroll
   for (int j = 0; j < TAIL_DK; ++j) {
@@ -945,18 +1004,25 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
       float h[F];
 #pragma unroll
       for (int f = 0; f < F; ++f) h[f] = hb[u][f];
+      int qv = q;  // opaque per pass: keeps the W reads below in the loop (hoisted, they would occupy 10 F registers)
+      asm volatile("" : "+v"(qv));
       {  // refill this slot with the row TAIL_PF passes ahead
         const int n2 = n + 16 * TAIL_PF;
         tail_load<F>(Hc + (long)n2 * d, t + TAIL_PF < passes && n2 < N, hb[u]);
       }
-      float z[TAIL_DK];
+      // logits: partial dot products over this lane's features, combined over the row's 16 lanes; rows of W beyond d_K
+      // are zero.  The activation switches sit OUTSIDE the element loops (one uniform branch per pass, not per element).
+      float z[TAIL_DK], da[TAIL_DK];
 #pragma unroll
       for (int j = 0; j < TAIL_DK; ++j) {
-        float pz = 0.0f;
+        float wj[F], pz = 0.0f;
+        tail_wrow<F>(wl, j, qv, wj);
 #pragma unroll
-        for (int f = 0; f < F; ++f) pz += h[f] * w[j][f];
-        z[j] = j < dK ? l_act_fast(a.act_last, row16_sum(pz) + bias[j]) : 0.0f;
+        for (int f = 0; f < F; ++f) pz += h[f] * wj[f];
+        z[j] = row16_sum(pz) + bias[j];
       }
+      act_vec<TAIL_DK>(a.act_last, z);
+      dact_vec<TAIL_DK>(a.act_last, z, da);
       // the row's loss term and dL/dz (same arithmetic as k_loss), in every lane of the row
       float row = 0.0f, dl[TAIL_DK];
       if (a.lik == EY_LIK_BCE_SUM) {
@@ -966,27 +1032,25 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
           if (j < dK && live) {
             const float p = z[j], yy = a.y[(long)n * dK + j];
             row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
-            dl[j] = (yy / p - (1.0f - yy) / (1.0f - p)) * l_dact(a.act_last, p);
+            dl[j] = (yy / p - (1.0f - yy) / (1.0f - p)) * da[j];
           }
         }
       } else {
         const int lab = live ? a.labels[n] : 0;
         float mx = z[0];
 #pragma unroll
-        for (int j = 1; j < TAIL_DK; ++j)
-          if (j < dK) mx = fmaxf(mx, z[j]);
+        for (int j = 1; j < TAIL_DK; ++j) mx = j < dK ? fmaxf(mx, z[j]) : mx;
         float e[TAIL_DK], ssum = 0.0f, zlab = 0.0f;
 #pragma unroll
         for (int j = 0; j < TAIL_DK; ++j) {
           e[j] = j < dK ? __expf(z[j] - mx) : 0.0f;
           ssum += e[j];
-          if (j == lab) zlab = z[j];
+          zlab = j == lab ? z[j] : zlab;
         }
         row = zlab - (mx + __logf(ssum));
-        const float rsum = 1.0f / ssum;
+        const float rsum = live ? 1.0f / ssum : 0.0f;
 #pragma unroll
-        for (int j = 0; j < TAIL_DK; ++j)
-          dl[j] = (j < dK && live) ? ((j == lab ? 1.0f : 0.0f) - e[j] * rsum) * l_dact(a.act_last, z[j]) : 0.0f;
+        for (int j = 0; j < TAIL_DK; ++j) dl[j] = ((j == lab && live ? 1.0f : 0.0f) - e[j] * rsum) * da[j];
       }
       if (live) {
         lik += row;
@@ -998,16 +1062,20 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
         for (int f = 0; f < F; ++f) dh[f] = 0.0f;
 #pragma unroll
         for (int j = 0; j < TAIL_DK; ++j) {
+          float wj[F];
+          tail_wrow<F>(wl, j, qv, wj);
           dbacc[j] += dl[j];
 #pragma unroll
           for (int f = 0; f < F; ++f) {
             acc[j][f] += dl[j] * h[f];
-            dh[f] += dl[j] * w[j][f];
+            dh[f] += dl[j] * wj[f];
           }
         }
         if (a.Dout && live) {
+          float dp[F];
+          dact_vec<F>(a.act_prev, h, dp);
 #pragma unroll
-          for (int f = 0; f < F; ++f) dh[f] *= l_dact(a.act_prev, h[f]);
+          for (int f = 0; f < F; ++f) dh[f] *= dp[f];
           tail_store<F>(a.Dout + c * (long)N * d + (long)n * d + F * q, dh);
         }
       }
