@@ -118,7 +118,7 @@ std::atomic<int> g_ey_force_large{0};  // ey_debug_set_variant bit 4: route f32 
 static bool use_mfma32(const ey_plan* pl) { return pl->mfma32_ok && (pl->mfma32_data_ok || !pl->has_data); }
 // nvec: state vectors the generic kernel of the calling operation keeps in LDS (2 value/MH, 3 HMC, 4 MALA)
 static bool use_large(const ey_plan* pl, int nvec = 3) {
-  return pl->dtype == EY_F32 && (ey_large_needed(pl, nvec) || (g_ey_force_large.load() && !pl->mfma32_ok));
+  return ey_large_needed(pl, nvec) || (g_ey_force_large.load() && !pl->mfma32_ok);
 }
 // the fused 16x16x4 kernels serve this plan (any batch size: their data image lives in global memory)
 static bool use_fused16(const ey_plan* pl) { return pl->fused16_ok && !g_ey_force_large.load(); }

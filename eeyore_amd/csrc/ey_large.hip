@@ -28,20 +28,22 @@ std::atomic<int> g_ey_no_dma{0};
 #endif
 #define LDT(R) ((R) + 4)  // [k][row] image of an R-row operand tile: 16-byte aligned rows, staggered over banks
 
-struct BG {
-  const float* A; const float* B; float* C;
+template <class T>
+struct BGT {
+  const T* A; const T* B; T* C;
   int M, N, K;
   long sAm, sAk, sBk, sBn, sCm, sCn;  // element strides
   long bA, bB, bC;                    // batch strides (0 = shared operand)
-  const float* bias; long bBias;      // bias along n, per batch (nullable)
+  const T* bias; long bBias;      // bias along n, per batch (nullable)
   int act;                            // activation applied to acc + bias
-  const float* Hm; long sHm, sHn, bH; // if set: C = acc * act'(Hm[m][n]) with act_h
+  const T* Hm; long sHm, sHn, bH; // if set: C = acc * act'(Hm[m][n]) with act_h
   int act_h;
-  float* rowsum; long bRow;           // if set: rowsum[m] = sum_k A[m][k] (the bias gradient of a dW product)
+  T* rowsum; long bRow;           // if set: rowsum[m] = sum_k A[m][k] (the bias gradient of a dW product)
   // if pr_theta is set the product is a weight gradient: the output becomes (acc - (theta - mu) / sigma^2) * t, i.e.
   // the prior gradient and the temperature are applied here (indexed like C; *_b like rowsum), batch stride bC / bRow
-  const float *pr_theta, *pr_mu, *pr_iv, *pr_theta_b, *pr_mu_b, *pr_iv_b, *pr_temp;
+  const T *pr_theta, *pr_mu, *pr_iv, *pr_theta_b, *pr_mu_b, *pr_iv_b, *pr_temp;
 };
+using BG = BGT<float>;
 
 __device__ __forceinline__ float l_act(int code, float g) {
   switch (code) {
@@ -51,12 +53,30 @@ __device__ __forceinline__ float l_act(int code, float g) {
     default: return g;
   }
 }
-__device__ __forceinline__ float l_dact(int code, float h) {
+template <class T>
+__device__ __forceinline__ T l_dact(int code, T h) {
   switch (code) {
-    case EY_ACT_SIGMOID: return h * (1.0f - h);
-    case EY_ACT_TANH: return 1.0f - h * h;
-    case EY_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
-    default: return 1.0f;
+    case EY_ACT_SIGMOID: return h * (T(1) - h);
+    case EY_ACT_TANH: return T(1) - h * h;
+    case EY_ACT_RELU: return h > T(0) ? T(1) : T(0);
+    default: return T(1);
+  }
+}
+// the elementwise kernels below are written once for f32 and f64: f32 keeps the fast intrinsics, f64 the library
+__device__ __forceinline__ float l_exp(float x) { return __expf(x); }
+__device__ __forceinline__ double l_exp(double x) { return exp(x); }
+__device__ __forceinline__ float l_log(float x) { return __logf(x); }
+__device__ __forceinline__ double l_log(double x) { return log(x); }
+__device__ __forceinline__ float l_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double l_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float l_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double l_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double l_act(int code, double g) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return 1.0 / (1.0 + exp(-g));
+    case EY_ACT_TANH: return tanh(g);
+    case EY_ACT_RELU: return g > 0.0 ? g : 0.0;
+    default: return g;
   }
 }
 
@@ -629,47 +649,183 @@ static int bgemm_one(const BG& g, int batch, hipStream_t s) {
   return EY_OK;
 }
 
-__device__ __forceinline__ float block_sum(float v, float* red) {
+
+// ---- f64 (the reference's default dtype, eeyore/models/model.py:7): the same three products on
+// v_mfma_f64_16x16x4_f64.  64 x 64 x 8 block tile through two LDS buffers (register-staged fetch of the next k-tile
+// while the current one is multiplied), the 4 waves in a 2 x 2 grid, each owning 2 x 2 MFMA tiles of 16 x 16.
+// Operand lane (i = lane & 15, k = lane >> 4); accumulator register r of lane (g = lane >> 4, c = lane & 15) is element
+// (row 4 r + g, column c) (profiles/r02_mfma_f64_lane_map.txt).  One generic kernel serves every shape of the path --
+// the f64 path exists for parity runs of models beyond LDS, not for the headline rate.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#define BK64 8
+#define LD64 66  // [k][64 rows] image, rows padded: 16-byte aligned pairs, k-rows staggered over the banks
+struct Fetch64 {
+  const double* base;  // this thread's pair in k-tile 0
+  int row, kk;         // global row of the pair's first element; k offset inside a k-tile
+  int lds;             // where the pair goes in the [k][row] image
+  long sRow, sK, step;
+  int rows, K;
+  bool kfast;
+  __device__ __forceinline__ void init(const double* P, long sRow_, long sK_, int row0, int rows_, int K_, int tid) {
+    sRow = sRow_; sK = sK_; rows = rows_; K = K_; kfast = sK_ == 1;
+    const int e = 2 * tid;  // 64 x 8 elements, two per thread along the contiguous stride
+    int r;
+    if (kfast) { r = e >> 3; kk = e & 7; } else { r = e & 63; kk = e >> 6; }
+    row = row0 + r;
+    lds = kk * LD64 + r;
+    base = P + (long)row * sRow + (long)kk * sK;
+    step = (long)BK64 * sK;
+  }
+  __device__ __forceinline__ void load(int kt, double (&v)[2]) const {
+    const double* src = base + (long)kt * step;
+    const int gk = kt * BK64 + kk;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r2 = kfast ? row : row + j, k2 = kfast ? gk + j : gk;
+      v[j] = (r2 < rows && k2 < K) ? src[kfast ? (long)j * sK : (long)j * sRow] : 0.0;
+    }
+  }
+  __device__ __forceinline__ void store(double* T, const double (&v)[2]) const {
+    if (kfast) { T[lds] = v[0]; T[lds + LD64] = v[1]; }
+    else { T[lds] = v[0]; T[lds + 1] = v[1]; }
+  }
+};
+__global__ void __launch_bounds__(256) k_bgemm_f64(BGT<double> g) {
+  __shared__ __attribute__((aligned(16))) double As[2][BK64 * LD64];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK64 * LD64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, gq = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const BlockId bid = xcd_block();
+  const int m0 = bid.y * 64, n0 = bid.x * 64;
+  const long b = bid.z;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+  Fetch64 FA, FB;
+  FA.init(g.A + b * g.bA, g.sAm, g.sAk, m0, g.M, g.K, tid);
+  FB.init(g.B + b * g.bB, g.sBn, g.sBk, n0, g.N, g.K, tid);
+  const int ktiles = (g.K + BK64 - 1) / BK64;
+  const bool do_rowsum = g.rowsum != nullptr && bid.x == 0 && tid < 64;
+  double rsum = 0.0;
+  double fa[2], fb[2];
+  FA.load(0, fa);
+  FB.load(0, fb);
+  FA.store(As[0], fa);
+  FB.store(Bs[0], fb);
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < ktiles) { FA.load(kt + 1, fa); FB.load(kt + 1, fb); }
+    const double* Ac = As[cur];
+    const double* Bc = Bs[cur];
+#pragma unroll
+    for (int s4 = 0; s4 < BK64 / 4; ++s4) {
+      double av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = Ac[(4 * s4 + gq) * LD64 + wm * 32 + 16 * i + c];
+        bv[i] = Bc[(4 * s4 + gq) * LD64 + wn * 32 + 16 * i + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_rowsum) {
+#pragma unroll
+      for (int k = 0; k < BK64; ++k) rsum += Ac[k * LD64 + tid];
+    }
+    if (kt + 1 < ktiles) {
+      FA.store(As[cur ^ 1], fa);
+      FB.store(Bs[cur ^ 1], fb);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue (the kinds of bg_epilogue, in double with the library functions)
+  const double tscale = g.pr_temp ? g.pr_temp[b] : 1.0;
+  if (do_rowsum && m0 + tid < g.M) {
+    const int mm = m0 + tid;
+    if (g.pr_theta_b) rsum = (rsum - (g.pr_theta_b[b * g.bRow + mm] - g.pr_mu_b[mm]) * g.pr_iv_b[mm]) * tscale;
+    g.rowsum[b * g.bRow + mm] = rsum;
+  }
+  double* C = g.C + b * g.bC;
+  const double* Hm = g.Hm ? g.Hm + b * g.bH : nullptr;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 32 + 16 * j + c;
+    if (n >= g.N) continue;
+    const double bias = g.bias ? g.bias[b * g.bBias + n] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + 16 * i + 4 * r + gq;
+        if (m >= g.M) continue;
+        double v = acc[i][j][r];
+        if (Hm) v *= l_dact(g.act_h, Hm[m * g.sHm + n * g.sHn]);
+        else v = l_act(g.act, v + bias);
+        const long ci = m * g.sCm + n * g.sCn;
+        if (g.pr_theta) v = (v - (g.pr_theta[b * g.bC + ci] - g.pr_mu[ci]) * g.pr_iv[ci]) * tscale;
+        C[ci] = v;
+      }
+    }
+  }
+}
+static int bgemm(const BGT<double>& g, int batch, hipStream_t s) {
+  dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
+  hipLaunchKernelGGL(k_bgemm_f64, grid, dim3(256), 0, s, g);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+
+template <class T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) red[wave] = v;
   __syncthreads();
-  float t = 0.0f;
+  T t = T(0.0);
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
   return t;
 }
 
 // log-likelihood of every chain and the output delta = dL/dh_K * act'(h_K); one block per chain
-__global__ void __launch_bounds__(256) k_loss(const float* __restrict__ out, float* __restrict__ delta,
-                                              const float* __restrict__ y, const int* __restrict__ labels, int N, int dK,
-                                              int lik_code, int act_last, float* __restrict__ lik_o,
-                                              float* __restrict__ rows_o, const float* __restrict__ temp) {
-  __shared__ float red[4];
+template <class T>
+__global__ void __launch_bounds__(256) k_loss(const T* __restrict__ out, T* __restrict__ delta,
+                                              const T* __restrict__ y, const int* __restrict__ labels, int N, int dK,
+                                              int lik_code, int act_last, T* __restrict__ lik_o,
+                                              T* __restrict__ rows_o, const T* __restrict__ temp) {
+  __shared__ T red[4];
   const long c = blockIdx.x;
-  const float* o = out + c * (long)N * dK;
-  float* d = delta + c * (long)N * dK;
-  float lik = 0.0f;
+  const T* o = out + c * (long)N * dK;
+  T* d = delta + c * (long)N * dK;
+  T lik = T(0.0);
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    float row = 0.0f;  // this row's term of the sum (ey_log_lik_rows)
+    T row = T(0.0);  // this row's term of the sum (ey_log_lik_rows)
     if (lik_code == EY_LIK_BCE_SUM) {
       for (int j = 0; j < dK; ++j) {
-        const float p = o[n * dK + j], yy = y[n * dK + j];
-        row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
-        d[n * dK + j] = (yy / p - (1.0f - yy) / (1.0f - p)) * l_dact(act_last, p);
+        const T p = o[n * dK + j], yy = y[n * dK + j];
+        row += l_log(p) * yy + l_log(T(1.0) - p) * (T(1.0) - yy);  // naive logs (eeyore/stats/loss.py:2)
+        d[n * dK + j] = (yy / p - (T(1.0) - yy) / (T(1.0) - p)) * l_dact(act_last, p);
       }
     } else {
       const int lab = labels[n];
-      float mx = o[n * dK];
-      for (int j = 1; j < dK; ++j) mx = fmaxf(mx, o[n * dK + j]);
-      float ssum = 0.0f;
-      for (int j = 0; j < dK; ++j) ssum += __expf(o[n * dK + j] - mx);
-      row = o[n * dK + lab] - (mx + __logf(ssum));
-      const float rs = 1.0f / ssum;
+      T mx = o[n * dK];
+      for (int j = 1; j < dK; ++j) mx = l_max(mx, o[n * dK + j]);
+      T ssum = T(0.0);
+      for (int j = 0; j < dK; ++j) ssum += l_exp(o[n * dK + j] - mx);
+      row = o[n * dK + lab] - (mx + l_log(ssum));
+      const T rs = T(1.0) / ssum;
       for (int j = 0; j < dK; ++j) {
-        const float v = o[n * dK + j];
-        d[n * dK + j] = ((j == lab ? 1.0f : 0.0f) - __expf(v - mx) * rs) * l_dact(act_last, v);
+        const T v = o[n * dK + j];
+        d[n * dK + j] = ((j == lab ? T(1.0) : T(0.0)) - l_exp(v - mx) * rs) * l_dact(act_last, v);
       }
     }
     lik += row;
@@ -680,21 +836,22 @@ __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ out, flo
 }
 
 // prior value, temperature, log-target; one block per chain
-__global__ void __launch_bounds__(256) k_prior(const float* __restrict__ theta, const float* __restrict__ mu,
-                                               const float* __restrict__ iv, float prior_const, int P,
-                                               const float* __restrict__ temp, const float* __restrict__ lik,
-                                               float* lik_o, float* prior_o, float* target_o) {
-  __shared__ float red[4];
+template <class T>
+__global__ void __launch_bounds__(256) k_prior(const T* __restrict__ theta, const T* __restrict__ mu,
+                                               const T* __restrict__ iv, T prior_const, int P,
+                                               const T* __restrict__ temp, const T* __restrict__ lik,
+                                               T* lik_o, T* prior_o, T* target_o) {
+  __shared__ T red[4];
   const long c = blockIdx.x;
-  const float t = temp ? temp[c] : 1.0f;
-  float q = 0.0f;
+  const T t = temp ? temp[c] : T(1.0);
+  T q = T(0.0);
   for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    const float d = theta[c * P + i] - mu[i];
+    const T d = theta[c * P + i] - mu[i];
     q += d * d * iv[i];
   }
   q = block_sum(q, red);
   if (threadIdx.x == 0) {
-    const float pr = (prior_const - 0.5f * q) * t, lk = lik[c] * t;
+    const T pr = (prior_const - T(0.5) * q) * t, lk = lik[c] * t;
     if (lik_o) lik_o[c] = lk;
     if (prior_o) prior_o[c] = pr;
     if (target_o) target_o[c] = lk + pr;
@@ -702,23 +859,24 @@ __global__ void __launch_bounds__(256) k_prior(const float* __restrict__ theta, 
 }
 
 // ---- HMC elementwise pieces (one block per chain)
-__global__ void __launch_bounds__(256) k_hmc_begin(const float* theta, const float* grad, const float* p0, float* thp,
-                                                   float* p, float* gp, int P, uint64_t seed, uint64_t iter,
-                                                   uint64_t chain_offset, const float* target, float* hcur) {
-  __shared__ float red[4];
+template <class T>
+__global__ void __launch_bounds__(256) k_hmc_begin(const T* theta, const T* grad, const T* p0, T* thp,
+                                                   T* p, T* gp, int P, uint64_t seed, uint64_t iter,
+                                                   uint64_t chain_offset, const T* target, T* hcur) {
+  __shared__ T red[4];
   const long c = blockIdx.x;
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
-  float kin = 0.0f;
+  T kin = T(0.0);
   // momentum (hmc.py:134): one block of four stream elements per thread and round (one Philox call each)
   for (int b = threadIdx.x; 4 * b < P; b += blockDim.x) {
-    float o[4];
-    if (!p0) ey_rng_normal4<float>(rn, (uint32_t)b, o);
+    T o[4];
+    if (!p0) ey_rng_normal4<T>(rn, (uint32_t)b, o);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = 4 * b + j;
       if (i >= P) break;
       const long k = c * P + i;
-      const float pv = p0 ? p0[k] : o[j];
+      const T pv = p0 ? p0[k] : o[j];
       p[k] = pv;
       kin += pv * pv;
       thp[k] = theta[k];
@@ -726,7 +884,7 @@ __global__ void __launch_bounds__(256) k_hmc_begin(const float* theta, const flo
     }
   }
   kin = block_sum(kin, red);
-  if (threadIdx.x == 0) hcur[c] = -target[c] + 0.5f * kin;  // hmc.py:91-98,137
+  if (threadIdx.x == 0) hcur[c] = -target[c] + T(0.5) * kin;  // hmc.py:91-98,137
 }
 
 // p += wp * eps * g ; then theta += wt * eps * p   (either weight may be 0)
@@ -736,35 +894,36 @@ __global__ void __launch_bounds__(256) k_hmc_begin(const float* theta, const flo
 #define LEAP_EPT 8                 // elements per thread: eight independent load chains in flight
 #define LEAP_BLOCK (256 * LEAP_EPT)
 static inline int leap_blocks(int P) { return (P + LEAP_BLOCK - 1) / LEAP_BLOCK; }
-__global__ void __launch_bounds__(256) k_leap(float* thp, float* p, const float* gp, int P, float step,
-                                              const float* step_vec, float wp, float wt, const float* __restrict__ mu,
-                                              const float* __restrict__ iv, float* __restrict__ qpart) {
-  __shared__ float red[4];
+template <class T>
+__global__ void __launch_bounds__(256) k_leap(T* thp, T* p, const T* gp, int P, T step,
+                                              const T* step_vec, T wp, T wt, const T* __restrict__ mu,
+                                              const T* __restrict__ iv, T* __restrict__ qpart) {
+  __shared__ T red[4];
   const long c = blockIdx.y;
   const int i0 = blockIdx.x * LEAP_BLOCK + threadIdx.x;
-  const float eps = step_vec ? step_vec[c] : step;
-  const float ep = wp * eps, et = wt * eps;
-  float pv[LEAP_EPT], tv[LEAP_EPT], gv[LEAP_EPT], mv[LEAP_EPT], vv[LEAP_EPT];
+  const T eps = step_vec ? step_vec[c] : step;
+  const T ep = wp * eps, et = wt * eps;
+  T pv[LEAP_EPT], tv[LEAP_EPT], gv[LEAP_EPT], mv[LEAP_EPT], vv[LEAP_EPT];
 #pragma unroll
   for (int j = 0; j < LEAP_EPT; ++j) {
     const int i = i0 + j * 256;
     const long k = c * P + i;
     const bool in = i < P;
-    pv[j] = in ? p[k] : 0.0f;
-    gv[j] = in && wp != 0.0f ? gp[k] : 0.0f;
-    tv[j] = in ? thp[k] : 0.0f;
-    mv[j] = in ? mu[i] : 0.0f;
-    vv[j] = in ? iv[i] : 0.0f;
+    pv[j] = in ? p[k] : T(0.0);
+    gv[j] = in && wp != T(0.0) ? gp[k] : T(0.0);
+    tv[j] = in ? thp[k] : T(0.0);
+    mv[j] = in ? mu[i] : T(0.0);
+    vv[j] = in ? iv[i] : T(0.0);
   }
-  float q = 0.0f;
+  T q = T(0.0);
 #pragma unroll
   for (int j = 0; j < LEAP_EPT; ++j) {
     const int i = i0 + j * 256;
     const long k = c * P + i;
     if (i < P) {
-      if (wp != 0.0f) { pv[j] = pv[j] + ep * gv[j]; p[k] = pv[j]; }
-      if (wt != 0.0f) { tv[j] = tv[j] + et * pv[j]; thp[k] = tv[j]; }
-      const float d = tv[j] - mv[j];
+      if (wp != T(0.0)) { pv[j] = pv[j] + ep * gv[j]; p[k] = pv[j]; }
+      if (wt != T(0.0)) { tv[j] = tv[j] + et * pv[j]; thp[k] = tv[j]; }
+      const T d = tv[j] - mv[j];
       q += d * d * vv[j];
     }
   }
@@ -774,41 +933,43 @@ __global__ void __launch_bounds__(256) k_leap(float* thp, float* p, const float*
 
 // log-target from the likelihood and the per-block partials of the prior quadratic form; one wave per chain, lanes
 // stride over the partials and combine with a fixed shuffle tree (reproducible)
-__global__ void __launch_bounds__(256) k_target(const float* __restrict__ qpart, int nblk, float prior_const,
-                                                const float* __restrict__ temp, const float* __restrict__ lik, int C,
-                                                float* lik_o, float* prior_o, float* target_o) {
+template <class T>
+__global__ void __launch_bounds__(256) k_target(const T* __restrict__ qpart, int nblk, T prior_const,
+                                                const T* __restrict__ temp, const T* __restrict__ lik, int C,
+                                                T* lik_o, T* prior_o, T* target_o) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (c >= C) return;
-  float q = 0.0f;
+  T q = T(0.0);
   for (int j = lane; j < nblk; j += 64) q += qpart[(long)c * nblk + j];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   if (lane != 0) return;
-  const float t = temp ? temp[c] : 1.0f;
-  const float pr = (prior_const - 0.5f * q) * t, lk = lik[c] * t;
+  const T t = temp ? temp[c] : T(1.0);
+  const T pr = (prior_const - T(0.5) * q) * t, lk = lik[c] * t;
   if (lik_o) lik_o[c] = lk;
   if (prior_o) prior_o[c] = pr;
   if (target_o) target_o[c] = lk + pr;
 }
 
-__global__ void __launch_bounds__(256) k_hmc_end(float* theta, float* grad, float* target, const float* thp,
-                                                 const float* p, const float* gp, const float* tprop, const float* hcur,
-                                                 const float* u_in, int P, uint64_t seed, uint64_t iter,
-                                                 uint64_t chain_offset, unsigned char* accepted, float* rate_o,
-                                                 float* hcur_o, float* hprop_o) {
-  __shared__ float red[4];
+template <class T>
+__global__ void __launch_bounds__(256) k_hmc_end(T* theta, T* grad, T* target, const T* thp,
+                                                 const T* p, const T* gp, const T* tprop, const T* hcur,
+                                                 const T* u_in, int P, uint64_t seed, uint64_t iter,
+                                                 uint64_t chain_offset, unsigned char* accepted, T* rate_o,
+                                                 T* hcur_o, T* hprop_o) {
+  __shared__ T red[4];
   __shared__ int s_acc;
   const long c = blockIdx.x;
-  float kin = 0.0f;
+  T kin = T(0.0);
   for (int i = threadIdx.x; i < P; i += blockDim.x) kin += p[c * P + i] * p[c * P + i];
   kin = block_sum(kin, red);
   if (threadIdx.x == 0) {
-    const float h_prop = -tprop[c] + 0.5f * kin;
-    float rate = __expf(hcur[c] - h_prop);  // hmc.py:143-146
-    if (rate > 1.0f) rate = 1.0f;
+    const T h_prop = -tprop[c] + T(0.5) * kin;
+    T rate = l_exp(hcur[c] - h_prop);  // hmc.py:143-146
+    if (rate > T(1.0)) rate = T(1.0);
     const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
-    const float u = u_in ? u_in[c] : ey_rng_uniform<float>(ru);
+    const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
     const int acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
     s_acc = acc;
     accepted[c] = (unsigned char)acc;
@@ -831,9 +992,9 @@ __global__ void __launch_bounds__(256) k_hmc_end(float* theta, float* grad, floa
 // draw, 3 for HMC, 4 for MALA, ey_generic.hip): a model may fit for one operation and not for another
 bool ey_large_needed(const ey_plan* pl, int nvec) {
   const EyModel& m = pl->m;
-  if (pl->dtype != EY_F32) return false;
   const size_t Ppad = (m.P + 3) & ~3;
-  const size_t generic_bytes = 4 * ((size_t)nvec * Ppad + (size_t)m.hrows * 65 + 2 * (size_t)m.dmax * 65);
+  const size_t esz = pl->dtype == EY_F32 ? 4 : 8;
+  const size_t generic_bytes = esz * ((size_t)nvec * Ppad + (size_t)m.hrows * 65 + 2 * (size_t)m.dmax * 65);
   return generic_bytes > 160 * 1024;
 }
 
@@ -1160,15 +1321,16 @@ static size_t act_floats_per_chain(const EyModel& m) {
 }
 
 // value (+ gradient when grad != null) for chains [0, C) of theta, using `ws` (2 * C * act_floats floats) as scratch
-static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C, float* lik_o, float* prior_o,
-                      float* target_o, float* grad, float* ws, float* lik_tmp, hipStream_t s,
-                      const float* qpart = nullptr, float* rows_o = nullptr) {
+template <class T>
+static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_o, T* prior_o,
+                      T* target_o, T* grad, T* ws, T* lik_tmp, hipStream_t s,
+                      const T* qpart = nullptr, T* rows_o = nullptr) {
   const EyModel& m = pl->m;
   const int K = m.nl, N = m.N, P = m.P;
   const size_t af = act_floats_per_chain(m);
-  float* Hbase = ws;
-  float* Dbase = ws + (size_t)C * af;
-  std::vector<float*> H(K + 1), D(K + 1);
+  T* Hbase = ws;
+  T* Dbase = ws + (size_t)C * af;
+  std::vector<T*> H(K + 1), D(K + 1);
   {
     size_t off = 0;
     for (int l = 1; l <= K; ++l) {
@@ -1178,10 +1340,10 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     }
   }
   int rc;
-  const bool tail = tail_ok(m) && !g_ey_no_tail.load();
+  const bool tail = sizeof(T) == 4 && tail_ok(m) && !g_ey_no_tail.load();
   for (int l = 0; l < (tail ? K - 1 : K); ++l) {
-    BG g = {};
-    g.A = l == 0 ? (const float*)m.x : H[l];
+    BGT<T> g = {};
+    g.A = l == 0 ? (const T*)m.x : H[l];
     g.B = theta + m.woff[l];
     g.C = H[l + 1];
     g.M = N; g.N = m.dims[l + 1]; g.K = m.dims[l];
@@ -1192,37 +1354,39 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     g.act = m.act[l];
     if ((rc = bgemm(g, C, s))) return rc;
   }
-  if (tail) {
-    TailArgs t = {};
-    t.H = H[K - 1]; t.Dout = grad ? D[K - 1] : nullptr; t.theta = theta; t.grad = grad;
-    t.mu = (const float*)m.mu; t.iv = (const float*)m.inv_var; t.y = (const float*)m.y; t.labels = m.labels;
-    t.temp = temp; t.lik_o = lik_tmp; t.rows_o = rows_o; t.P = P; t.woff = m.woff[K - 1]; t.boff = m.boff[K - 1];
-    t.N = N; t.d = m.dims[K - 1]; t.dK = m.dims[K]; t.lik = m.lik; t.act_last = m.act[K - 1]; t.act_prev = m.act[K - 2];
-    t.rows_temp = rows_o != nullptr;
-    if (grad) tail_launch<true>(t, C, s);
-    else tail_launch<false>(t, C, s);
-  } else {
-    hipLaunchKernelGGL(k_loss, dim3(C), dim3(256), 0, s, (const float*)H[K], D[K], (const float*)m.y, m.labels, N,
-                       m.dims[K], m.lik, m.act[K - 1], lik_tmp, rows_o, rows_o ? temp : nullptr);
+  if constexpr (sizeof(T) == 4) {
+    if (tail) {
+      TailArgs t = {};
+      t.H = H[K - 1]; t.Dout = grad ? D[K - 1] : nullptr; t.theta = theta; t.grad = grad;
+      t.mu = (const T*)m.mu; t.iv = (const T*)m.inv_var; t.y = (const T*)m.y; t.labels = m.labels;
+      t.temp = temp; t.lik_o = lik_tmp; t.rows_o = rows_o; t.P = P; t.woff = m.woff[K - 1]; t.boff = m.boff[K - 1];
+      t.N = N; t.d = m.dims[K - 1]; t.dK = m.dims[K]; t.lik = m.lik; t.act_last = m.act[K - 1];
+      t.act_prev = m.act[K - 2]; t.rows_temp = rows_o != nullptr;
+      if (grad) tail_launch<true>(t, C, s);
+      else tail_launch<false>(t, C, s);
+    }
   }
+  if (!tail)
+    hipLaunchKernelGGL((k_loss<T>), dim3(C), dim3(256), 0, s, (const T*)H[K], D[K], (const T*)m.y, m.labels, N,
+                       m.dims[K], m.lik, m.act[K - 1], lik_tmp, rows_o, rows_o ? temp : nullptr);
   const int ltop = tail ? K - 2 : K - 1;
   if (grad) {
     for (int l = ltop; l >= 0; --l) {
-      BG g = {};  // dW_l = delta_{l+1}^T H_l, db_l = row sums of delta_{l+1}^T
+      BGT<T> g = {};  // dW_l = delta_{l+1}^T H_l, db_l = row sums of delta_{l+1}^T
       g.A = D[l + 1]; g.sAm = 1; g.sAk = m.dims[l + 1]; g.bA = (long)N * m.dims[l + 1];
-      g.B = l == 0 ? (const float*)m.x : H[l]; g.sBk = m.dims[l]; g.sBn = 1; g.bB = l == 0 ? 0 : (long)N * m.dims[l];
+      g.B = l == 0 ? (const T*)m.x : H[l]; g.sBk = m.dims[l]; g.sBn = 1; g.bB = l == 0 ? 0 : (long)N * m.dims[l];
       g.C = grad + m.woff[l]; g.sCm = m.dims[l]; g.sCn = 1; g.bC = P;
       g.M = m.dims[l + 1]; g.N = m.dims[l]; g.K = N; g.act = EY_ACT_NONE;
       if (m.boff[l] >= 0) { g.rowsum = grad + m.boff[l]; g.bRow = P; }
-      g.pr_theta = theta + m.woff[l]; g.pr_mu = (const float*)m.mu + m.woff[l]; g.pr_iv = (const float*)m.inv_var + m.woff[l];
+      g.pr_theta = theta + m.woff[l]; g.pr_mu = (const T*)m.mu + m.woff[l]; g.pr_iv = (const T*)m.inv_var + m.woff[l];
       if (m.boff[l] >= 0) {
-        g.pr_theta_b = theta + m.boff[l]; g.pr_mu_b = (const float*)m.mu + m.boff[l];
-        g.pr_iv_b = (const float*)m.inv_var + m.boff[l];
+        g.pr_theta_b = theta + m.boff[l]; g.pr_mu_b = (const T*)m.mu + m.boff[l];
+        g.pr_iv_b = (const T*)m.inv_var + m.boff[l];
       }
       g.pr_temp = temp;
       if ((rc = bgemm(g, C, s))) return rc;
       if (l > 0) {
-        BG d = {};  // delta_l = (delta_{l+1} W_l) * act'(H_l)
+        BGT<T> d = {};  // delta_l = (delta_{l+1} W_l) * act'(H_l)
         d.A = D[l + 1]; d.sAm = m.dims[l + 1]; d.sAk = 1; d.bA = (long)N * m.dims[l + 1];
         d.B = theta + m.woff[l]; d.sBk = m.dims[l]; d.sBn = 1; d.bB = P;
         d.C = D[l]; d.sCm = m.dims[l]; d.sCn = 1; d.bC = (long)N * m.dims[l];
@@ -1233,17 +1397,17 @@ static int eval_chunk(ey_plan* pl, const float* theta, const float* temp, int C,
     }
   }
   if (qpart)
-    hipLaunchKernelGGL(k_target, dim3((C + 3) / 4), dim3(256), 0, s, qpart, leap_blocks(P), (float)m.prior_const,
-                       temp, (const float*)lik_tmp, C, lik_o, prior_o, target_o);
+    hipLaunchKernelGGL((k_target<T>), dim3((C + 3) / 4), dim3(256), 0, s, qpart, leap_blocks(P), (T)m.prior_const,
+                       temp, (const T*)lik_tmp, C, lik_o, prior_o, target_o);
   else
-    hipLaunchKernelGGL(k_prior, dim3(C), dim3(256), 0, s, theta, (const float*)m.mu, (const float*)m.inv_var,
-                       (float)m.prior_const, P, temp, (const float*)lik_tmp, lik_o, prior_o, target_o);
+    hipLaunchKernelGGL((k_prior<T>), dim3(C), dim3(256), 0, s, theta, (const T*)m.mu, (const T*)m.inv_var,
+                       (T)m.prior_const, P, temp, (const T*)lik_tmp, lik_o, prior_o, target_o);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
 
 static int chunk_size(const ey_plan* pl, int64_t C) {
-  const size_t per_chain = 2 * act_floats_per_chain(pl->m) * sizeof(float);
+  const size_t per_chain = 2 * act_floats_per_chain(pl->m) * (pl->dtype == EY_F32 ? 4 : 8);
   size_t cap = (size_t)3 << 30;  // activation scratch budget
   int64_t cc = (int64_t)(cap / (per_chain ? per_chain : 1));
   if (cc < 1) cc = 1;
@@ -1251,26 +1415,32 @@ static int chunk_size(const ey_plan* pl, int64_t C) {
   return (int)(cc < C ? cc : C);
 }
 
-int ey_large_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+template <class T>
+static int large_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                         void* target, void* grad, hipStream_t s) {
   const EyModel& m = pl->m;
   const int cc = chunk_size(pl, C);
   const size_t ws_floats = 2 * (size_t)cc * act_floats_per_chain(m) + (size_t)cc;
-  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  int rc = ensure_work(pl, ws_floats * sizeof(T));
   if (rc) return rc;
-  float* ws = (float*)pl->d_work;
-  float* lik_tmp = ws + 2 * (size_t)cc * act_floats_per_chain(m);
+  T* ws = (T*)pl->d_work;
+  T* lik_tmp = ws + 2 * (size_t)cc * act_floats_per_chain(m);
   for (int64_t c0 = 0; c0 < C; c0 += cc) {
     const int n = (int)((C - c0) < cc ? (C - c0) : cc);
-    rc = eval_chunk(pl, (const float*)theta + c0 * m.P, temp ? (const float*)temp + c0 : nullptr, n,
-                    lik ? (float*)lik + c0 : nullptr, prior ? (float*)prior + c0 : nullptr,
-                    target ? (float*)target + c0 : nullptr, grad ? (float*)grad + c0 * m.P : nullptr, ws, lik_tmp, s);
+    rc = eval_chunk<T>(pl, (const T*)theta + c0 * m.P, temp ? (const T*)temp + c0 : nullptr, n,
+                    lik ? (T*)lik + c0 : nullptr, prior ? (T*)prior + c0 : nullptr,
+                    target ? (T*)target + c0 : nullptr, grad ? (T*)grad + c0 * m.P : nullptr, ws, lik_tmp, s);
     if (rc) return rc;
   }
   return EY_OK;
 }
+int ey_large_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
+                        void* target, void* grad, hipStream_t s) {
+  return pl->dtype == EY_F32 ? large_log_target<float>(pl, theta, temp, C, lik, prior, target, grad, s) : large_log_target<double>(pl, theta, temp, C, lik, prior, target, grad, s);
+}
 
-int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+template <class T>
+static int large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                  const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                  uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
                  hipStream_t s) {
@@ -1281,94 +1451,102 @@ int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void*
   // workspace: activations for a chunk + lik + [thp, p, gp] for the chunk + tprop, hcur
   const int nblk = leap_blocks(P);
   const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc + (size_t)cc * nblk;
-  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  int rc = ensure_work(pl, ws_floats * sizeof(T));
   if (rc) return rc;
-  float* ws = (float*)pl->d_work;
-  float* lik_tmp = ws + 2 * (size_t)cc * af;
-  float* thp = lik_tmp + cc;
-  float* p = thp + (size_t)cc * P;
-  float* gp = p + (size_t)cc * P;
-  float* tprop = gp + (size_t)cc * P;
-  float* hc = tprop + cc;
-  float* qpart = hc + cc;
-  const float* mu = (const float*)m.mu;
-  const float* iv = (const float*)m.inv_var;
+  T* ws = (T*)pl->d_work;
+  T* lik_tmp = ws + 2 * (size_t)cc * af;
+  T* thp = lik_tmp + cc;
+  T* p = thp + (size_t)cc * P;
+  T* gp = p + (size_t)cc * P;
+  T* tprop = gp + (size_t)cc * P;
+  T* hc = tprop + cc;
+  T* qpart = hc + cc;
+  const T* mu = (const T*)m.mu;
+  const T* iv = (const T*)m.inv_var;
   const dim3 eg(nblk, 1);
   for (int64_t c0 = 0; c0 < C; c0 += cc) {
     const int n = (int)((C - c0) < cc ? (C - c0) : cc);
-    float* th_c = (float*)theta + c0 * P;
-    float* g_c = (float*)grad + c0 * P;
-    float* t_c = (float*)target + c0;
-    const float* temp_c = temp ? (const float*)temp + c0 : nullptr;
-    const float* sv_c = step_vec ? (const float*)step_vec + c0 : nullptr;
-    hipLaunchKernelGGL(k_hmc_begin, dim3(n), dim3(256), 0, s, (const float*)th_c, (const float*)g_c,
-                       p0 ? (const float*)p0 + c0 * P : nullptr, thp, p, gp, P, seed, iter, chain_offset + (uint64_t)c0,
-                       (const float*)t_c, hc);
+    T* th_c = (T*)theta + c0 * P;
+    T* g_c = (T*)grad + c0 * P;
+    T* t_c = (T*)target + c0;
+    const T* temp_c = temp ? (const T*)temp + c0 : nullptr;
+    const T* sv_c = step_vec ? (const T*)step_vec + c0 : nullptr;
+    hipLaunchKernelGGL((k_hmc_begin<T>), dim3(n), dim3(256), 0, s, (const T*)th_c, (const T*)g_c,
+                       p0 ? (const T*)p0 + c0 * P : nullptr, thp, p, gp, P, seed, iter, chain_offset + (uint64_t)c0,
+                       (const T*)t_c, hc);
     if (flags & EY_RECOMPUTE_INITIAL_GRAD) {  // hmc.py:104
-      if ((rc = eval_chunk(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s))) return rc;
+      if ((rc = eval_chunk<T>(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s))) return rc;
     }
     const dim3 grid(eg.x, n);
     // p += eps/2 g ; theta += eps p      (hmc.py:105,110)
-    hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, thp, p, (const float*)gp, P, (float)step, sv_c, 0.5f, 1.0f, mu, iv,
+    hipLaunchKernelGGL((k_leap<T>), grid, dim3(256), 0, s, thp, p, (const T*)gp, P, (T)step, sv_c, T(0.5), T(1.0), mu, iv,
                        qpart);
     for (int k = 1; k <= L; ++k) {
-      if ((rc = eval_chunk(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s, qpart))) return rc;
+      if ((rc = eval_chunk<T>(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s, qpart))) return rc;
       // full momentum step + position step, or the closing half momentum step (hmc.py:113-119)
-      hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, thp, p, (const float*)gp, P, (float)step, sv_c,
-                         k < L ? 1.0f : 0.5f, k < L ? 1.0f : 0.0f, mu, iv, qpart);
+      hipLaunchKernelGGL((k_leap<T>), grid, dim3(256), 0, s, thp, p, (const T*)gp, P, (T)step, sv_c,
+                         k < L ? T(1.0) : T(0.5), k < L ? T(1.0) : T(0.0), mu, iv, qpart);
     }
-    hipLaunchKernelGGL(k_hmc_end, dim3(n), dim3(256), 0, s, th_c, g_c, t_c, (const float*)thp, (const float*)p,
-                       (const float*)gp, (const float*)tprop, (const float*)hc, u ? (const float*)u + c0 : nullptr, P,
+    hipLaunchKernelGGL((k_hmc_end<T>), dim3(n), dim3(256), 0, s, th_c, g_c, t_c, (const T*)thp, (const T*)p,
+                       (const T*)gp, (const T*)tprop, (const T*)hc, u ? (const T*)u + c0 : nullptr, P,
                        seed, iter, chain_offset + (uint64_t)c0, (unsigned char*)accepted + c0,
-                       rate ? (float*)rate + c0 : nullptr, hcur ? (float*)hcur + c0 : nullptr,
-                       hprop ? (float*)hprop + c0 : nullptr);
+                       rate ? (T*)rate + c0 : nullptr, hcur ? (T*)hcur + c0 : nullptr,
+                       hprop ? (T*)hprop + c0 : nullptr);
   }
   EY_HIP(hipGetLastError());
   return EY_OK;
+}
+int ey_large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
+                 const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                 uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
+                 hipStream_t s) {
+  return pl->dtype == EY_F32 ? large_hmc<float>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags, accepted, rate, hcur, hprop, s) : large_hmc<double>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags, accepted, rate, hcur, hprop, s);
 }
 
 // ----------------------------------------------------------------------------------------------- MALA / MH / leapfrog
 // proposal of every chain: MALA  prop = theta + eps/2 grad + sqrt(eps) z   (mala.py:35-41,53)
 //                          MH    prop = theta + scale z                    (metropolis_hastings.py:45, normal_kernel.py)
-__global__ void __launch_bounds__(256) k_propose(const float* __restrict__ theta, const float* __restrict__ grad,
-                                                 const float* __restrict__ z_in, const float* __restrict__ scale,
-                                                 float* __restrict__ prop, int P, float step,
-                                                 const float* __restrict__ step_vec, float sqrt_step, uint64_t seed,
+template <class T>
+__global__ void __launch_bounds__(256) k_propose(const T* __restrict__ theta, const T* __restrict__ grad,
+                                                 const T* __restrict__ z_in, const T* __restrict__ scale,
+                                                 T* __restrict__ prop, int P, T step,
+                                                 const T* __restrict__ step_vec, T sqrt_step, uint64_t seed,
                                                  uint64_t iter, uint64_t chain_offset) {
   const long c = blockIdx.x;
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
-  const float eps = step_vec ? step_vec[c] : step;
-  const float sc = step_vec ? sqrtf(eps) : sqrt_step;
+  const T eps = step_vec ? step_vec[c] : step;
+  const T sc = step_vec ? l_sqrt(eps) : sqrt_step;
   for (int b = threadIdx.x; 4 * b < P; b += blockDim.x) {
-    float o[4];
-    if (!z_in) ey_rng_normal4<float>(rn, (uint32_t)b, o);
+    T o[4];
+    if (!z_in) ey_rng_normal4<T>(rn, (uint32_t)b, o);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = 4 * b + j;
       if (i >= P) break;
       const long k = c * P + i;
-      const float zi = z_in ? z_in[k] : o[j];
-      prop[k] = grad ? (theta[k] + 0.5f * eps * grad[k]) + sc * zi : theta[k] + scale[i] * zi;
+      const T zi = z_in ? z_in[k] : o[j];
+      prop[k] = grad ? (theta[k] + T(0.5) * eps * grad[k]) + sc * zi : theta[k] + scale[i] * zi;
     }
   }
 }
 
 // log-rate, accept and state update of every chain (mala.py:55-82; metropolis_hastings.py:47-73)
-__global__ void __launch_bounds__(256) k_mh_finish(float* theta, float* grad, float* target, const float* prop,
-                                                   const float* gprop, const float* tprop, const float* u_in, int P,
-                                                   float step, const float* step_vec, float sqrt_step, uint64_t seed,
+template <class T>
+__global__ void __launch_bounds__(256) k_mh_finish(T* theta, T* grad, T* target, const T* prop,
+                                                   const T* gprop, const T* tprop, const T* u_in, int P,
+                                                   T step, const T* step_vec, T sqrt_step, uint64_t seed,
                                                    uint64_t iter, uint64_t chain_offset, unsigned char* accepted,
-                                                   float* log_rate_o) {
-  __shared__ float red[4];
+                                                   T* log_rate_o) {
+  __shared__ T red[4];
   __shared__ int s_acc;
   const long c = blockIdx.x;
-  float qf = 0.0f, qb = 0.0f;
-  const float eps = step_vec ? step_vec[c] : step;
+  T qf = T(0.0), qb = T(0.0);
+  const T eps = step_vec ? step_vec[c] : step;
   if (gprop) {  // MALA: forward and backward proposal densities (their normalising terms cancel, mala.py:58-64)
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
       const long k = c * P + i;
-      const float df = prop[k] - (theta[k] + 0.5f * eps * grad[k]);
-      const float db = theta[k] - (prop[k] + 0.5f * eps * gprop[k]);
+      const T df = prop[k] - (theta[k] + T(0.5) * eps * grad[k]);
+      const T db = theta[k] - (prop[k] + T(0.5) * eps * gprop[k]);
       qf += df * df;
       qb += db * db;
     }
@@ -1376,14 +1554,14 @@ __global__ void __launch_bounds__(256) k_mh_finish(float* theta, float* grad, fl
     qb = block_sum(qb, red);
   }
   if (threadIdx.x == 0) {
-    float log_rate = tprop[c] - target[c];
+    T log_rate = tprop[c] - target[c];
     if (gprop) {
-      const float sc = step_vec ? sqrtf(eps) : sqrt_step;
-      log_rate += (qf - qb) * (1.0f / (2.0f * sc * sc));
+      const T sc = step_vec ? l_sqrt(eps) : sqrt_step;
+      log_rate += (qf - qb) * (T(1.0) / (T(2.0) * sc * sc));
     }
     const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
-    const float u = u_in ? u_in[c] : ey_rng_uniform<float>(ru);
-    const int acc = __logf(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
+    const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
+    const int acc = l_log(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
     s_acc = acc;
     accepted[c] = (unsigned char)acc;
     if (acc) target[c] = tprop[c];
@@ -1398,13 +1576,15 @@ __global__ void __launch_bounds__(256) k_mh_finish(float* theta, float* grad, fl
   }
 }
 
-__global__ void __launch_bounds__(256) k_negate(float* p, long n) {
+template <class T>
+__global__ void __launch_bounds__(256) k_negate(T* p, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = -p[i];
 }
 
 // One MALA.draw (grad != null) or MetropolisHastings.draw (scale != null) for C chains
-int ey_large_mala_mh(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+template <class T>
+static int large_mala_mh(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                      const void* step_vec, const void* scale, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                      uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
   const EyModel& m = pl->m;
@@ -1413,37 +1593,43 @@ int ey_large_mala_mh(ey_plan* pl, void* theta, void* target, void* grad, const v
   const int cc = chunk_size(pl, C);
   const size_t af = act_floats_per_chain(m);
   const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 2 * (size_t)cc * P + (size_t)cc;
-  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  int rc = ensure_work(pl, ws_floats * sizeof(T));
   if (rc) return rc;
-  float* ws = (float*)pl->d_work;
-  float* lik_tmp = ws + 2 * (size_t)cc * af;
-  float* prop = lik_tmp + cc;
-  float* gprop = prop + (size_t)cc * P;
-  float* tprop = gprop + (size_t)cc * P;
-  const float sqrt_step = (float)sqrt(step);  // scale = sqrt(step) in double on the host (mala.py:39)
+  T* ws = (T*)pl->d_work;
+  T* lik_tmp = ws + 2 * (size_t)cc * af;
+  T* prop = lik_tmp + cc;
+  T* gprop = prop + (size_t)cc * P;
+  T* tprop = gprop + (size_t)cc * P;
+  const T sqrt_step = (T)sqrt(step);  // scale = sqrt(step) in double on the host (mala.py:39)
   for (int64_t c0 = 0; c0 < C; c0 += cc) {
     const int n = (int)((C - c0) < cc ? (C - c0) : cc);
-    float* th_c = (float*)theta + c0 * P;
-    float* g_c = mala ? (float*)grad + c0 * P : nullptr;
-    const float* temp_c = temp ? (const float*)temp + c0 : nullptr;
-    const float* sv_c = step_vec ? (const float*)step_vec + c0 : nullptr;
-    hipLaunchKernelGGL(k_propose, dim3(n), dim3(256), 0, s, (const float*)th_c, (const float*)g_c,
-                       z ? (const float*)z + c0 * P : nullptr, (const float*)scale, prop, P, (float)step, sv_c,
+    T* th_c = (T*)theta + c0 * P;
+    T* g_c = mala ? (T*)grad + c0 * P : nullptr;
+    const T* temp_c = temp ? (const T*)temp + c0 : nullptr;
+    const T* sv_c = step_vec ? (const T*)step_vec + c0 : nullptr;
+    hipLaunchKernelGGL((k_propose<T>), dim3(n), dim3(256), 0, s, (const T*)th_c, (const T*)g_c,
+                       z ? (const T*)z + c0 * P : nullptr, (const T*)scale, prop, P, (T)step, sv_c,
                        sqrt_step, seed, iter, chain_offset + (uint64_t)c0);
-    if ((rc = eval_chunk(pl, prop, temp_c, n, nullptr, nullptr, tprop, mala ? gprop : nullptr, ws, lik_tmp, s)))
+    if ((rc = eval_chunk<T>(pl, prop, temp_c, n, nullptr, nullptr, tprop, mala ? gprop : nullptr, ws, lik_tmp, s)))
       return rc;
-    hipLaunchKernelGGL(k_mh_finish, dim3(n), dim3(256), 0, s, th_c, g_c, (float*)target + c0, (const float*)prop,
-                       mala ? (const float*)gprop : nullptr, (const float*)tprop,
-                       u ? (const float*)u + c0 : nullptr, P, (float)step, sv_c, sqrt_step, seed, iter,
+    hipLaunchKernelGGL((k_mh_finish<T>), dim3(n), dim3(256), 0, s, th_c, g_c, (T*)target + c0, (const T*)prop,
+                       mala ? (const T*)gprop : nullptr, (const T*)tprop,
+                       u ? (const T*)u + c0 : nullptr, P, (T)step, sv_c, sqrt_step, seed, iter,
                        chain_offset + (uint64_t)c0, (unsigned char*)accepted + c0,
-                       log_rate ? (float*)log_rate + c0 : nullptr);
+                       log_rate ? (T*)log_rate + c0 : nullptr);
   }
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
+int ey_large_mala_mh(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
+                     const void* step_vec, const void* scale, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
+                     uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s) {
+  return pl->dtype == EY_F32 ? large_mala_mh<float>(pl, theta, target, grad, z, u, step, step_vec, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s) : large_mala_mh<double>(pl, theta, target, grad, z, u, step, step_vec, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s);
+}
 
 // HMC.leapfrog (hmc.py:100-124) as the reference runs it: L steps, L+1 gradient evaluations, momentum negated at the end
-int ey_large_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+template <class T>
+static int large_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                       int64_t C, void* target, void* grad, hipStream_t s) {
   const EyModel& m = pl->m;
   const int P = m.P;
@@ -1451,54 +1637,62 @@ int ey_large_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void
   const size_t af = act_floats_per_chain(m);
   const int nblk = leap_blocks(P);
   const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + (size_t)cc * nblk;
-  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  int rc = ensure_work(pl, ws_floats * sizeof(T));
   if (rc) return rc;
-  float* ws = (float*)pl->d_work;
-  float* lik_tmp = ws + 2 * (size_t)cc * af;
-  float* qpart = lik_tmp + cc;
-  const float* mu = (const float*)m.mu;
-  const float* iv = (const float*)m.inv_var;
+  T* ws = (T*)pl->d_work;
+  T* lik_tmp = ws + 2 * (size_t)cc * af;
+  T* qpart = lik_tmp + cc;
+  const T* mu = (const T*)m.mu;
+  const T* iv = (const T*)m.inv_var;
   for (int64_t c0 = 0; c0 < C; c0 += cc) {
     const int n = (int)((C - c0) < cc ? (C - c0) : cc);
-    float* th_c = (float*)theta + c0 * P;
-    float* p_c = (float*)p + c0 * P;
-    float* g_c = (float*)grad + c0 * P;
-    float* t_c = (float*)target + c0;
-    const float* temp_c = temp ? (const float*)temp + c0 : nullptr;
-    const float* sv_c = step_vec ? (const float*)step_vec + c0 : nullptr;
+    T* th_c = (T*)theta + c0 * P;
+    T* p_c = (T*)p + c0 * P;
+    T* g_c = (T*)grad + c0 * P;
+    T* t_c = (T*)target + c0;
+    const T* temp_c = temp ? (const T*)temp + c0 : nullptr;
+    const T* sv_c = step_vec ? (const T*)step_vec + c0 : nullptr;
     const dim3 grid(nblk, n);
-    if ((rc = eval_chunk(pl, th_c, temp_c, n, nullptr, nullptr, t_c, g_c, ws, lik_tmp, s))) return rc;  // :104
-    hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, th_c, p_c, (const float*)g_c, P, (float)step, sv_c, 0.5f, 1.0f,
+    if ((rc = eval_chunk<T>(pl, th_c, temp_c, n, nullptr, nullptr, t_c, g_c, ws, lik_tmp, s))) return rc;  // :104
+    hipLaunchKernelGGL((k_leap<T>), grid, dim3(256), 0, s, th_c, p_c, (const T*)g_c, P, (T)step, sv_c, T(0.5), T(1.0),
                        mu, iv, qpart);
     for (int k = 1; k <= L; ++k) {
-      if ((rc = eval_chunk(pl, th_c, temp_c, n, nullptr, nullptr, t_c, g_c, ws, lik_tmp, s, qpart))) return rc;
-      hipLaunchKernelGGL(k_leap, grid, dim3(256), 0, s, th_c, p_c, (const float*)g_c, P, (float)step, sv_c,
-                         k < L ? 1.0f : 0.5f, k < L ? 1.0f : 0.0f, mu, iv, qpart);
+      if ((rc = eval_chunk<T>(pl, th_c, temp_c, n, nullptr, nullptr, t_c, g_c, ws, lik_tmp, s, qpart))) return rc;
+      hipLaunchKernelGGL((k_leap<T>), grid, dim3(256), 0, s, th_c, p_c, (const T*)g_c, P, (T)step, sv_c,
+                         k < L ? T(1.0) : T(0.5), k < L ? T(1.0) : T(0.0), mu, iv, qpart);
     }
     const long tot = (long)n * P;
-    hipLaunchKernelGGL(k_negate, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p_c, tot);  // :122
+    hipLaunchKernelGGL((k_negate<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p_c, tot);  // :122
   }
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
+int ey_large_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
+                      int64_t C, void* target, void* grad, hipStream_t s) {
+  return pl->dtype == EY_F32 ? large_leapfrog<float>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s) : large_leapfrog<double>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
+}
 
 // the N terms of the log-likelihood sum of every chain (ey_log_lik_rows): forward products and the loss kernel only
-int ey_large_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, hipStream_t s) {
+template <class T>
+static int large_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, hipStream_t s) {
   const EyModel& m = pl->m;
   const int cc = chunk_size(pl, C);
   const size_t af = act_floats_per_chain(m);
   const size_t ws_floats = 2 * (size_t)cc * af + 2 * (size_t)cc;
-  int rc = ensure_work(pl, ws_floats * sizeof(float));
+  int rc = ensure_work(pl, ws_floats * sizeof(T));
   if (rc) return rc;
-  float* ws = (float*)pl->d_work;
-  float* lik_tmp = ws + 2 * (size_t)cc * af;
+  T* ws = (T*)pl->d_work;
+  T* lik_tmp = ws + 2 * (size_t)cc * af;
   for (int64_t c0 = 0; c0 < C; c0 += cc) {
     const int n = (int)((C - c0) < cc ? (C - c0) : cc);
-    rc = eval_chunk(pl, (const float*)theta + c0 * m.P, temp ? (const float*)temp + c0 : nullptr, n, nullptr, nullptr,
-                    lik_tmp + cc, nullptr, ws, lik_tmp, s, nullptr, (float*)rows + c0 * m.N);
+    rc = eval_chunk<T>(pl, (const T*)theta + c0 * m.P, temp ? (const T*)temp + c0 : nullptr, n, nullptr, nullptr,
+                    lik_tmp + cc, nullptr, ws, lik_tmp, s, nullptr, (T*)rows + c0 * m.N);
     if (rc) return rc;
   }
   return EY_OK;
+}
+int ey_large_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, hipStream_t s) {
+  return pl->dtype == EY_F32 ? large_log_lik_rows<float>(pl, theta, temp, C, rows, s) : large_log_lik_rows<double>(pl, theta, temp, C, rows, s);
 }
 
 // Test / measurement entry (not part of the sampler surface): C[b] = act(A[b] B[b] + bias[b]) through the same

@@ -1131,6 +1131,98 @@ def test_bgemm_path_mala_mh_leapfrog_rows_vs_oracle(dims, acts, bias, lik, N):
         _force_large(False)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,acts,bias,lik,N", [
+    ([4, 3, 3], [1, 0], [1, 1], 1, 150),
+    ([3, 5, 4, 2], [2, 3, 0], [1, 0, 1], 1, 77),
+    ([6, 70, 33, 2], [1, 2, 1], [1, 1, 1], 0, 130),
+    ([20, 128, 10], [1, 0], [1, 1], 1, 96),
+])
+def test_bgemm_path_f64_vs_oracle(dims, acts, bias, lik, N):
+    """The layerwise path in the reference's default dtype (eeyore/models/model.py:7): every entry point of ey_large.hip
+    with T = double (v_mfma_f64_16x16x4_f64 products) against the f64 C oracle at the f64 tolerance, decisions exact."""
+    from eeyore_amd.plan import Plan
+    from oracle import mlp_oracle as mo
+    f64 = torch.float64
+    rng = np.random.default_rng(sum(dims) + N + 2)
+    x = rng.standard_normal((N, dims[0]))
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(float)
+    P = sum((dims[l] + bias[l]) * dims[l + 1] for l in range(len(dims) - 1))
+    mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+    co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=np.float64, bias=bias, nthreads=4)
+    _force_large(True)
+    try:
+        pl = Plan(dims, bias, acts, lik, f64, DEV)
+        pl.set_data(_t(x), _t(y))
+        pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+        assert pl.kernel == "bgemm"
+        C = 7
+        th0 = 0.3 * rng.standard_normal((C, P))
+        temps = torch.tensor([1.0, 0.5, 1.0, 0.25, 1.0, 1.0, 2.0], dtype=f64)
+        t, g = pl.log_target_grad(_t(th0))
+        tt, gt = pl.log_target_grad(_t(th0), temp=temps)
+        lk, pr = pl.log_target(_t(th0))
+        for c in range(C):
+            to, go, lo, po = co.log_target_grad(th0[c])
+            gs = max(1.0, np.abs(go).max())
+            np.testing.assert_allclose(t[c].item(), to, rtol=1e-10, atol=1e-10)
+            np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=1e-9, atol=1e-11 * gs)
+            np.testing.assert_allclose([lk[c].item(), pr[c].item()], [lo, po], rtol=1e-10, atol=1e-10)
+            np.testing.assert_allclose(tt[c].item(), temps[c].item() * to, rtol=1e-10, atol=1e-10)
+            np.testing.assert_allclose(gt[c].cpu().numpy(), temps[c].item() * go, rtol=1e-9, atol=1e-11 * gs)
+        # ---- HMC with recorded momentum and uniforms, both evaluation modes
+        p0 = rng.standard_normal((C, P)); u = rng.random(C)
+        for flags in (0, 1):
+            th, tv, gg = _t(th0).clone(), t.clone(), g.clone()
+            out = pl.hmc_step(th, tv, gg, 0.02, 6, p0=_t(p0), u=_t(u), flags=flags)
+            tho, tvo, go = th0.copy(), t.cpu().numpy().copy(), g.cpu().numpy().copy()
+            acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, 0.02, 6)
+            rate = np.minimum(np.exp(np.minimum(hc - hp, 0)), 1)
+            assert (np.abs(u - rate) > 1e-9).all()
+            np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
+            np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(th.cpu().numpy(), tho, rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(gg.cpu().numpy(), go, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(go).max()))
+        # ---- MALA, random-walk MH
+        z = rng.standard_normal((C, P))
+        th, tv, gg = _t(th0).clone(), t.clone(), g.clone()
+        out = pl.mala_step(th, tv, gg, 0.002, z=_t(z), u=_t(u))
+        tho, tvo, go = th0.copy(), t.cpu().numpy().copy(), g.cpu().numpy().copy()
+        acc, lr = co.mala_draw(tho, tvo, go, z, u, 0.002)
+        assert (np.abs(np.log(u) - lr) > 1e-9 * np.maximum(1.0, np.abs(lr))).all()
+        np.testing.assert_allclose(out["log_rate"].cpu().numpy(), lr, rtol=1e-8, atol=1e-8)
+        np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
+        np.testing.assert_allclose(th.cpu().numpy(), tho, rtol=1e-9, atol=1e-11)
+        th, tv = _t(th0).clone(), t.clone()
+        out = pl.mh_step(th, tv, 0.02, z=_t(z), u=_t(u))
+        tho, tvo = th0.copy(), t.cpu().numpy().copy()
+        acc, lr = co.mh_draw(tho, tvo, z, u, 0.02)
+        np.testing.assert_allclose(out["log_rate"].cpu().numpy(), lr, rtol=1e-8, atol=1e-8)
+        np.testing.assert_array_equal(out["accepted"].cpu().numpy(), acc)
+        np.testing.assert_allclose(th.cpu().numpy(), tho, rtol=1e-9, atol=1e-11)
+        # in-kernel Philox == streams passed in
+        a = [_t(th0).clone(), t.clone(), g.clone()]
+        b = [_t(th0).clone(), t.clone(), g.clone()]
+        oa = pl.hmc_step(*a, 0.02, 4, seed=5, it=2, chain_offset=10)
+        ob = pl.hmc_step(*b, 0.02, 4, p0=pl.philox_normal(C, 5, 2, 10), u=pl.philox_uniform(C, 5, 2, 10))
+        assert torch.equal(oa["accepted"], ob["accepted"]) and torch.equal(a[0], b[0])
+        # ---- HMC.leapfrog and the rows of the log-likelihood
+        th, p = _t(th0).clone(), _t(p0).clone()
+        tl, gl = pl.leapfrog(th, p, 0.01, 5)
+        for c in (0, C - 1):
+            tho, po, to, go = co.leapfrog(th0[c], p0[c], 0.01, 5)
+            np.testing.assert_allclose(th[c].cpu().numpy(), tho, rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(p[c].cpu().numpy(), po, rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(tl[c].item(), to, rtol=1e-10, atol=1e-9)
+        rows = pl.log_lik_rows(_t(th0)).cpu().numpy()
+        spec = mo.Spec(dims, acts, lik, bias=bias)
+        for n in (0, N // 2, N - 1):
+            want = mo.log_lik(spec, th0[2], x[n:n + 1], y[n:n + 1])
+            np.testing.assert_allclose(rows[2, n], want, rtol=1e-9, atol=1e-10)
+    finally:
+        _force_large(False)
+
+
 def test_config5_shape_mnist_like_model_runs_on_bgemm_path():
     """BASELINE config 5's model shape: MLP(784-128-10), P = 101 770 (does not fit LDS) -> batched-GEMM path."""
     from eeyore_amd.plan import Plan
