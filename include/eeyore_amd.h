@@ -61,7 +61,9 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
 int ey_plan_destroy(ey_plan* plan);
 /* Model.num_params (eeyore/models/model.py:34-36) */
 int ey_plan_num_params(const ey_plan* plan, int64_t* P);
-/* name of the kernel family that serves ey_hmc_step for this plan: "generic" or "mfma32" */
+/* name of the kernel family that serves ey_hmc_step for this plan: "mfma32" (fused f32 trajectory, 4-32-32-3), "fused16"
+ * (fused 16x16x4 trajectory, f32 and f64), "bgemm" (layerwise batched GEMMs for models beyond LDS, f32 and f64) or
+ * "generic" */
 const char* ey_plan_kernel(const ey_plan* plan);
 
 /* The (x, y) full batch the samplers receive from their DataLoader (eeyore/samplers/serial_sampler.py:41-46).
@@ -209,6 +211,14 @@ int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* ta
 /* Tuning knob for the MFMA kernel family (not part of the drop-in surface): selects the workgroup shape /
  * issue-priority variant of the fused trajectory kernel; returns the previous value.  Results do not depend on it. */
 int ey_debug_set_variant(int variant);
+
+/* Test / measurement entry of the layerwise path's batched f32 product (not part of the drop-in surface):
+ * C[b] = act(A[b] B[b] + bias[b]) for b < batch through the same dispatcher the evaluations use.  Element strides
+ * (sAm, sAk), (sBk, sBn), (sCm, sCn), batch strides bA, bB, bC (0 = shared operand); bias may be NULL; act is an
+ * EY_ACT_* code.  Parity against torch.bmm: tests/test_gpu_parity.py::test_batched_gemm_vs_torch_bmm. */
+int ey_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int K, long sAm, long sAk, long sBk, long sBn,
+                   long sCm, long sCn, long bA, long bB, long bC, const float* bias, long bBias, int act, int batch,
+                   void* stream);
 
 #ifdef __cplusplus
 }
