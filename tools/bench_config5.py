@@ -30,18 +30,20 @@ if os.environ.get("EY_NO_DMA"):  # A/B: the register-staged GEMM instead of the 
     from eeyore_amd import _lib as L
     L.lib().ey_debug_set_variant(32)
 N, L, eps, between = 1024, 20, 0.001, 10
+DT = torch.float64 if os.environ.get("EY_F64") else torch.float32   # EY_F64=1: the f64 layerwise path (parity dtype)
+PEAK, PEAK_NAME = (78.6e12, "f64") if DT == torch.float64 else (157.3e12, "f32")
 
 rng = np.random.default_rng(0)
 x = (rng.random((N, 784)) * (rng.random((N, 784)) < 0.19)).astype(np.float32)
 y = np.eye(10, dtype=np.float32)[np.arange(N) % 10]
-pl = Plan([784, 128, 10], [1, 1], [1, 0], 1, torch.float32, dev)
-pl.set_data(torch.tensor(x, device=dev), torch.tensor(y, device=dev))
+pl = Plan([784, 128, 10], [1, 1], [1, 0], 1, DT, dev)
+pl.set_data(torch.tensor(x, device=dev, dtype=DT), torch.tensor(y, device=dev, dtype=DT))
 pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
 
 ladder = [(i / world) ** 4 for i in range(1, world + 1)]
 pt = TemperingExchange(ladder, C, rank, world, dev, seed=11)
 th = 0.05 * pl.philox_normal(C, seed=0, it=0)  # every rank starts its replicas from the same states
-temps = pt.temperature_vector(torch.float32)
+temps = pt.temperature_vector(DT)
 t, g = pl.log_target_grad(th, temp=temps)
 out = pl.hmc_step(th, t, g, eps, L, temp=temps, seed=1 + rank, it=1)
 torch.cuda.synchronize()
@@ -55,7 +57,7 @@ for it in range(iters):
     if world > 1 and (it + 1) % between == 0:
         old = temps
         swaps += pt.exchange(t / old)          # untempered log-target ell = T / t
-        temps = pt.temperature_vector(torch.float32)
+        temps = pt.temperature_vector(DT)
         ratio = temps / old                    # a relabelled chain keeps its state: rescale the cached tempered values
         t *= ratio
         g *= ratio[:, None]
@@ -68,7 +70,7 @@ if rank == 0:
     tot = C * world
     print(f"kernel {pl.kernel}: {world} temperature(s) x {C} chains, {dt * 1e3:.1f} ms per HMC iteration (L={L}) -> "
           f"{tot * L / dt:.3e} leapfrog-steps/s x chains, {f_step * C * L / dt / 1e12:.1f} TFLOP/s per GPU "
-          f"({100 * f_step * C * L / dt / 157.3e12:.1f}% of f32 MFMA peak), acceptance {np.mean(accs):.2f}, "
+          f"({100 * f_step * C * L / dt / PEAK:.1f}% of {PEAK_NAME} MFMA peak), acceptance {np.mean(accs):.2f}, "
           f"label exchanges accepted {swaps}")
 if world > 1:
     dist.destroy_process_group()
