@@ -42,6 +42,15 @@ struct BGT {
   // if pr_theta is set the product is a weight gradient: the output becomes (acc - (theta - mu) / sigma^2) * t, i.e.
   // the prior gradient and the temperature are applied here (indexed like C; *_b like rowsum), batch stride bC / bRow
   const T *pr_theta, *pr_mu, *pr_iv, *pr_theta_b, *pr_mu_b, *pr_iv_b, *pr_temp;
+  // if lf_p is set (a weight-gradient product inside an HMC trajectory) the leapfrog update is applied where the
+  // gradient element g is produced:  p += wp eps g ;  theta += wt eps p  (hmc.py:105-119), the gradient itself is
+  // stored only if lf_store_g, and the workgroup leaves its partial sum of (theta_new - mu)^2 / sigma^2 in
+  // lf_q[b * lf_nslots + lf_slot0 + tile index] (summed in a fixed order: reproducible).  lf_p / lf_p_b are indexed
+  // like C / rowsum; theta is written through pr_theta / pr_theta_b.
+  T *lf_p, *lf_p_b, *lf_q;
+  const T* lf_step_vec;
+  T lf_step, lf_wp, lf_wt;
+  int lf_slot0, lf_nslots, lf_store_g;
 };
 using BG = BGT<float>;
 
@@ -208,11 +217,33 @@ __device__ __forceinline__ void epi_loop(const BG& g, const f32x16 (&acc)[TM][TN
     }
   }
 }
+// returns this lane's part of the prior quadratic form of the NEW position when the leapfrog update is fused in
 template <int TM, int TN, bool FULL>
-__device__ __forceinline__ void epi_kind(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
-                                         int h, long b, float tscale) {
+__device__ __forceinline__ float epi_kind(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
+                                          int h, long b, float tscale, float ep, float et) {
   float* C = g.C + b * g.bC;
-  if (g.pr_theta) {  // weight gradient: minus the prior gradient, times the temperature
+  float q = 0.0f;
+  if (g.pr_theta && g.lf_p) {  // weight gradient with the leapfrog update fused in
+    // the four arrays are distinct and every element is touched once: telling the compiler lets it issue the loads of
+    // the following elements before the stores of this one (otherwise every element is a serialized HBM round trip)
+    float* __restrict__ th = const_cast<float*>(g.pr_theta) + b * g.bC;
+    float* __restrict__ pp = g.lf_p + b * g.bC;
+    const float* __restrict__ mu = g.pr_mu;
+    const float* __restrict__ iv = g.pr_iv;
+    float* __restrict__ Cr = C;
+    const bool store_g = g.lf_store_g != 0, move = g.lf_wt != 0.0f;
+    epi_loop<TM, TN, FULL>(g, acc, m0, n0, wm, wn, c, h, [&](float v, int, int, unsigned ci) {
+      const float m_ = EPI_AT(mu, ci), i_ = EPI_AT(iv, ci);
+      float tv = EPI_AT(th, ci);
+      const float gv = (v - (tv - m_) * i_) * tscale;
+      if (store_g) EPI_AT(Cr, ci) = gv;
+      const float pv = EPI_AT(pp, ci) + ep * gv;
+      EPI_AT(pp, ci) = pv;
+      if (move) { tv = tv + et * pv; EPI_AT(th, ci) = tv; }
+      const float d = tv - m_;
+      q += d * d * i_;
+    });
+  } else if (g.pr_theta) {  // weight gradient: minus the prior gradient, times the temperature
     const float* th = g.pr_theta + b * g.bC;
     const float* mu = g.pr_mu;
     const float* iv = g.pr_iv;
@@ -253,18 +284,51 @@ __device__ __forceinline__ void epi_kind(const BG& g, const f32x16 (&acc)[TM][TN
                                [&](float v, int, int n, unsigned ci) { EPI_AT(C, ci) = v + bj(n); });
     }
   }
+  return q;
 }
 template <int TM, int TN, int WGM, int WGN>
 __device__ __forceinline__ void bg_epilogue(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
                                             int h, long b, float rsum, bool do_rowsum, int tid) {
+  __shared__ float epi_red[4];
   const float tscale = g.pr_temp ? g.pr_temp[b] : 1.0f;
+  const bool fuse = g.lf_p != nullptr;
+  float ep = 0.0f, et = 0.0f, q = 0.0f;
+  if (fuse) {
+    const float eps = g.lf_step_vec ? g.lf_step_vec[b] : g.lf_step;
+    ep = g.lf_wp * eps;
+    et = g.lf_wt * eps;
+  }
   if (do_rowsum && m0 + tid < g.M) {
     const int mm = m0 + tid;
-    if (g.pr_theta_b) rsum = (rsum - (g.pr_theta_b[b * g.bRow + mm] - g.pr_mu_b[mm]) * g.pr_iv_b[mm]) * tscale;
-    g.rowsum[b * g.bRow + mm] = rsum;
+    if (fuse) {  // the bias gradient element, with the same update
+      float* thb = const_cast<float*>(g.pr_theta_b) + b * g.bRow;
+      const float m_ = g.pr_mu_b[mm], i_ = g.pr_iv_b[mm];
+      float tv = thb[mm];
+      const float gv = (rsum - (tv - m_) * i_) * tscale;
+      if (g.lf_store_g) g.rowsum[b * g.bRow + mm] = gv;
+      const float pv = g.lf_p_b[b * g.bRow + mm] + ep * gv;
+      g.lf_p_b[b * g.bRow + mm] = pv;
+      if (g.lf_wt != 0.0f) { tv = tv + et * pv; thb[mm] = tv; }
+      const float d = tv - m_;
+      q = d * d * i_;
+    } else {
+      if (g.pr_theta_b) rsum = (rsum - (g.pr_theta_b[b * g.bRow + mm] - g.pr_mu_b[mm]) * g.pr_iv_b[mm]) * tscale;
+      g.rowsum[b * g.bRow + mm] = rsum;
+    }
   }
-  if (m0 + 32 * TM * WGM <= g.M && n0 + 32 * TN * WGN <= g.N) epi_kind<TM, TN, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale);
-  else epi_kind<TM, TN, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale);
+  if (m0 + 32 * TM * WGM <= g.M && n0 + 32 * TN * WGN <= g.N)
+    q += epi_kind<TM, TN, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et);
+  else
+    q += epi_kind<TM, TN, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et);
+  if (fuse) {  // uniform over the workgroup
+    const int gx = (g.N + 32 * TN * WGN - 1) / (32 * TN * WGN);
+    const int slot = g.lf_slot0 + (m0 / (32 * TM * WGM)) * gx + n0 / (32 * TN * WGN);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if ((tid & 63) == 0) epi_red[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) g.lf_q[b * g.lf_nslots + slot] = ((epi_red[0] + epi_red[1]) + epi_red[2]) + epi_red[3];
+  }
 }
 
 // Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD has its own L2: the
@@ -372,7 +436,7 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
 // in outputs the epilogue discards).
 #define DMA_STAGES 3
 template <bool KFAST>
-__global__ void __launch_bounds__(256) k_bgemm_dma(BG g) {
+__global__ void __launch_bounds__(256, 3) k_bgemm_dma(BG g) {
   __shared__ __attribute__((aligned(16))) float As[DMA_STAGES][BK * 128];
   __shared__ __attribute__((aligned(16))) float Bs[DMA_STAGES][BK * 128];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -592,12 +656,14 @@ static bool dh_smallk_ok(const BG& g) {
          (((uintptr_t)g.C | (uintptr_t)g.Hm) & 15) == 0;
 }
 
-static int bgemm_one(const BG& g, int batch, hipStream_t s);
+static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry);
 
 // One product, split where that saves padded work: a weight gradient whose N is a few columns past a multiple of 128
 // (784 = 6 x 128 + 16 in config 5: the seventh 128-wide block would be 12 % full) runs its remainder through the
 // 32-wide kernel.
-static int bgemm(const BG& g, int batch, hipStream_t s) {
+// cursor: next free slot of the fused leapfrog update's partial sums (g.lf_p set), advanced by the blocks launched;
+// dry: only advance the cursor (the host sizes the slot buffer with the same dispatch logic it launches with).
+static int bgemm(const BG& g, int batch, hipStream_t s, int* cursor = nullptr, bool dry = false) {
   if (dh_smallk_ok(g)) {
     if (256 / (g.N >> 2) >= 1) {
       dim3 grid((g.M + DH_ROWS - 1) / DH_ROWS, 1, batch);
@@ -610,7 +676,7 @@ static int bgemm(const BG& g, int batch, hipStream_t s) {
   if (g.M > 32 && g.N > 128 && rem > 0 && rem <= 32 && !g.bias && !g.Hm) {
     BG body = g, tail = g;
     body.N = g.N - rem;
-    int rc = bgemm_one(body, batch, s);
+    int rc = bgemm_one(body, batch, s, cursor, dry);
     if (rc) return rc;
     const long off = (long)body.N * g.sCn;  // the tail's columns: B, C and everything indexed like C move along n
     tail.N = rem;
@@ -618,12 +684,21 @@ static int bgemm(const BG& g, int batch, hipStream_t s) {
     tail.C = g.C + off;
     tail.rowsum = nullptr;  // the body's first block column has written the row sums
     if (g.pr_theta) { tail.pr_theta = g.pr_theta + off; tail.pr_mu = g.pr_mu + off; tail.pr_iv = g.pr_iv + off; }
-    return bgemm_one(tail, batch, s);
+    if (g.lf_p) { tail.lf_p = g.lf_p + off; tail.lf_p_b = nullptr; }
+    return bgemm_one(tail, batch, s, cursor, dry);
   }
-  return bgemm_one(g, batch, s);
+  return bgemm_one(g, batch, s, cursor, dry);
 }
 
-static int bgemm_one(const BG& g, int batch, hipStream_t s) {
+static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry) {
+  if (cursor && (g.lf_p || dry)) {
+    const bool narrow_n = g.N <= 32, narrow_m = !narrow_n && g.M <= 32;
+    const int gx = (g.N + (narrow_n ? 31 : 127)) / (narrow_n ? 32 : 128);
+    const int gy = (g.M + (narrow_m ? 31 : 127)) / (narrow_m ? 32 : 128);
+    g.lf_slot0 = *cursor;
+    *cursor += gx * gy;
+    if (dry) return EY_OK;
+  }
   // the epilogue indexes one batch item's output (and H) with 32-bit byte offsets
   if ((g.M - 1) * g.sCm + (g.N - 1) * g.sCn >= (1L << 30) ||
       (g.Hm && (g.M - 1) * g.sHm + (g.N - 1) * g.sHn >= (1L << 30)))
@@ -776,7 +851,7 @@ __global__ void __launch_bounds__(256) k_bgemm_f64(BGT<double> g) {
     }
   }
 }
-static int bgemm(const BGT<double>& g, int batch, hipStream_t s) {
+static int bgemm(const BGT<double>& g, int batch, hipStream_t s, int* = nullptr, bool = false) {
   dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
   hipLaunchKernelGGL(k_bgemm_f64, grid, dim3(256), 0, s, g);
   EY_HIP(hipGetLastError());
@@ -1014,6 +1089,11 @@ struct TailArgs {
   const float* H; float* Dout; const float* theta; float* grad; const float* mu; const float* iv;
   const float* y; const int* labels; const float* temp; float* lik_o; float* rows_o;
   long P; int woff, boff, N, d, dK, lik, act_last, act_prev, rows_temp;
+  // the leapfrog update fused into the gradient write-out, as BGT's lf_* (the workgroup's slot is lf_slot0)
+  float *lf_p, *lf_q;
+  const float* lf_step_vec;
+  float lf_step, lf_wp, lf_wt;
+  int lf_slot0, lf_nslots, lf_store_g;
 };
 __device__ __forceinline__ float l_act_fast(int code, float g) {
   switch (code) {
@@ -1268,17 +1348,39 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
   if (GRAD) {
     const float tscale = a.temp ? a.temp[c] : 1.0f;
     float* gc = a.grad + c * a.P;
+    const bool fuse = a.lf_p != nullptr;
+    float* thw = const_cast<float*>(th);
+    float* pc = fuse ? a.lf_p + c * a.P : nullptr;
+    const float eps = fuse ? (a.lf_step_vec ? a.lf_step_vec[c] : a.lf_step) : 0.0f;
+    const float ep = a.lf_wp * eps, et = a.lf_wt * eps;
+    float q = 0.0f;
+    // one gradient element: the prior term and the temperature; with the leapfrog update fused in (see BGT) the
+    // momentum and the position of the element move here and q collects the new position's prior quadratic form
+    auto emit = [&](int k, float v) {
+      const float m_ = a.mu[k], i_ = a.iv[k];
+      float tv = th[k];
+      const float gv = (v - (tv - m_) * i_) * tscale;
+      if (!fuse) { gc[k] = gv; return; }
+      if (a.lf_store_g) gc[k] = gv;
+      const float pv = pc[k] + ep * gv;
+      pc[k] = pv;
+      if (a.lf_wt != 0.0f) { tv = tv + et * pv; thw[k] = tv; }
+      const float dd = tv - m_;
+      q += dd * dd * i_;
+    };
     for (int e = tid; e < dK * d; e += 256) {
       const int j = e / d, i = e - j * d;
-      const float v = ((red[0][j * (16 * F) + i] + red[1][j * (16 * F) + i]) + red[2][j * (16 * F) + i]) +
-                      red[3][j * (16 * F) + i];
-      const int k = a.woff + e;
-      gc[k] = (v - (th[k] - a.mu[k]) * a.iv[k]) * tscale;
+      emit(a.woff + e, ((red[0][j * (16 * F) + i] + red[1][j * (16 * F) + i]) + red[2][j * (16 * F) + i]) +
+                           red[3][j * (16 * F) + i]);
     }
-    if (a.boff >= 0 && tid < dK) {
-      const float v = ((redb[0][tid] + redb[1][tid]) + redb[2][tid]) + redb[3][tid];
-      const int k = a.boff + tid;
-      gc[k] = (v - (th[k] - a.mu[k]) * a.iv[k]) * tscale;
+    if (a.boff >= 0 && tid < dK) emit(a.boff + tid, ((redb[0][tid] + redb[1][tid]) + redb[2][tid]) + redb[3][tid]);
+    if (fuse) {  // uniform over the workgroup
+      __shared__ float redq[4];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      if (lane == 0) redq[wave] = q;
+      __syncthreads();
+      if (tid == 0) a.lf_q[c * a.lf_nslots + a.lf_slot0] = ((redq[0] + redq[1]) + redq[2]) + redq[3];
     }
   }
 }
@@ -1320,11 +1422,31 @@ static size_t act_floats_per_chain(const EyModel& m) {
   return f;
 }
 
-// value (+ gradient when grad != null) for chains [0, C) of theta, using `ws` (2 * C * act_floats floats) as scratch
+// The leapfrog update of an HMC trajectory applied by the kernels that produce the gradient (f32): momentum p, step,
+// weights of the momentum and position updates (hmc.py:105-119), where the partial sums of the new position's prior
+// quadratic form go (q_out[c][nslots]) and whether the gradient itself is still stored (the last step: hmc.py:150).
+template <class T>
+struct LeapFuse {
+  T* p; const T* step_vec; T step, wp, wt; T* q_out; int nslots, store_g;
+};
+// slots the fused update of one evaluation writes per chain (the same dispatch logic as the launches, dry)
+static int leap_fuse_slots(const EyModel& m, bool tail) {
+  int cursor = tail ? 1 : 0;
+  for (int l = (tail ? m.nl - 2 : m.nl - 1); l >= 0; --l) {
+    BG g = {};
+    g.M = m.dims[l + 1]; g.N = m.dims[l]; g.K = m.N; g.sCm = m.dims[l]; g.sCn = 1;
+    bgemm(g, 1, nullptr, &cursor, true);
+  }
+  return cursor;
+}
+std::atomic<int> g_ey_no_fuse{0};  // ey_debug_set_variant bit 7: HMC with the separate leapfrog kernel (A/B, tests)
+
+// value (+ gradient when grad != null) for chains [0, C) of theta, using `ws` (2 * C * act_floats floats) as scratch;
+// qpart / nblk: partial sums of the prior quadratic form of theta left by the previous leapfrog update (else k_prior)
 template <class T>
 static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_o, T* prior_o,
                       T* target_o, T* grad, T* ws, T* lik_tmp, hipStream_t s,
-                      const T* qpart = nullptr, T* rows_o = nullptr) {
+                      const T* qpart = nullptr, T* rows_o = nullptr, int nblk = 0, const LeapFuse<T>* lf = nullptr) {
   const EyModel& m = pl->m;
   const int K = m.nl, N = m.N, P = m.P;
   const size_t af = act_floats_per_chain(m);
@@ -1339,7 +1461,7 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
       off += (size_t)N * m.dims[l];
     }
   }
-  int rc;
+  int rc, cursor = 0;
   const bool tail = sizeof(T) == 4 && tail_ok(m) && !g_ey_no_tail.load();
   for (int l = 0; l < (tail ? K - 1 : K); ++l) {
     BGT<T> g = {};
@@ -1362,6 +1484,10 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
       t.temp = temp; t.lik_o = lik_tmp; t.rows_o = rows_o; t.P = P; t.woff = m.woff[K - 1]; t.boff = m.boff[K - 1];
       t.N = N; t.d = m.dims[K - 1]; t.dK = m.dims[K]; t.lik = m.lik; t.act_last = m.act[K - 1];
       t.act_prev = m.act[K - 2]; t.rows_temp = rows_o != nullptr;
+      if (lf) {
+        t.lf_p = lf->p; t.lf_q = lf->q_out; t.lf_step_vec = lf->step_vec; t.lf_step = lf->step; t.lf_wp = lf->wp;
+        t.lf_wt = lf->wt; t.lf_slot0 = cursor++; t.lf_nslots = lf->nslots; t.lf_store_g = lf->store_g;
+      }
       if (grad) tail_launch<true>(t, C, s);
       else tail_launch<false>(t, C, s);
     }
@@ -1372,6 +1498,15 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
   const int ltop = tail ? K - 2 : K - 1;
   if (grad) {
     for (int l = ltop; l >= 0; --l) {
+      if (l > 0) {  // first, while W_l is still the evaluated position (the fused update below moves it)
+        BGT<T> d = {};  // delta_l = (delta_{l+1} W_l) * act'(H_l)
+        d.A = D[l + 1]; d.sAm = m.dims[l + 1]; d.sAk = 1; d.bA = (long)N * m.dims[l + 1];
+        d.B = theta + m.woff[l]; d.sBk = m.dims[l]; d.sBn = 1; d.bB = P;
+        d.C = D[l]; d.sCm = m.dims[l]; d.sCn = 1; d.bC = (long)N * m.dims[l];
+        d.M = N; d.N = m.dims[l]; d.K = m.dims[l + 1];
+        d.Hm = H[l]; d.sHm = m.dims[l]; d.sHn = 1; d.bH = (long)N * m.dims[l]; d.act_h = m.act[l - 1];
+        if ((rc = bgemm(d, C, s))) return rc;
+      }
       BGT<T> g = {};  // dW_l = delta_{l+1}^T H_l, db_l = row sums of delta_{l+1}^T
       g.A = D[l + 1]; g.sAm = 1; g.sAk = m.dims[l + 1]; g.bA = (long)N * m.dims[l + 1];
       g.B = l == 0 ? (const T*)m.x : H[l]; g.sBk = m.dims[l]; g.sBn = 1; g.bB = l == 0 ? 0 : (long)N * m.dims[l];
@@ -1384,20 +1519,16 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
         g.pr_iv_b = (const T*)m.inv_var + m.boff[l];
       }
       g.pr_temp = temp;
-      if ((rc = bgemm(g, C, s))) return rc;
-      if (l > 0) {
-        BGT<T> d = {};  // delta_l = (delta_{l+1} W_l) * act'(H_l)
-        d.A = D[l + 1]; d.sAm = m.dims[l + 1]; d.sAk = 1; d.bA = (long)N * m.dims[l + 1];
-        d.B = theta + m.woff[l]; d.sBk = m.dims[l]; d.sBn = 1; d.bB = P;
-        d.C = D[l]; d.sCm = m.dims[l]; d.sCn = 1; d.bC = (long)N * m.dims[l];
-        d.M = N; d.N = m.dims[l]; d.K = m.dims[l + 1];
-        d.Hm = H[l]; d.sHm = m.dims[l]; d.sHn = 1; d.bH = (long)N * m.dims[l]; d.act_h = m.act[l - 1];
-        if ((rc = bgemm(d, C, s))) return rc;
+      if (lf) {
+        g.lf_p = lf->p + m.woff[l]; g.lf_p_b = m.boff[l] >= 0 ? lf->p + m.boff[l] : nullptr; g.lf_q = lf->q_out;
+        g.lf_step_vec = lf->step_vec; g.lf_step = lf->step; g.lf_wp = lf->wp; g.lf_wt = lf->wt;
+        g.lf_nslots = lf->nslots; g.lf_store_g = lf->store_g;
       }
+      if ((rc = bgemm(g, C, s, &cursor))) return rc;
     }
   }
   if (qpart)
-    hipLaunchKernelGGL((k_target<T>), dim3((C + 3) / 4), dim3(256), 0, s, qpart, leap_blocks(P), (T)m.prior_const,
+    hipLaunchKernelGGL((k_target<T>), dim3((C + 3) / 4), dim3(256), 0, s, qpart, nblk ? nblk : leap_blocks(P), (T)m.prior_const,
                        temp, (const T*)lik_tmp, C, lik_o, prior_o, target_o);
   else
     hipLaunchKernelGGL((k_prior<T>), dim3(C), dim3(256), 0, s, theta, (const T*)m.mu, (const T*)m.inv_var,
@@ -1448,9 +1579,15 @@ static int large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const v
   const int P = m.P;
   const int cc = chunk_size(pl, C);
   const size_t af = act_floats_per_chain(m);
-  // workspace: activations for a chunk + lik + [thp, p, gp] for the chunk + tprop, hcur
+  // workspace: activations for a chunk + lik + [thp, p, gp] for the chunk + tprop, hcur + two buffers of partial sums
+  // of the prior quadratic form (one being read by the evaluation at theta_k while its epilogues fill the other for
+  // theta_{k+1})
   const int nblk = leap_blocks(P);
-  const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc + (size_t)cc * nblk;
+  const bool tail = sizeof(T) == 4 && tail_ok(m) && !g_ey_no_tail.load();
+  const bool fuse = sizeof(T) == 4 && !g_ey_no_fuse.load();
+  const int nslots = fuse ? leap_fuse_slots(m, tail) : 0;
+  const int nq = nblk > nslots ? nblk : nslots;
+  const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc + 2 * (size_t)cc * nq;
   int rc = ensure_work(pl, ws_floats * sizeof(T));
   if (rc) return rc;
   T* ws = (T*)pl->d_work;
@@ -1460,10 +1597,9 @@ static int large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const v
   T* gp = p + (size_t)cc * P;
   T* tprop = gp + (size_t)cc * P;
   T* hc = tprop + cc;
-  T* qpart = hc + cc;
+  T* qbuf[2] = {hc + cc, hc + cc + (size_t)cc * nq};
   const T* mu = (const T*)m.mu;
   const T* iv = (const T*)m.inv_var;
-  const dim3 eg(nblk, 1);
   for (int64_t c0 = 0; c0 < C; c0 += cc) {
     const int n = (int)((C - c0) < cc ? (C - c0) : cc);
     T* th_c = (T*)theta + c0 * P;
@@ -1477,15 +1613,24 @@ static int large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const v
     if (flags & EY_RECOMPUTE_INITIAL_GRAD) {  // hmc.py:104
       if ((rc = eval_chunk<T>(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s))) return rc;
     }
-    const dim3 grid(eg.x, n);
+    const dim3 grid(nblk, n);
     // p += eps/2 g ; theta += eps p      (hmc.py:105,110)
     hipLaunchKernelGGL((k_leap<T>), grid, dim3(256), 0, s, thp, p, (const T*)gp, P, (T)step, sv_c, T(0.5), T(1.0), mu, iv,
-                       qpart);
+                       qbuf[0]);
     for (int k = 1; k <= L; ++k) {
-      if ((rc = eval_chunk<T>(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s, qpart))) return rc;
-      // full momentum step + position step, or the closing half momentum step (hmc.py:113-119)
-      hipLaunchKernelGGL((k_leap<T>), grid, dim3(256), 0, s, thp, p, (const T*)gp, P, (T)step, sv_c,
-                         k < L ? T(1.0) : T(0.5), k < L ? T(1.0) : T(0.0), mu, iv, qpart);
+      // full momentum step + position step, or the closing half momentum step (hmc.py:113-119): applied by the
+      // kernels that produce the gradient (fuse), else by k_leap after the evaluation
+      const T wp = k < L ? T(1.0) : T(0.5), wt = k < L ? T(1.0) : T(0.0);
+      if (fuse) {
+        const LeapFuse<T> lf = {p, sv_c, (T)step, wp, wt, qbuf[k & 1], nslots, k == L};
+        if ((rc = eval_chunk<T>(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s, qbuf[(k - 1) & 1], nullptr,
+                                k == 1 ? nblk : nslots, &lf)))
+          return rc;
+      } else {
+        if ((rc = eval_chunk<T>(pl, thp, temp_c, n, nullptr, nullptr, tprop, gp, ws, lik_tmp, s, qbuf[0]))) return rc;
+        hipLaunchKernelGGL((k_leap<T>), grid, dim3(256), 0, s, thp, p, (const T*)gp, P, (T)step, sv_c, wp, wt, mu, iv,
+                           qbuf[0]);
+      }
     }
     hipLaunchKernelGGL((k_hmc_end<T>), dim3(n), dim3(256), 0, s, th_c, g_c, t_c, (const T*)thp, (const T*)p,
                        (const T*)gp, (const T*)tprop, (const T*)hc, u ? (const T*)u + c0 : nullptr, P,

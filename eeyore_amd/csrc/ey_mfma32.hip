@@ -917,18 +917,21 @@ static size_t mf_lds_bytes(int ntiles, int waves, int park) {
 // kernel variant (A/B knob): bit 0 = former launch shape (4-wave workgroups, one chain per wave), bit 1 = no priority
 // balancing between the two waves of a SIMD, bit 2 = no momentum parking, bit 4 = route f32 plans through the layerwise
 // path, bit 5 = the layerwise path's register-staged GEMM instead of the LDS-DMA one, bit 6 = the layerwise path's
-// narrow last layer as separate launches instead of the fused tail kernel
+// narrow last layer as separate launches instead of the fused tail kernel, bit 7 = the layerwise path's leapfrog update
+// as a separate kernel instead of in the gradient kernels' epilogues
 static std::atomic<int> g_variant{0};
 extern std::atomic<int> g_ey_force_large;
 extern std::atomic<int> g_ey_no_dma;
 extern std::atomic<int> g_ey_no_tail;
+extern std::atomic<int> g_ey_no_fuse;
 extern "C" int ey_debug_set_variant(int v) {
   const int old = g_variant.load() | (g_ey_force_large.load() << 4) | (g_ey_no_dma.load() << 5) |
-                  (g_ey_no_tail.load() << 6);
+                  (g_ey_no_tail.load() << 6) | (g_ey_no_fuse.load() << 7);
   g_variant.store(v & 15);
   g_ey_force_large.store((v >> 4) & 1);
   g_ey_no_dma.store((v >> 5) & 1);
   g_ey_no_tail.store((v >> 6) & 1);
+  g_ey_no_fuse.store((v >> 7) & 1);
   return old;
 }
 

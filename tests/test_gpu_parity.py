@@ -1223,6 +1223,59 @@ def test_bgemm_path_f64_vs_oracle(dims, acts, bias, lik, N):
         _force_large(False)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,acts,bias,N", [
+    ([4, 3, 3], [1, 0], [1, 1], 150),            # no fused tail (d = 3)
+    ([3, 5, 4, 2], [2, 3, 0], [1, 0, 1], 77),    # a layer without bias
+    ([20, 32, 10], [2, 0], [1, 1], 33),          # fused tail, F = 2
+    ([300, 128, 10], [1, 0], [1, 1], 96),        # fused tail, 128-wide tiles, N-remainder split (300 = 2 x 128 + 44: none)
+    ([784, 128, 10], [1, 0], [1, 1], 64),        # config 5's shape: body + 16-column remainder
+])
+def test_bgemm_hmc_fused_leapfrog_equals_separate_kernel(dims, acts, bias, N):
+    """The leapfrog update applied in the epilogues of the gradient kernels (ey_large.hip: BGT::lf_*, k_tail) against
+    the same trajectory with the separate k_leap kernel (ey_debug_set_variant bit 7): same accept decisions, states
+    equal to f32 rounding of the reordered prior sums."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(sum(dims) + N + 3)
+    x = rng.standard_normal((N, dims[0])) * (rng.random((N, dims[0])) < 0.5)
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)]
+    f32 = torch.float32
+    C = 6
+    res = []
+    for variant in (16, 16 | 128):
+        L.lib().ey_debug_set_variant(variant)
+        try:
+            pl = Plan(dims, bias, acts, 1, f32, DEV)
+            pl.set_data(_t(x, f32), _t(y, f32))
+            pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), 2.0))
+            assert pl.kernel == "bgemm"
+            th = 0.1 * pl.philox_normal(C, seed=9, it=0)
+            temps = torch.tensor([1.0, 0.5, 1.0, 0.25, 1.0, 2.0])
+            steps = torch.tensor([0.01, 0.02, 0.005, 0.01, 0.015, 0.01])
+            t, g = pl.log_target_grad(th, temp=temps)
+            outs = []
+            for it in range(3):
+                o = pl.hmc_step(th, t, g, 0.01, 7, temp=temps, step_vec=steps, seed=4, it=1 + it)
+                outs.append((o["accepted"].clone(), o["h_prop"].clone(), o["rate"].clone()))
+            tn, gn = pl.log_target_grad(th, temp=temps)
+            res.append((th.clone(), t.clone(), g.clone(), tn, gn, outs))
+        finally:
+            L.lib().ey_debug_set_variant(0)
+    a, b = res
+    for (acc_a, hp_a, r_a), (acc_b, hp_b, r_b) in zip(a[5], b[5]):
+        assert torch.equal(acc_a, acc_b)
+        np.testing.assert_allclose(hp_a.cpu().numpy(), hp_b.cpu().numpy(), rtol=2e-5, atol=2e-3)
+    assert sum(int(o[0].sum()) for o in a[5]) > 0
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=2e-5, atol=2e-3)
+    gs = max(1.0, float(b[2].abs().max()))
+    np.testing.assert_allclose(a[2].cpu().numpy(), b[2].cpu().numpy(), rtol=1e-3, atol=1e-4 * gs)
+    # the cached target / gradient of the fused run are those of its final state
+    np.testing.assert_allclose(a[1].cpu().numpy(), a[3].cpu().numpy(), rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(a[2].cpu().numpy(), a[4].cpu().numpy(), rtol=1e-3, atol=1e-4 * gs)
+
+
 def test_config5_shape_mnist_like_model_runs_on_bgemm_path():
     """BASELINE config 5's model shape: MLP(784-128-10), P = 101 770 (does not fit LDS) -> batched-GEMM path."""
     from eeyore_amd.plan import Plan
