@@ -996,6 +996,11 @@ def _force_large(on):
     ([4, 3, 3], [1, 0], [1, 1], 1, 150),
     ([3, 5, 4, 2], [2, 3, 0], [1, 0, 1], 1, 77),
     ([6, 70, 33, 2], [1, 2, 1], [1, 1, 1], 0, 130),
+    # shapes the fused last-layer kernel (k_tail) takes: d_{K-1} in {16, 32, 64, 128}, d_K <= 10
+    ([5, 32, 1], [2, 1], [1, 1], 0, 90),             # BCE on a sigmoid output, tanh hidden layer, F = 2
+    ([7, 20, 64, 3], [1, 3, 0], [1, 1, 0], 1, 70),   # relu before the last layer, last layer without bias, F = 4
+    ([6, 16, 10], [1, 0], [1, 1], 1, 41),            # F = 1, ten classes
+    ([9, 128, 4], [1, 0], [1, 1], 1, 50),            # F = 8
 ])
 def test_bgemm_path_on_small_models_vs_oracle(dims, acts, bias, lik, N):
     """The layerwise batched-GEMM kernels (ey_large.hip), forced onto models the other kernels also cover."""
@@ -1051,6 +1056,8 @@ def test_bgemm_path_on_small_models_vs_oracle(dims, acts, bias, lik, N):
 @pytest.mark.parametrize("dims,acts,bias,lik,N", [
     ([4, 3, 3], [1, 0], [1, 1], 1, 150),
     ([6, 70, 33, 2], [1, 2, 1], [1, 1, 1], 0, 130),
+    ([5, 32, 1], [2, 1], [1, 1], 0, 90),             # through k_tail (value-only and gradient forms, rows output)
+    ([7, 20, 64, 3], [1, 3, 0], [1, 1, 0], 1, 70),
 ])
 def test_bgemm_path_mala_mh_leapfrog_rows_vs_oracle(dims, acts, bias, lik, N):
     """The other entry points of the layerwise path (ey_mala_step, ey_mh_step, ey_hmc_leapfrog, ey_log_lik_rows for
@@ -1137,6 +1144,7 @@ def test_bgemm_path_mala_mh_leapfrog_rows_vs_oracle(dims, acts, bias, lik, N):
     ([3, 5, 4, 2], [2, 3, 0], [1, 0, 1], 1, 77),
     ([6, 70, 33, 2], [1, 2, 1], [1, 1, 1], 0, 130),
     ([20, 128, 10], [1, 0], [1, 1], 1, 96),
+    ([5, 32, 1], [2, 1], [1, 1], 0, 90),
 ])
 def test_bgemm_path_f64_vs_oracle(dims, acts, bias, lik, N):
     """The layerwise path in the reference's default dtype (eeyore/models/model.py:7): every entry point of ey_large.hip
