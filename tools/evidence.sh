@@ -21,5 +21,7 @@ echo "pmc done"
 hipcc -O3 --offload-arch=gfx950 -o /tmp/issue_probe tools/issue_probe.hip 2>/dev/null
 /tmp/issue_probe > $OUT/issue_probe.txt 2>&1
 echo "probe done"
-python3 bench.py --no-cpu-baseline > $OUT/bench_with_traffic.json 2>/dev/null || true
+# with the PMC file of THIS tree in place, the bench line carries roofline.traffic (bench.py checks the source hash)
+cp $OUT/pmc_latest.json profiles/pmc_latest.json
+python3 bench.py > $OUT/bench_with_traffic.json 2>/dev/null || true
 tail -c 600 $OUT/bench_unprofiled.json
