@@ -6,11 +6,13 @@ predictive probability of held-out points integrated over the pooled samples.
 EEYORE_EXAMPLE_CHAINS / EEYORE_EXAMPLE_EPOCHS shrink the run.
 """
 import os
+import sys
 
 import torch
 from torch.distributions import Normal
 from torch.utils.data import DataLoader
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
 from eeyore_amd.constants import loss_functions
 from eeyore_amd.datasets import XYDataset
 from eeyore_amd.distributed import ChainStats, reduce_ess

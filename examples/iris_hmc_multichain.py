@@ -4,12 +4,14 @@ The reference runs one chain per sampler; here ``theta0`` of shape [C, P] makes 
 (momentum draw, L leapfrog steps, accept) for all C chains.  EEYORE_EXAMPLE_CHAINS / EEYORE_EXAMPLE_EPOCHS shrink the run.
 """
 import os
+import sys
 import time
 
 import torch
 from torch.distributions import Normal
 from torch.utils.data import DataLoader
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
 from eeyore_amd.constants import loss_functions
 from eeyore_amd.datasets import XYDataset
 from eeyore_amd.distributed import ChainStats

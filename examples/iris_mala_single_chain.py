@@ -5,12 +5,14 @@ the model, prior, DataLoader, sampler constructor and ``run`` call are the refer
 Set EEYORE_EXAMPLE_EPOCHS to shorten the run.
 """
 import os
+import sys
 import time
 
 import torch
 from torch.distributions import Normal
 from torch.utils.data import DataLoader
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
 from eeyore_amd.constants import loss_functions
 from eeyore_amd.datasets import XYDataset
 from eeyore_amd.models import mlp
@@ -46,7 +48,9 @@ def main():
     print(f"Acceptance rate: {chain.acceptance_rate():.3f}")
     print(f"Monte Carlo mean: {chain.mean()}")
     if len(chain) >= 200:
-        print(f"Multivariate ESS: {chain.multi_ess():.1f}")
+        # in f64: the 27-dimensional determinants of multi_ess underflow in f32 (the reference's multi_ess would too)
+        from eeyore_amd.stats import multi_ess
+        print(f"Multivariate ESS: {multi_ess(chain.get_samples().double()):.1f}")
 
 
 if __name__ == '__main__':
