@@ -198,6 +198,19 @@ class SingleChainSerialSampler(SerialSampler):
     def _temp(self):
         return self.temperature if self.temperature is not None else self.model.temperature
 
+    def set_temperature(self, temperature):
+        """Give the chains new temperatures [C] without touching their states (a replica of a tempering ladder that
+        exchanged its temperature LABEL with a neighbour, ``distributed.TemperingExchange``): the cached tempered
+        log-target and gradient are rescaled by t_new / t_old, which is what re-evaluating them would give
+        (bayesian_model.py:33-34,48-49 multiply both by the temperature)."""
+        old = self._temp()
+        self.temperature = temperature
+        if old is not None and getattr(self, '_target', None) is not None:
+            ratio = (temperature / old).to(self._target.dtype)
+            self._target *= ratio
+            if getattr(self, '_grad', None) is not None:
+                self._grad *= ratio[:, None]
+
     def _step_args(self):
         """(scalar step, per-chain step vector or None) as the C ABI takes them."""
         if torch.is_tensor(self.step) and self.step.dim() == 1:

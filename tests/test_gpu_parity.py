@@ -543,6 +543,37 @@ def test_sampler_surface_batched_philox():
         assert torch.isfinite(ch.get_target_vals()).all()
 
 
+def test_set_temperature_rescales_the_cached_state():
+    """A tempering replica that takes a new temperature label keeps its state (SerialSampler surface,
+    samplers/base.py::set_temperature): the cached tempered log-target and gradient must equal a re-evaluation at the
+    new temperatures (bayesian_model.py:33-34,48-49), and the next draws proceed from them."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    data = synthetic.iris_shaped(dtype=torch.float64, device=DEV)
+    hp = mlp.Hyperparameters(dims=[4, 5, 3], bias=2 * [True], activations=[torch.sigmoid, None])
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'], hparams=hp, dtype=torch.float64, device=DEV)
+    P = model.num_params()
+    model.prior = Normal(torch.zeros(P, device=DEV, dtype=torch.float64), torch.ones(P, device=DEV, dtype=torch.float64))
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    C = 16
+    t_old = torch.linspace(0.1, 1.0, C, dtype=torch.float64, device=DEV)
+    s = HMC(model, theta0=0.2 * torch.randn(C, P, dtype=torch.float64, device=DEV), dataloader=loader, step=0.02,
+            num_steps=5, seed=3, temperature=t_old)
+    s.run(num_epochs=6, num_burnin_epochs=0)
+    t_new = t_old.flip(0).contiguous()
+    s.set_temperature(t_new)
+    x, y = next(iter(loader))
+    tv, gv = model._plan(x, y).log_target_grad(s._theta, temp=t_new)
+    np.testing.assert_allclose(s._target.cpu().numpy(), tv.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(s._grad.cpu().numpy(), gv.cpu().numpy(), rtol=1e-11, atol=1e-11)
+    s.run(num_epochs=4, num_burnin_epochs=0)
+    assert torch.isfinite(s.get_chain().get_target_vals()).all()
+
+
 def test_hmc_fused_run_loop_gives_the_same_chains():
     """HMC.run with blocks of iterations per launch (ey_hmc_run, records written straight into the chain buffer)
     against the same run with one launch per iteration: identical chains, targets and accept flags; with a per-chain
