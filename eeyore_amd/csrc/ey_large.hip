@@ -1,6 +1,6 @@
-// Layerwise batched-GEMM path (f32) for models whose parameters do not fit the LDS of a CU -- BASELINE config 5's
-// MLP(784-128-10) has P = 101 770 (407 KB per chain per state vector).  theta, momentum, gradient and all activations
-// live in HBM; every layer of every chain is one tile job of a chain-batched GEMM on the f32 matrix cores:
+// Layerwise batched-GEMM path (f32 and f64) for models whose parameters do not fit the LDS of a CU -- BASELINE config
+// 5's MLP(784-128-10) has P = 101 770 (407 KB per chain per state vector).  theta, momentum, gradient and all
+// activations live in HBM; every layer of every chain is one tile job of a chain-batched GEMM on the matrix cores:
 //
 //   forward    H_{l+1}[c] = act(H_l[c] W_l[c]^T + b_l[c])            M = rows, N = d_{l+1}, K = d_l   (H_0 = X, shared)
 //   dW         dW_l[c]    = delta_{l+1}[c]^T H_l[c]                  M = d_{l+1}, N = d_l, K = rows
@@ -8,9 +8,11 @@
 //
 // with the same semantics as the other kernel families (MLP.forward eeyore/models/mlp.py:45-50, losses
 // eeyore/constants/constants.py:15-18, log_target eeyore/models/bayesian_model.py:30-56, gradient
-// eeyore/models/log_target_model.py:15-23, HMC eeyore/samplers/hmc.py:100-156).  One GEMM kernel serves the three
-// products through element strides; 128x128x16 tiles through double-buffered LDS, each wave a 64x64 quadrant of
-// v_mfma_f32_32x32x2_f32 tiles.
+// eeyore/models/log_target_model.py:15-23, HMC eeyore/samplers/hmc.py:100-156).  f32: 128x128x16 tiles, each wave a
+// 64x64 quadrant of v_mfma_f32_32x32x2_f32 tiles, operands staged HBM -> LDS by the DMA path (k_bgemm_dma) or through
+// registers (k_bgemm: any strides, narrow shapes); the narrow last layer fused into one pass (k_tail); the leapfrog
+// update in the epilogues of the gradient kernels.  f64: k_bgemm_f64 on v_mfma_f64_16x16x4_f64.  The elementwise
+// kernels and the host logic are written once for both types.
 #include <atomic>
 #include <vector>
 
@@ -23,9 +25,6 @@ std::atomic<int> g_ey_no_dma{0};
 #define g_bgemm_dma (!g_ey_no_dma.load())
 
 #define BK 16
-#ifndef BG_ABL
-#define BG_ABL 0  // timing-only ablations (tools/scratch): 1 = no LDS fragment reads, 2 = no global fetch / staging
-#endif
 #define LDT(R) ((R) + 4)  // [k][row] image of an R-row operand tile: 16-byte aligned rows, staggered over banks
 
 template <class T>
@@ -388,7 +387,7 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
   for (int kt = 0; kt < ktiles; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < ktiles;
-    if (more && !(BG_ABL & 2)) {
+    if (more) {
       fa = FA.load(kt + 1);
       fb = FB.load(kt + 1);
     }
@@ -398,9 +397,9 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
     for (int s = 0; s < BK / 2; ++s) {
       float av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = (BG_ABL & 1) ? (float)(s + i) : Ac[(2 * s + h) * LDT(BMT) + 32 * i];
+      for (int i = 0; i < TM; ++i) av[i] = Ac[(2 * s + h) * LDT(BMT) + 32 * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = (BG_ABL & 1) ? (float)(s - j) : Bc[(2 * s + h) * LDT(BNT) + 32 * j];
+      for (int j = 0; j < TN; ++j) bv[j] = Bc[(2 * s + h) * LDT(BNT) + 32 * j];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -410,7 +409,7 @@ __global__ void __launch_bounds__(256) k_bgemm(BG g) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) rsum += As[cur][k * LDT(BMT) + tid];
     }
-    if (more && !(BG_ABL & 2)) {
+    if (more) {
       FA.store(As[cur ^ 1], fa);
       FB.store(Bs[cur ^ 1], fb);
     }
