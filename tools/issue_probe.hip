@@ -153,6 +153,40 @@ __global__ void __launch_bounds__(256 * W, W) k44(int iters, float* out, unsigne
   report(t0, t1, cyc);
 }
 
+// (e) 64 4x4x1 MFMAs (4 accumulators) and 64 independent v_fma_f32 per iteration, alternating in groups of G:
+// G = 1 is MFMA, FMA, MFMA, FMA, ...; G = 64 is all MFMAs then all FMAs.  What does a switch between the two cost?
+template <int W, int G, int BIG>
+__global__ void __launch_bounds__(256 * W, W) k_alt(int iters, float* out, unsigned long long* cyc) {
+  float a = threadIdx.x * 1e-3f, b = 1.0001f;
+  f32x4 d[4];
+  f32x16 D[2];
+  for (int i = 0; i < 4; ++i) d[i] = (f32x4){0, 0, 0, 0};
+  for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 16; ++r) D[i][r] = 0.0f;
+  float v[8];
+  for (int i = 0; i < 8; ++i) v[i] = a + i;
+  const unsigned long long t0 = STAMP();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u0 = 0; u0 < 64; u0 += G) {
+#pragma unroll
+      for (int u = u0; u < u0 + G; ++u) {
+        if (BIG) D[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, D[u & 1], 0, 0, 0);
+        else d[u & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, d[u & 3], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = u0; u < u0 + G; ++u) v[u & 7] = __builtin_fmaf(v[u & 7], b, a);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const unsigned long long t1 = STAMP();
+  float s = 0.0f;
+  for (int i = 0; i < 8; ++i) s += v[i];
+  out[blockIdx.x * 256 * W + threadIdx.x] = d[0][0] + d[1][0] + d[2][0] + d[3][0] + D[0][0] + D[1][0] + s;
+  report(t0, t1, cyc);
+}
+
 static float* g_out;
 static unsigned long long* g_cyc;
 
@@ -204,5 +238,14 @@ int main() {
   printf("  W=%d accumulators=%d: %.1f\n", W, N, \
          run([&] { hipLaunchKernelGGL((k44<W, N>), dim3(256), dim3(256 * W), 0, 0, it, g_out, g_cyc); }) / it / 64)
   K44(1, 1); K44(1, 2); K44(1, 4); K44(2, 1); K44(2, 2); K44(2, 4);
+  printf("(e) cycles per iteration of 64 MFMAs + 64 independent v_fma_f32 alternating in groups of G (4x4x1 alone 64 x 8.4 =\n"
+         "    538, 32x32x2 alone 4096, the 64 FMAs alone 141)\n");
+#define ALT(W, G, BIG) \
+  printf("  %s W=%d G=%2d: %.0f\n", BIG ? "32x32x2" : "4x4x1  ", W, G, \
+         run([&] { hipLaunchKernelGGL((k_alt<W, G, BIG>), dim3(256), dim3(256 * W), 0, 0, it, g_out, g_cyc); }) / it)
+  ALT(1, 1, 0); ALT(1, 2, 0); ALT(1, 4, 0); ALT(1, 16, 0); ALT(1, 64, 0);
+  ALT(2, 1, 0); ALT(2, 4, 0); ALT(2, 64, 0);
+  ALT(1, 1, 1); ALT(1, 4, 1); ALT(1, 64, 1);
+  ALT(2, 1, 1); ALT(2, 64, 1);
   return 0;
 }
