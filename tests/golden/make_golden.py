@@ -527,6 +527,58 @@ def g9_tuner_initstep_chainfile():
     print("g9", len(out), out["benchmark/listing"])
 
 
+# ----------------------------------------------------------------------------- G10: LogisticRegression
+def g10_logistic_regression():
+    """eeyore/models/logistic_regression.py:8-37 (the model of examples/samplers/logistic_regression/banknotes): values
+    and gradients at seeded thetas in f64 / f32, and a random-walk MH trace as the banknotes example runs it."""
+    from eeyore.models import logistic_regression as lr
+    out = {}
+    rng = np.random.default_rng(10)
+    N, D = 120, 4
+    x = rng.standard_normal((N, D))
+    w_true = np.array([1.5, -2.0, 0.7, 0.0])
+    y = (rng.random(N) < 1.0 / (1.0 + np.exp(-(x @ w_true + 0.3)))).astype(float)[:, None]
+    for tag, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        data = XYDataset(torch.tensor(x, dtype=dtype), torch.tensor(y, dtype=dtype))
+        for bias in (True, False):
+            hp = lr.Hyperparameters(input_size=D, output_size=1, bias=bias)
+            m = lr.LogisticRegression(loss_functions["binary_classification"], hparams=hp, dtype=dtype)
+            P = m.num_params()
+            m.prior = Normal(torch.zeros(P, dtype=dtype), np.sqrt(10.0) * torch.ones(P, dtype=dtype))
+            torch.manual_seed(5)
+            ths = 0.8 * torch.randn(6, P, dtype=dtype)
+            lls, lps, lts, gs = [], [], [], []
+            for th in ths:
+                m.set_params(th.clone())
+                lls.append(tnp(m.log_lik(data.x, data.y)))
+                lps.append(tnp(m.log_prior()))
+                lt, g = m.upto_grad_log_target(th.clone(), data.x, data.y)
+                lts.append(tnp(lt)); gs.append(tnp(g))
+            key = f"{tag}/bias{int(bias)}"
+            out[f"{key}/theta"] = tnp(ths); out[f"{key}/log_lik"] = np.array(lls); out[f"{key}/log_prior"] = np.array(lps)
+            out[f"{key}/log_target"] = np.array(lts); out[f"{key}/grad"] = np.array(gs)
+    out["x"], out["y"], out["prior_sigma"] = x, y, np.array(np.sqrt(10.0))
+    # random-walk Metropolis-Hastings, f64, with bias (metropolis_hastings.py:35-73 through SerialSampler's draw)
+    dtype = torch.float64
+    data = XYDataset(torch.tensor(x, dtype=dtype), torch.tensor(y, dtype=dtype))
+    m = lr.LogisticRegression(loss_functions["binary_classification"], hparams=lr.Hyperparameters(input_size=D), dtype=dtype)
+    P = m.num_params()
+    m.prior = Normal(torch.zeros(P, dtype=dtype), np.sqrt(10.0) * torch.ones(P, dtype=dtype))
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    torch.manual_seed(7)
+    th0 = 0.3 * torch.randn(P, dtype=dtype)
+    s = MetropolisHastings(m, theta0=th0.clone(), dataloader=loader, chain=ChainList())
+    s.kernel.set_density_params(th0.clone(), scale=torch.full([P], 0.25, dtype=dtype))
+    init_t = tnp(s.current["target_val"])
+    rec = run_trace(s, data, 80)
+    print("g10 mh acceptance", rec["accepted"].mean())
+    rec.update(theta0=tnp(th0), init_target=init_t, par=np.array(0.25))
+    for k, v in rec.items():
+        out[f"mh/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g10_logistic_regression.npz"), **out)
+    print("g10", len(out))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     if len(sys.argv) > 1:  # regenerate selected groups only, e.g. `make_golden.py g8_univariate_stats`
@@ -542,6 +594,7 @@ if __name__ == "__main__":
     g7_stats()
     g8_univariate_stats()
     g9_tuner_initstep_chainfile()
+    g10_logistic_regression()
     # bundled datasets re-exported as data fixtures (inputs only)
     d = datasets(torch.float64)
     np.savez_compressed(os.path.join(HERE, "datasets.npz"), xor_x=d["xor"].x.numpy(), xor_y=d["xor"].y.numpy(),

@@ -417,6 +417,70 @@ def test_sampler_surface_single_chain_cfg1():
                                model.log_target(model.get_params(), xor.x, xor.y).item(), rtol=1e-12)
 
 
+def test_g10_logistic_regression_through_the_hip_path():
+    """models.LogisticRegression (the reference's constructor surface, logistic_regression.py:8-37) runs as a one-layer
+    plan: values and gradients against the reference's own numbers (G10) in f64 and f32, with and without bias, the
+    recorded random-walk MH trace of the banknotes example's sampler reproduced decision by decision, and the batched
+    posterior predictive on the same model."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.chains import ChainList
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import XYDataset
+    from eeyore_amd.models import logistic_regression as lr
+    from eeyore_amd.samplers import MetropolisHastings
+    z = load("g10_logistic_regression.npz")
+    D = z["x"].shape[1]
+    for tag, dtype, rtol, atol in (("f64", torch.float64, 1e-10, 1e-11), ("f32", torch.float32, 2e-4, 2e-4)):
+        x, y = _t(z["x"], dtype), _t(z["y"], dtype)
+        for bias in (1, 0):
+            m = lr.LogisticRegression(loss_functions['binary_classification'],
+                                      hparams=lr.Hyperparameters(input_size=D, bias=bool(bias)), dtype=dtype, device=DEV)
+            P = m.num_params()
+            assert P == D + bias
+            m.prior = Normal(torch.zeros(P, dtype=dtype, device=DEV), float(z["prior_sigma"]) * torch.ones(P, dtype=dtype, device=DEV))
+            key = f"{tag}/bias{bias}"
+            for i in range(z[f"{key}/theta"].shape[0]):
+                th = _t(z[f"{key}/theta"][i], dtype)
+                m.set_params(th.clone())
+                np.testing.assert_allclose(m.log_lik(x, y).item(), z[f"{key}/log_lik"][i], rtol=rtol, atol=atol * 10)
+                np.testing.assert_allclose(m.log_prior().item(), z[f"{key}/log_prior"][i], rtol=rtol, atol=atol * 10)
+                t, g = m.upto_grad_log_target(th.clone(), x, y)
+                np.testing.assert_allclose(t.item(), z[f"{key}/log_target"][i], rtol=rtol, atol=atol * 10)
+                np.testing.assert_allclose(g.cpu().numpy(), z[f"{key}/grad"][i], rtol=rtol * 10, atol=atol * 10)
+    # the recorded MH trace (f64, bias)
+    rec = {k[3:]: z[k] for k in z.files if k.startswith("mh/")}
+    m = lr.LogisticRegression(loss_functions['binary_classification'], hparams=lr.Hyperparameters(input_size=D),
+                              dtype=torch.float64, device=DEV)
+    P = m.num_params()
+    m.prior = Normal(torch.zeros(P, dtype=torch.float64, device=DEV), float(z["prior_sigma"]) * torch.ones(P, dtype=torch.float64, device=DEV))
+    data = XYDataset(_t(z["x"]), _t(z["y"]))
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    s = MetropolisHastings(m, theta0=_t(rec["theta0"]), dataloader=loader, chain=ChainList())
+    s.kernel.set_density_params(_t(rec["theta0"]), scale=torch.full((P,), float(rec["par"]), dtype=torch.float64, device=DEV))
+    np.testing.assert_allclose(s.current['target_val'].item(), rec["init_target"], rtol=1e-12)
+    it = {"i": 0}
+    s._randn = lambda C, P_: _t(rec["z"][it["i"]])[None]
+    def rand(C):
+        v = _t([rec["u"][it["i"]]]); it["i"] += 1
+        return v
+    s._rand = rand
+    s.run(num_epochs=rec["z"].shape[0], num_burnin_epochs=0)
+    ch = s.get_chain()
+    assert ch.vals['accepted'] == rec["accepted"].tolist()
+    np.testing.assert_allclose(ch.get_samples().cpu().numpy(), rec["sample"], rtol=1e-9, atol=1e-11)
+    # batched posterior predictive over the stored samples agrees with the model's own forward pass
+    xs, ys = _t(z["x"][:7]), _t(z["y"][:7])
+    pp, dropped = m.predictive_posterior_batched(ch.get_samples()[-20:], xs, ys)
+    assert int(dropped.sum()) == 0
+    want = []
+    for th in ch.get_samples()[-20:]:
+        m.set_params(th.clone())
+        pr = m(xs)
+        want.append(torch.where(ys > 0.5, pr, 1 - pr)[:, 0])
+    np.testing.assert_allclose(pp.cpu().numpy(), torch.stack(want).mean(0).detach().cpu().numpy(), rtol=1e-9)
+
+
 def _model_for(rec, dtype=torch.float64):
     from torch.distributions import Normal
     from eeyore_amd.constants import loss_functions

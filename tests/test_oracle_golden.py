@@ -156,3 +156,44 @@ def test_g7_is_the_reference_published_check():
     assert float(z["multi_ess"][0]) == 564.6937234344964
     z8 = load("g8_univariate_stats.npz")
     assert z8["chains"].shape == (4, 1000, 3) and np.array_equal(z8["chains"], z["chains"])
+
+
+# ------------------------------------------------------------------------------------------------ G10: LogisticRegression
+def _lr_spec(z, bias, dt=np.float64):
+    D = z["x"].shape[1]
+    P = D + int(bias)
+    return orc.Spec([D, 1], [1], 0, bias=[int(bias)], mu=np.zeros(P, dt), sigma=np.full(P, float(z["prior_sigma"]), dt))
+
+
+@pytest.mark.parametrize("tag,rtol,atol", [("f64", 1e-12, 1e-13), ("f32", 2e-5, 2e-5)])
+def test_g10_logistic_regression_values_and_gradients(tag, rtol, atol):
+    """The reference's LogisticRegression (eeyore/models/logistic_regression.py:8-37) is the one-layer case of the MLP
+    oracle: sigmoid(x w + b), BCE-sum, Normal prior."""
+    z = load("g10_logistic_regression.npz")
+    dt = np.float64 if tag == "f64" else np.float32
+    for bias in (1, 0):
+        spec = _lr_spec(z, bias, dt)
+        key = f"{tag}/bias{bias}"
+        for i in range(z[f"{key}/theta"].shape[0]):
+            th = z[f"{key}/theta"][i].astype(dt)
+            x, y = z["x"].astype(dt), z["y"].astype(dt)
+            np.testing.assert_allclose(orc.log_lik(spec, th, x, y), z[f"{key}/log_lik"][i], rtol=rtol, atol=atol * 100)
+            np.testing.assert_allclose(orc.log_prior(spec, th), z[f"{key}/log_prior"][i], rtol=rtol, atol=atol * 100)
+            t, g = orc.upto_grad_log_target(spec, th, x, y)
+            np.testing.assert_allclose(t, z[f"{key}/log_target"][i], rtol=rtol, atol=atol * 100)
+            np.testing.assert_allclose(g, z[f"{key}/grad"][i], rtol=rtol * 10, atol=atol * 10)
+
+
+def test_g10_logistic_regression_mh_trace():
+    z = load("g10_logistic_regression.npz")
+    rec = {k[3:]: z[k] for k in z.files if k.startswith("mh/")}
+    spec = _lr_spec(z, 1)
+    cur = dict(sample=rec["theta0"].copy(), target_val=rec["init_target"][()])
+    margins = []
+    for it in range(rec["z"].shape[0]):
+        cur, info = orc.mh_draw(spec, cur, rec["z"][it], rec["u"][it], z["x"], z["y"], float(rec["par"]))
+        margins.append(abs(np.log(float(rec["u"][it])) - float(info["log_rate"])))
+        assert info["accepted"] == int(rec["accepted"][it]), (it, margins[-1])
+        np.testing.assert_allclose(cur["sample"], rec["sample"][it], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(cur["target_val"], rec["target_val"][it], rtol=1e-10)
+    assert min(margins) > 1e-9 and 0 < rec["accepted"].sum() < len(rec["accepted"])
