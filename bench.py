@@ -187,12 +187,25 @@ def main():
     # (the allocations and host work above) and ramps them over the first hundreds of milliseconds of load, so a 20-step
     # run (23 ms) would be timed on the ramp.  Untimed launches, the same as the timed ones, queued without a gap; the
     # timed region follows the last of them directly (one synchronize, one barrier, no other host work in between).
+    # With several ranks the SAME number of settling launches is queued on every rank from a common start, so that
+    # they reach the barrier in front of the timed region together (a rank that waited there for a slower one would
+    # start its timed steps on an idle device's clock).
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_seconds:
-        for _ in range(4):
-            steps(it, ipl); it += ipl
-        torch.cuda.synchronize()
+    for _ in range(4):
+        steps(it, ipl); it += ipl
+    torch.cuda.synchronize()
+    batch_s = max(time.perf_counter() - t_pre, 1e-4)
+    n_batches = max(0, int(np.ceil(args.prewarm_seconds / batch_s)) - 1)
+    if world > 1:
+        nb = torch.tensor([n_batches], dtype=torch.int64, device="cpu" if gloo else dev)
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
+        n_batches = int(nb.item())
+    for _ in range(4 * n_batches):
+        steps(it, ipl); it += ipl
+    torch.cuda.synchronize()
     stats.attach(plan)  # host-side only: no device work between the warm launches and the timed ones
     if world > 1:
         dist.barrier()
