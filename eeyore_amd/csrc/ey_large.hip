@@ -1538,7 +1538,7 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
 
 static int chunk_size(const ey_plan* pl, int64_t C) {
   const size_t per_chain = 2 * act_floats_per_chain(pl->m) * (pl->dtype == EY_F32 ? 4 : 8);
-  size_t cap = (size_t)3 << 30;  // activation scratch budget
+  size_t cap = (size_t)16 << 30;  // activation scratch budget (of 288 GB): config 5's 4096 chains x 1024 rows are one chunk (4.6 GB)
   int64_t cc = (int64_t)(cap / (per_chain ? per_chain : 1));
   if (cc < 1) cc = 1;
   if (cc > 32768) cc = 32768;  // gridDim.z
