@@ -37,6 +37,7 @@ enum { F16_HMC = 0, F16_GRAD = 1, F16_LEAPFROG = 2, F16_MALA = 3, F16_MH = 4 };
 template <typename T>
 struct F16Args {
   int d0, dK, act0, act1, lik, P;
+  int h1, h2;  // true widths of the two hidden layers (<= H, the template's tile grid; the rest is zero padding)
   int iW0, iB0, iW1, iB1, iW2, iB2;  // offsets of the layers in theta (weights row-major, then the bias, per layer)
   const T* xpack;                    // [ntiles][xt] operand-order data image (k_f16_pack)
   int ntiles, ks0, xt;
@@ -230,22 +231,35 @@ struct F16Slot {
 template <int H, typename T, typename A>
 __device__ __forceinline__ F16Slot f16_slot(int k, const A& a, int c, int g, int lane) {
   typedef F16Cfg<H> K;
+  // Hidden widths h1, h2 below the tile grid H: the slots of features beyond them hold no parameter (theta 0, gradient
+  // masked, no momentum).  A padded hidden unit is act(0) -- not 0 for a sigmoid -- but every weight that reads it is a
+  // padding slot, so it reaches nothing; the weight gradients it produces land in padding slots and are dropped.
   if (k < K::S_W0) {
     const int r = k & 3, n = (k >> 2) % K::MT, mo = (k >> 2) / K::MT;
-    return {a.iW1 + (16 * mo + Lay<T>::fi(g, r)) * H + 16 * n + c, true, true};
+    const int out = 16 * mo + Lay<T>::fi(g, r), in = 16 * n + c;
+    const bool v = out < a.h2 && in < a.h1;
+    return {a.iW1 + out * a.h1 + in, v, v};
   }
   if (k < K::S_W2) {
     const int kk = k - K::S_W0, r = kk & 3, m = kk >> 2;
-    const bool v = c < a.d0;
-    return {a.iW0 + (16 * m + Lay<T>::fi(g, r)) * a.d0 + c, v, v};
+    const int out = 16 * m + Lay<T>::fi(g, r);
+    const bool v = c < a.d0 && out < a.h1;
+    return {a.iW0 + out * a.d0 + c, v, v};
   }
   if (k < K::S_B1) {
     const int kk = k - K::S_W2, r = kk & 3, n = kk >> 2;
-    const bool v = Lay<T>::fi(g, r) < a.dK;
-    return {a.iW2 + Lay<T>::fi(g, r) * H + 16 * n + c, v, v};
+    const int in = 16 * n + c;
+    const bool v = Lay<T>::fi(g, r) < a.dK && in < a.h2;
+    return {a.iW2 + Lay<T>::fi(g, r) * a.h2 + in, v, v};
   }
-  if (k < K::S_B0) return {a.iB1 + 16 * (k - K::S_B1) + c, true, g == 0};
-  if (k < K::S_B2) return {a.iB0 + 16 * (k - K::S_B0) + c, true, g == 0};
+  if (k < K::S_B0) {
+    const int f = 16 * (k - K::S_B1) + c;
+    return {a.iB1 + f, f < a.h2, g == 0 && f < a.h2};
+  }
+  if (k < K::S_B2) {
+    const int f = 16 * (k - K::S_B0) + c;
+    return {a.iB0 + f, f < a.h1, g == 0 && f < a.h1};
+  }
   const int o = k - K::S_B2;
   return {a.iB2 + o, o < a.dK, lane == 0 && o < a.dK};
 }
@@ -804,15 +818,19 @@ __global__ void k_f16_pack(const T* __restrict__ x, const T* __restrict__ y, con
 bool ey_fused16_supports(const ey_plan* pl) {
   const EyModel& m = pl->m;
   if (m.nl != 3) return false;
-  const int H = m.dims[1];
-  if (m.dims[2] != H || (H != 16 && H != 32 && H != 64)) return false;
+  const int H = std::max(m.dims[1], m.dims[2]);  // the tile grid is the next of 16 / 32 / 64; narrower layers are padded
+  if (m.dims[1] < 1 || m.dims[2] < 1 || H > 64) return false;
+  // padded tiles are worth it while the padded W1 is at most eight times the real one (MLP(2-3-2-1) on a 16 x 16 grid
+  // would do 43 times its work: measured half the generic kernel's rate at 65 536 chains)
+  const int Hp = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
+  if (8 * m.dims[1] * m.dims[2] < Hp * Hp) return false;
   if (m.dims[0] < 1 || m.dims[0] > 8 || m.dims[3] < 1 || m.dims[3] > 4) return false;
   if (!m.bias[0] || !m.bias[1] || !m.bias[2]) return false;
   for (int l = 0; l < 2; ++l)
     if (m.act[l] != EY_ACT_SIGMOID && m.act[l] != EY_ACT_TANH && m.act[l] != EY_ACT_RELU) return false;
   if (m.lik == EY_LIK_CE_SUM && m.act[2] != EY_ACT_NONE) return false;
   if (m.lik == EY_LIK_BCE_SUM && m.act[2] != EY_ACT_SIGMOID) return false;
-  if (pl->dtype == EY_F64 && H == 64) return false;  // theta and the gradient alone would take 428 of 512 registers
+  if (pl->dtype == EY_F64 && H > 32) return false;  // theta and the gradient alone would take 428 of 512 registers
   return true;
 }
 
@@ -865,14 +883,15 @@ static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
   a.mu = (const T*)m.mu;
   a.inv_var = (const T*)m.inv_var;
   a.prior_const = (T)m.prior_const;
-  const int H = m.dims[1];
+  a.h1 = m.dims[1]; a.h2 = m.dims[2];
+  const int H = std::max(a.h1, a.h2);
   // waves per CU by what the per-wave LDS region and the register file allow
   if constexpr (sizeof(T) == 4) {
-    if (H == 16) return f16_launch_w<float, 16, 8>(a, pl->n_cu, s);
-    if (H == 32) return f16_launch_w<float, 32, 8>(a, pl->n_cu, s);
+    if (H <= 16) return f16_launch_w<float, 16, 8>(a, pl->n_cu, s);
+    if (H <= 32) return f16_launch_w<float, 32, 8>(a, pl->n_cu, s);
     return f16_launch_w<float, 64, 4>(a, pl->n_cu, s);
   } else {
-    if (H == 16) return f16_launch_w<double, 16, 8>(a, pl->n_cu, s);
+    if (H <= 16) return f16_launch_w<double, 16, 8>(a, pl->n_cu, s);
     return f16_launch_w<double, 32, 4>(a, pl->n_cu, s);
   }
 }

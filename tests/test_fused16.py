@@ -22,6 +22,13 @@ CASES = [
     ([5, 32, 32, 2], [3, 2, 1], 0, "f64", 49),    # relu, tanh, two BCE outputs
     ([3, 64, 64, 2], [1, 2, 1], 0, "f32", 130),
     ([1, 16, 16, 2], [1, 1, 0], 1, "f32", 1),     # one input, one row
+    # hidden widths off the tile grid and unequal: zero-padded to the next of 16 / 32 / 64 (sigmoid(0) = 0.5 in a padded
+    # unit must reach nothing)
+    ([4, 20, 20, 3], [1, 1, 0], 1, "f64", 60),
+    ([4, 10, 7, 3], [1, 1, 0], 1, "f32", 150),
+    ([5, 50, 30, 2], [1, 2, 0], 1, "f32", 77),
+    ([3, 7, 12, 1], [2, 1, 1], 0, "f64", 40),     # 7 x 12 = 84 >= 256 / 8: still worth the 16 x 16 grid
+    ([6, 33, 64, 4], [1, 3, 0], 1, "f32", 45),
 ]
 
 
