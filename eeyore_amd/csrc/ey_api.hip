@@ -86,7 +86,7 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
   EY_HIP(hipGetDeviceProperties(&prop, device_id));
   pl->n_cu = prop.multiProcessorCount;
   pl->mfma32_ok = ey_mfma32_supports(pl);
-  pl->fused16_ok = !pl->mfma32_ok && ey_fused16_supports(pl);
+  pl->fused16_ok = ey_fused16_supports(pl);  // also the headline model's second choice (batches beyond mfma32's row limit)
   *out = pl;
   return EY_OK;
 }
@@ -117,11 +117,24 @@ std::atomic<int> g_ey_force_large{0};  // ey_debug_set_variant bit 4: route f32 
 // the fused MFMA kernel serves this plan with the batch it currently holds
 static bool use_mfma32(const ey_plan* pl) { return pl->mfma32_ok && (pl->mfma32_data_ok || !pl->has_data); }
 // nvec: state vectors the generic kernel of the calling operation keeps in LDS (2 value/MH, 3 HMC, 4 MALA)
-static bool use_large(const ey_plan* pl, int nvec = 3) {
-  return ey_large_needed(pl, nvec) || (g_ey_force_large.load() && !pl->mfma32_ok);
+// The layerwise path is NEEDED when the generic kernel's LDS image does not fit, and PREFERRED for models that fit but
+// are wide enough for 32-wide matrix tiles to beat one wave's vector ALUs: measured (tools/route_probe.py, any number
+// of chains, any row count) the crossover is at sum_l d_l d_{l+1} ~ 600 in f32 (MLP(4-70-3) 0.9 x, MLP(12-48-6) 2 x,
+// MLP(10-100-10) 6-7 x the generic kernel) and below 240 in f64 (MLP(6-24-4) 1.3 x, MLP(4-70-3) 2.3 x).
+// EY_FORCE_GENERIC overrides the preference, not the need.
+static bool prefer_large(const ey_plan* pl) {
+  long w = 0;
+  for (int l = 0; l < pl->m.nl; ++l) w += (long)pl->m.dims[l] * pl->m.dims[l + 1];
+  return w >= (pl->dtype == EY_F32 ? 640 : 200);
+}
+static bool use_large(const ey_plan* pl, int nvec = 3, uint32_t flags = 0) {
+  if (ey_large_needed(pl, nvec)) return true;
+  if (flags & EY_FORCE_GENERIC) return false;
+  if (g_ey_force_large.load() && !pl->mfma32_ok) return true;
+  return prefer_large(pl);
 }
 // the fused 16x16x4 kernels serve this plan (any batch size: their data image lives in global memory)
-static bool use_fused16(const ey_plan* pl) { return pl->fused16_ok && !g_ey_force_large.load(); }
+static bool use_fused16(const ey_plan* pl) { return pl->fused16_ok && !use_mfma32(pl) && !g_ey_force_large.load(); }
 const char* ey_plan_kernel(const ey_plan* pl) {
   if (!pl) return "generic";
   if (use_mfma32(pl)) return "mfma32";
@@ -167,7 +180,7 @@ int ey_plan_set_data(ey_plan* pl, const void* x, const void* y, int64_t N, void*
     int rc = ey_mfma32_set_data(pl, s);
     if (rc) return rc;
   }
-  if (pl->fused16_ok) {
+  if (pl->fused16_ok && !(pl->mfma32_ok && pl->mfma32_data_ok)) {
     int rc = ey_fused16_set_data(pl, s);
     if (rc) return rc;
   }
@@ -328,7 +341,7 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
   if (use_fused16(pl) && !(flags & EY_FORCE_GENERIC))
     rc = ey_fused16_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                         accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream, nullptr, &da);
-  else if (use_large(pl))
+  else if (use_large(pl, 3, flags))
     rc = ey_large_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                       accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
   else
@@ -364,7 +377,7 @@ int ey_hmc_run(ey_plan* pl, void* theta, void* target, void* grad, double step, 
   if (m32)
     return ey_mfma32_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
                          flags, accepted, nullptr, nullptr, nullptr, s, &run, &da);
-  if (f16 || !use_large(pl)) {
+  if (f16 || !use_large(pl, 3, flags)) {
     // the generic kernels do not fuse the moments: they are replayed from the recorded samples, which must then exist
     // (checked BEFORE the launch: a failure must leave the chains where they were)
     if (pl->mom_s1 && n_iters > 1 && (!samples || !accepted_rec))
@@ -480,7 +493,7 @@ static int mala_impl(ey_plan* pl, void* theta, void* target, void* grad, const v
     return ey_mfma32_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
                           log_rate, s, run);
   const bool f16 = use_fused16(pl) && !(flags & EY_FORCE_GENERIC);
-  if (f16 || !use_large(pl, 4)) {  // k_mala carves four state vectors from LDS
+  if (f16 || !use_large(pl, 4, flags)) {  // k_mala carves four state vectors from LDS
     if ((rc = moments_replay_check(pl, run, who))) return rc;  // before the launch: a failure leaves the chains alone
     rc = f16 ? ey_fused16_mala(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter, chain_offset, accepted,
                                log_rate, s, run)
@@ -514,7 +527,7 @@ static int mh_impl(ey_plan* pl, void* theta, void* target, const void* z, const 
   if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC))
     return ey_mfma32_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run);
   const bool f16 = use_fused16(pl) && !(flags & EY_FORCE_GENERIC);
-  if (f16 || !use_large(pl, 2)) {
+  if (f16 || !use_large(pl, 2, flags)) {
     if ((rc = moments_replay_check(pl, run, who))) return rc;
     rc = f16 ? ey_fused16_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run)
              : ey_generic_mh(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset, accepted, log_rate, s, run);

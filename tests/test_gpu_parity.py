@@ -731,14 +731,21 @@ def test_mfma32_row_counts_vs_oracle(N):
                                    atol=2e-4 * max(1.0, np.abs(go).max()))
 
 
-def test_mfma32_falls_back_to_generic_beyond_its_row_limit():
+def test_mfma32_hands_over_to_fused16_beyond_its_row_limit():
+    """The headline model with more rows than mfma32's LDS data image holds (768) is served by the 16x16x4 fused kernel
+    (its data image lives in global memory), and goes back to mfma32 when a batch fits again."""
     rec, pl = _cfg3_plan(800)
-    assert pl.kernel == "generic"
+    assert pl.kernel == "fused16"
     co = _oracle(rec, np.float32)
     th = 0.3 * pl.philox_normal(2, seed=9, it=0)
     t, g = pl.log_target_grad(th)
     to, go, _, _ = co.log_target_grad(th[0].cpu().numpy())
     np.testing.assert_allclose(t[0].item(), to, rtol=2e-4)
+    np.testing.assert_allclose(g[0].cpu().numpy(), go, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(go).max()))
+    out = pl.hmc_step(th, t, g, 0.002, 5, seed=3, it=1)
+    assert torch.isfinite(out["h_prop"]).all()
+    pl.set_data(_t(rec["x"][:150], torch.float32), _t(rec["y"][:150], torch.float32))
+    assert pl.kernel == "mfma32"
 
 
 def test_mfma32_elementwise_prior_vs_oracle():
