@@ -1149,35 +1149,40 @@ __device__ __forceinline__ float row16_sum(float v) {
   v = dpp_add<0x128>(v); v = dpp_add<0x124>(v); v = dpp_add<0x122>(v); v = dpp_add<0x121>(v);
   return v;
 }
+// `room` = how many of this lane's F features exist (d - F q: the layer may be narrower than the 16 F the lanes span;
+// its width is a multiple of the vector piece -- 4, 2 or 1 floats -- so a piece is whole or absent)
 template <int F>
-__device__ __forceinline__ void tail_load(const float* p, bool ok, float (&h)[F]) {
-  if (!ok) {
+__device__ __forceinline__ void tail_load(const float* p, bool ok, int room, float (&h)[F]) {
 #pragma unroll
-    for (int f = 0; f < F; ++f) h[f] = 0.0f;
-    return;
-  }
+  for (int f = 0; f < F; ++f) h[f] = 0.0f;
+  if (!ok) return;
   if constexpr (F >= 4) {
 #pragma unroll
     for (int f = 0; f < F; f += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(p + f);
-      h[f] = v.x; h[f + 1] = v.y; h[f + 2] = v.z; h[f + 3] = v.w;
+      if (f < room) {
+        const float4 v = *reinterpret_cast<const float4*>(p + f);
+        h[f] = v.x; h[f + 1] = v.y; h[f + 2] = v.z; h[f + 3] = v.w;
+      }
     }
   } else if constexpr (F == 2) {
-    const float2 v = *reinterpret_cast<const float2*>(p);
-    h[0] = v.x; h[1] = v.y;
+    if (room > 0) {
+      const float2 v = *reinterpret_cast<const float2*>(p);
+      h[0] = v.x; h[1] = v.y;
+    }
   } else {
-    h[0] = p[0];
+    if (room > 0) h[0] = p[0];
   }
 }
 template <int F>
-__device__ __forceinline__ void tail_store(float* p, const float (&h)[F]) {
+__device__ __forceinline__ void tail_store(float* p, int room, const float (&h)[F]) {
   if constexpr (F >= 4) {
 #pragma unroll
-    for (int f = 0; f < F; f += 4) *reinterpret_cast<float4*>(p + f) = make_float4(h[f], h[f + 1], h[f + 2], h[f + 3]);
+    for (int f = 0; f < F; f += 4)
+      if (f < room) *reinterpret_cast<float4*>(p + f) = make_float4(h[f], h[f + 1], h[f + 2], h[f + 3]);
   } else if constexpr (F == 2) {
-    *reinterpret_cast<float2*>(p) = make_float2(h[0], h[1]);
+    if (room > 0) *reinterpret_cast<float2*>(p) = make_float2(h[0], h[1]);
   } else {
-    p[0] = h[0];
+    if (room > 0) p[0] = h[0];
   }
 }
 template <int F>
@@ -1205,6 +1210,7 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
   const long c = blockIdx.x;
   const int N = a.N, d = a.d, dK = a.dK;
   const float* Hc = a.H + c * (long)N * d + F * q;
+  const int room = d - F * q;  // this lane's features that exist
   const float* th = a.theta + c * a.P;
   // W_{K-1} in LDS (rows beyond d_K zero), laid out so that the 16 lanes of a row read consecutive 16-byte pieces:
   // plane p holds features F q + 4 p .. + 3 of lane q.  (In registers it would cost 10 F of them next to the 10 F
@@ -1212,7 +1218,7 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
   for (int idx = tid; idx < TAIL_DK * 16 * F; idx += 256) {
     const int j = idx / (16 * F), i = idx - j * (16 * F), qq = i / F, f = i - qq * F;
     const int dst = F >= 4 ? ((f >> 2) * TAIL_DK + j) * 64 + 4 * qq + (f & 3) : j * 64 + F * qq + f;
-    wl[dst] = j < dK ? th[a.woff + j * d + i] : 0.0f;
+    wl[dst] = (j < dK && i < d) ? th[a.woff + j * d + i] : 0.0f;
   }
   float bias[TAIL_DK];
 #pragma unroll
@@ -1232,7 +1238,7 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
 #pragma unroll
   for (int u = 0; u < TAIL_PF; ++u) {
     const int n = 16 * u + rs;
-    tail_load<F>(Hc + (long)n * d, u < passes && n < N, hb[u]);
+    tail_load<F>(Hc + (long)n * d, u < passes && n < N, room, hb[u]);
   }
   for (int t0 = 0; t0 < passes; t0 += TAIL_PF) {
 #pragma unroll
@@ -1248,7 +1254,7 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
       asm volatile("" : "+v"(qv));
       {  // refill this slot with the row TAIL_PF passes ahead
         const int n2 = n + 16 * TAIL_PF;
-        tail_load<F>(Hc + (long)n2 * d, t + TAIL_PF < passes && n2 < N, hb[u]);
+        tail_load<F>(Hc + (long)n2 * d, t + TAIL_PF < passes && n2 < N, room, hb[u]);
       }
       // logits: partial dot products over this lane's features, combined over the row's 16 lanes; rows of W beyond d_K
       // are zero.  The activation switches sit OUTSIDE the element loops (one uniform branch per pass, not per element).
@@ -1316,7 +1322,7 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
           dact_vec<F>(a.act_prev, h, dp);
 #pragma unroll
           for (int f = 0; f < F; ++f) dh[f] *= dp[f];
-          tail_store<F>(a.Dout + c * (long)N * d + (long)n * d + F * q, dh);
+          tail_store<F>(a.Dout + c * (long)N * d + (long)n * d + F * q, room, dh);
         }
       }
     }
@@ -1383,13 +1389,17 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
     }
   }
 }
+// d_{K-1} <= 128 and a multiple of the lanes' vector piece: the 16 lanes of a row span 16 F >= d features
+static int tail_f(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 64 ? 4 : 8)); }
 static bool tail_ok(const EyModel& m) {
   const int K = m.nl, d = m.dims[K - 1];
-  return K >= 2 && m.dims[K] <= TAIL_DK && (d == 16 || d == 32 || d == 64 || d == 128);
+  if (K < 2 || m.dims[K] > TAIL_DK || d < 1 || d > 128) return false;
+  const int F = tail_f(d);
+  return d % (F >= 4 ? 4 : F) == 0;
 }
 template <bool GRAD>
 static void tail_launch(const TailArgs& a, int C, hipStream_t s) {
-  switch (a.d / 16) {
+  switch (tail_f(a.d)) {
     case 1: hipLaunchKernelGGL((k_tail<1, GRAD>), dim3(C), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((k_tail<2, GRAD>), dim3(C), dim3(256), 0, s, a); break;
     case 4: hipLaunchKernelGGL((k_tail<4, GRAD>), dim3(C), dim3(256), 0, s, a); break;

@@ -1103,6 +1103,11 @@ def _force_large(on):
     ([7, 20, 64, 3], [1, 3, 0], [1, 1, 0], 1, 70),   # relu before the last layer, last layer without bias, F = 4
     ([6, 16, 10], [1, 0], [1, 1], 1, 41),            # F = 1, ten classes
     ([9, 128, 4], [1, 0], [1, 1], 1, 50),            # F = 8
+    # ... and widths below the 16 F features the lanes of a row span (whole vector pieces masked)
+    ([10, 100, 10], [1, 0], [1, 1], 1, 64),          # F = 8, d = 100
+    ([6, 20, 3], [2, 0], [1, 1], 1, 50),             # F = 2, d = 20
+    ([5, 12, 2], [1, 0], [1, 1], 1, 30),             # F = 1, d = 12
+    ([8, 36, 1], [3, 1], [1, 1], 0, 40),             # F = 4, d = 36, BCE
 ])
 def test_bgemm_path_on_small_models_vs_oracle(dims, acts, bias, lik, N):
     """The layerwise batched-GEMM kernels (ey_large.hip), forced onto models the other kernels also cover."""
@@ -1340,6 +1345,7 @@ def test_bgemm_path_f64_vs_oracle(dims, acts, bias, lik, N):
     ([20, 32, 10], [2, 0], [1, 1], 33),          # fused tail, F = 2
     ([300, 128, 10], [1, 0], [1, 1], 96),        # fused tail, 128-wide tiles, N-remainder split (300 = 2 x 128 + 44: none)
     ([784, 128, 10], [1, 0], [1, 1], 64),        # config 5's shape: body + 16-column remainder
+    ([10, 100, 10], [1, 0], [1, 1], 70),         # fused tail with masked vector pieces (d = 100 < 128)
 ])
 def test_bgemm_hmc_fused_leapfrog_equals_separate_kernel(dims, acts, bias, N):
     """The leapfrog update applied in the epilogues of the gradient kernels (ey_large.hip: BGT::lf_*, k_tail) against

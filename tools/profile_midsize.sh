@@ -1,0 +1,27 @@
+#!/bin/bash
+# Kernel trace of the layerwise path on a mid-size model that fits LDS (MLP(10-100-10), N = 256, 2048 chains, HMC L = 10).
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/midsize
+cat > /tmp/midsize.py <<'PY'
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from eeyore_amd.plan import Plan
+dev = torch.device('cuda', 0)
+dims, N, C = [10, 100, 10], 256, 2048
+rng = np.random.default_rng(0)
+x = rng.standard_normal((N, dims[0])).astype(np.float32)
+y = np.eye(dims[-1], dtype=np.float32)[rng.integers(0, dims[-1], N)]
+pl = Plan(dims, [1, 1], [1, 0], 1, torch.float32, dev)
+pl.set_data(torch.tensor(x, device=dev), torch.tensor(y, device=dev))
+pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
+th = 0.1 * pl.philox_normal(C, seed=0, it=0)
+t, g = pl.log_target_grad(th)
+for i in range(6):
+    pl.hmc_step(th, t, g, 0.005, 10, seed=1, it=1 + i)
+torch.cuda.synchronize()
+print(pl.kernel)
+PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 /tmp/midsize.py > $OUT.log 2>&1
+cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+head -14 $OUT/kernel_stats.csv | cut -c1-150
