@@ -195,6 +195,45 @@ __device__ __forceinline__ float l_sigmoid_fast(float g) {
 __device__ __forceinline__ float l_tanh_fast(float g) {
   return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * g)) - 1.0f;
 }
+// activation / derivative over a small register array with the switch OUTSIDE the element loop
+template <int n>
+__device__ __forceinline__ void act_vec(int code, float (&v)[n]) {
+  switch (code) {
+    case EY_ACT_SIGMOID:
+#pragma unroll
+      for (int i = 0; i < n; ++i) v[i] = l_sigmoid_fast(v[i]);
+      break;
+    case EY_ACT_TANH:
+#pragma unroll
+      for (int i = 0; i < n; ++i) v[i] = l_tanh_fast(v[i]);
+      break;
+    case EY_ACT_RELU:
+#pragma unroll
+      for (int i = 0; i < n; ++i) v[i] = fmaxf(v[i], 0.0f);
+      break;
+    default: break;
+  }
+}
+template <int n>
+__device__ __forceinline__ void dact_vec(int code, const float (&h)[n], float (&o)[n]) {
+  switch (code) {
+    case EY_ACT_SIGMOID:
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i] = h[i] * (1.0f - h[i]);
+      break;
+    case EY_ACT_TANH:
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i] = 1.0f - h[i] * h[i];
+      break;
+    case EY_ACT_RELU:
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i] = h[i] > 0.0f ? 1.0f : 0.0f;
+      break;
+    default:
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i] = 1.0f;
+  }
+}
 #define EPI_AT(base, byte_off) (*(decltype(base))((const char*)(base) + (byte_off)))
 template <int TM, int TN, bool FULL, class F>
 __device__ __forceinline__ void epi_loop(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
@@ -613,20 +652,28 @@ static bool dma_ok(const BG& g, bool& kfast) {
   return false;
 }
 
-// Input gradient of a narrow layer, delta_l = (delta_{l+1} W_l) * act'(H_l) with K = d_{l+1} <= 16 (the 10-class output
-// layer of config 5): ten multiply-adds per output do not need the matrix cores or a 128 x 128 tile -- the product is
-// HBM-bound on reading H_l and writing delta_l.  One thread per four consecutive outputs of a row; the chain's W_l
-// (K x N) is staged in LDS, the row's delta_{l+1} comes through the scalar path.
-#define DH_ROWS 128  // rows of delta_l per workgroup (the staged W_l is reused across them)
-__global__ void __launch_bounds__(256) k_dh_smallk(BG g) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [K][N]
+// Products with a short contraction, K <= 16, through the vector ALUs: a handful of multiply-adds per output do not
+// need the matrix cores or a 128 x 128 tile -- the product is HBM-bound on its output (and on H_l for the input
+// gradient).  Two users: the input gradient of a narrow layer, delta_l = (delta_{l+1} W_l) * act'(H_l) with K = d_{l+1}
+// (the 10-class output layer of config 5), and the forward product of a layer with few inputs, H_1 = act(X W_0^T + b_0)
+// with K = d_0 (tabular data: Iris has 4 features).  One thread per four consecutive outputs of a row; the chain's
+// K x N operand is staged in LDS (whatever its strides), the row's K values of A come through the scalar path.
+#define DH_ROWS 128  // rows per workgroup (the staged operand is reused across them)
+template <bool FWD>
+__global__ void __launch_bounds__(256) k_smallk(BG g) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [K][N] (+ [N] bias)
   const long b = blockIdx.z;
   const float* A = g.A + b * g.bA;
   const float* B = g.B + b * g.bB;
-  const float* Hm = g.Hm + b * g.bH;
   float* C = g.C + b * g.bC;
   const int N4 = g.N >> 2;
-  for (int i = threadIdx.x; i < g.K * g.N; i += 256) wsm[i] = B[(long)(i / g.N) * g.sBk + (i % g.N)];
+  for (int i = threadIdx.x; i < g.K * g.N; i += 256) {
+    const int k = i / g.N, n = i - k * g.N;
+    wsm[i] = B[(long)k * g.sBk + (long)n * g.sBn];
+  }
+  float* bsm = wsm + g.K * g.N;
+  if (FWD)
+    for (int i = threadIdx.x; i < g.N; i += 256) bsm[i] = g.bias ? g.bias[b * g.bBias + i] : 0.0f;
   __syncthreads();
   const int rows_per_pass = 256 / N4;
   const int n = (threadIdx.x % N4) * 4;
@@ -639,20 +686,31 @@ __global__ void __launch_bounds__(256) k_dh_smallk(BG g) {
       const float4 w = *reinterpret_cast<const float4*>(wsm + k * g.N + n);
       acc[0] += a * w.x; acc[1] += a * w.y; acc[2] += a * w.z; acc[3] += a * w.w;
     }
-    const float4 hv = *reinterpret_cast<const float4*>(Hm + (long)m * g.sHm + n);
-    float4 o;
-    o.x = acc[0] * l_dact(g.act_h, hv.x);
-    o.y = acc[1] * l_dact(g.act_h, hv.y);
-    o.z = acc[2] * l_dact(g.act_h, hv.z);
-    o.w = acc[3] * l_dact(g.act_h, hv.w);
-    *reinterpret_cast<float4*>(C + (long)m * g.sCm + n) = o;
+    if (FWD) {
+      const float4 bv = *reinterpret_cast<const float4*>(bsm + n);
+      acc[0] += bv.x; acc[1] += bv.y; acc[2] += bv.z; acc[3] += bv.w;
+      act_vec<4>(g.act, acc);
+    } else {
+      const float4 hv = *reinterpret_cast<const float4*>(g.Hm + b * g.bH + (long)m * g.sHm + n);
+      const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
+      float da[4];
+      dact_vec<4>(g.act_h, hh, da);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] *= da[j];
+    }
+    *reinterpret_cast<float4*>(C + (long)m * g.sCm + n) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
-static bool dh_smallk_ok(const BG& g) {
-  return g.Hm && !g.bias && !g.pr_theta && !g.rowsum && g.K <= 16 && g.N % 4 == 0 && g.N <= 1024 && g.sAk == 1 &&
-         g.sBn == 1 && g.sCn == 1 && g.sHn == 1 && g.sCm % 4 == 0 && g.sHm % 4 == 0 && g.bC % 4 == 0 && g.bH % 4 == 0 &&
-         (size_t)g.K * g.N * 4 <= 48 * 1024 && g.N >= 4 &&
-         (((uintptr_t)g.C | (uintptr_t)g.Hm) & 15) == 0;
+// 0 = not this kernel's product, 1 = input gradient, 2 = forward
+static int smallk_kind(const BG& g) {
+  if (g.pr_theta || g.rowsum || g.K > 16 || g.N % 4 != 0 || g.N < 4 || g.N > 1024 || g.sAk != 1 || g.sCn != 1 ||
+      g.sCm % 4 != 0 || g.bC % 4 != 0 || ((uintptr_t)g.C & 15) != 0 || (size_t)(g.K + 1) * g.N * 4 > 48 * 1024)
+    return 0;
+  if (g.Hm) {
+    if (g.bias || g.sHn != 1 || g.sHm % 4 != 0 || g.bH % 4 != 0 || ((uintptr_t)g.Hm & 15) != 0) return 0;
+    return 1;
+  }
+  return 2;
 }
 
 static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry);
@@ -663,13 +721,13 @@ static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry);
 // cursor: next free slot of the fused leapfrog update's partial sums (g.lf_p set), advanced by the blocks launched;
 // dry: only advance the cursor (the host sizes the slot buffer with the same dispatch logic it launches with).
 static int bgemm(const BG& g, int batch, hipStream_t s, int* cursor = nullptr, bool dry = false) {
-  if (dh_smallk_ok(g)) {
-    if (256 / (g.N >> 2) >= 1) {
-      dim3 grid((g.M + DH_ROWS - 1) / DH_ROWS, 1, batch);
-      hipLaunchKernelGGL(k_dh_smallk, grid, dim3(256), (size_t)g.K * g.N * sizeof(float), s, g);
-      EY_HIP(hipGetLastError());
-      return EY_OK;
-    }
+  if (const int kind = smallk_kind(g)) {
+    const dim3 grid((g.M + DH_ROWS - 1) / DH_ROWS, 1, batch);
+    const size_t lds = (size_t)(g.K + 1) * g.N * sizeof(float);
+    if (kind == 1) hipLaunchKernelGGL(k_smallk<false>, grid, dim3(256), lds, s, g);
+    else hipLaunchKernelGGL(k_smallk<true>, grid, dim3(256), lds, s, g);
+    EY_HIP(hipGetLastError());
+    return EY_OK;
   }
   const int rem = g.N % 128;
   if (g.M > 32 && g.N > 128 && rem > 0 && rem <= 32 && !g.bias && !g.Hm) {
@@ -1100,44 +1158,6 @@ __device__ __forceinline__ float l_act_fast(int code, float g) {
     case EY_ACT_TANH: return l_tanh_fast(g);
     case EY_ACT_RELU: return g > 0.0f ? g : 0.0f;
     default: return g;
-  }
-}
-template <int n>
-__device__ __forceinline__ void act_vec(int code, float (&v)[n]) {
-  switch (code) {
-    case EY_ACT_SIGMOID:
-#pragma unroll
-      for (int i = 0; i < n; ++i) v[i] = l_sigmoid_fast(v[i]);
-      break;
-    case EY_ACT_TANH:
-#pragma unroll
-      for (int i = 0; i < n; ++i) v[i] = l_tanh_fast(v[i]);
-      break;
-    case EY_ACT_RELU:
-#pragma unroll
-      for (int i = 0; i < n; ++i) v[i] = fmaxf(v[i], 0.0f);
-      break;
-    default: break;
-  }
-}
-template <int n>
-__device__ __forceinline__ void dact_vec(int code, const float (&h)[n], float (&o)[n]) {
-  switch (code) {
-    case EY_ACT_SIGMOID:
-#pragma unroll
-      for (int i = 0; i < n; ++i) o[i] = h[i] * (1.0f - h[i]);
-      break;
-    case EY_ACT_TANH:
-#pragma unroll
-      for (int i = 0; i < n; ++i) o[i] = 1.0f - h[i] * h[i];
-      break;
-    case EY_ACT_RELU:
-#pragma unroll
-      for (int i = 0; i < n; ++i) o[i] = h[i] > 0.0f ? 1.0f : 0.0f;
-      break;
-    default:
-#pragma unroll
-      for (int i = 0; i < n; ++i) o[i] = 1.0f;
   }
 }
 template <int CTRL>
