@@ -713,6 +713,116 @@ static int smallk_kind(const BG& g) {
   return 2;
 }
 
+// Weight gradient of a layer with few inputs, dW[m][n] = sum_k delta[k][m] X[k][n] with N = d_l <= 16 (the first layer on
+// tabular data) and M = d_{l+1} <= 256: HBM-bound on reading delta once.  One workgroup per chain; thread (grp, m) owns
+// output row m for the rows k = grp, grp + G, ... (G = 256 / Mp groups, Mp = M rounded up to whole waves, so that the
+// lanes of a wave share k and the X row is an LDS broadcast); X is staged in LDS 64 rows at a time.  The groups'
+// partial sums are combined in group order (reproducible), then the epilogue of the weight-gradient products: bias
+// gradient (the sum of delta over rows), prior gradient, temperature and, when asked, the leapfrog update with the
+// workgroup's partial prior sum in ONE slot.
+#define DWN_XROWS 64
+__global__ void __launch_bounds__(256) k_dw_smalln(BG g) {
+  __shared__ __attribute__((aligned(16))) float xs[DWN_XROWS * 16];
+  __shared__ float part[256 * 17];  // [grp][m][N + 1], reused for the reduction of q
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x;
+  const int M = g.M, N = g.N, K = g.K;
+  const int Mp = (M + 63) & ~63, G = 256 / Mp;
+  const int m = tid % Mp, grp = tid / Mp;
+  const bool live = m < M && grp < G;
+  const float* A = g.A + b * g.bA;   // delta: [k][m], m contiguous
+  const float* B = g.B + b * g.bB;   // X: [k][n], n contiguous
+  float acc[16], rs = 0.0f;
+#pragma unroll
+  for (int n = 0; n < 16; ++n) acc[n] = 0.0f;
+  for (int k0 = 0; k0 < K; k0 += DWN_XROWS) {
+    const int kn = min(DWN_XROWS, K - k0);
+    __syncthreads();
+    for (int i = tid; i < kn * 16; i += 256) {
+      const int kk = i >> 4, n = i & 15;
+      xs[i] = n < N ? B[(long)(k0 + kk) * g.sBk + n] : 0.0f;
+    }
+    __syncthreads();
+    if (live) {
+      // eight rows' delta values are fetched before any is used: the loop is bound by the latency of these loads
+      for (int kk = grp; kk < kn; kk += 8 * G) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = kk + u * G < kn ? A[(long)(k0 + kk + u * G) * g.sAk + m] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (kk + u * G >= kn) break;
+          rs += a[u];
+          const float4* xr = reinterpret_cast<const float4*>(xs + (kk + u * G) * 16);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float4 xv = xr[v];
+            acc[4 * v] += a[u] * xv.x; acc[4 * v + 1] += a[u] * xv.y; acc[4 * v + 2] += a[u] * xv.z;
+            acc[4 * v + 3] += a[u] * xv.w;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int n = 0; n < 16; ++n) part[(grp * Mp + m) * 17 + n] = acc[n];
+    part[(grp * Mp + m) * 17 + 16] = rs;
+  }
+  __syncthreads();
+  // ---- epilogue: thread e handles output element e of the M x N block, then the M bias elements
+  const float tscale = g.pr_temp ? g.pr_temp[b] : 1.0f;
+  const bool fuse = g.lf_p != nullptr;
+  const float eps = fuse ? (g.lf_step_vec ? g.lf_step_vec[b] : g.lf_step) : 0.0f;
+  const float ep = g.lf_wp * eps, et = g.lf_wt * eps;
+  float q = 0.0f;
+  auto emit = [&](float v, float* gout, float* theta, float* pmom, const float* mu, const float* iv) {
+    const float m_ = *mu, i_ = *iv;
+    float tv = *theta;
+    const float gv = (v - (tv - m_) * i_) * tscale;
+    if (!fuse) { *gout = gv; return; }
+    if (g.lf_store_g) *gout = gv;
+    const float pv = *pmom + ep * gv;
+    *pmom = pv;
+    if (g.lf_wt != 0.0f) { tv = tv + et * pv; *theta = tv; }
+    const float dd = tv - m_;
+    q += dd * dd * i_;
+  };
+  for (int e = tid; e < M * N; e += 256) {
+    const int mm = e / N, n = e - mm * N;
+    float v = 0.0f;
+    for (int gg = 0; gg < G; ++gg) v += part[(gg * Mp + mm) * 17 + n];
+    const long ci = (long)mm * g.sCm + n;
+    emit(v, g.C + b * g.bC + ci, const_cast<float*>(g.pr_theta) + b * g.bC + ci, fuse ? g.lf_p + b * g.bC + ci : nullptr,
+         g.pr_mu + ci, g.pr_iv + ci);
+  }
+  if (g.rowsum) {
+    for (int mm = tid; mm < M; mm += 256) {
+      float v = 0.0f;
+      for (int gg = 0; gg < G; ++gg) v += part[(gg * Mp + mm) * 17 + 16];
+      if (g.pr_theta_b)
+        emit(v, g.rowsum + b * g.bRow + mm, const_cast<float*>(g.pr_theta_b) + b * g.bRow + mm,
+             fuse ? g.lf_p_b + b * g.bRow + mm : nullptr, g.pr_mu_b + mm, g.pr_iv_b + mm);
+      else
+        g.rowsum[b * g.bRow + mm] = v;
+    }
+  }
+  if (fuse) {  // uniform over the workgroup
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = q;
+    __syncthreads();
+    if (tid == 0) g.lf_q[b * g.lf_nslots + g.lf_slot0] = ((part[0] + part[1]) + part[2]) + part[3];
+  }
+}
+// a weight-gradient product (pr_theta set) of a layer with at most 16 inputs and 256 outputs, both operands row-major
+static bool dw_smalln_ok(const BG& g) {
+  return g.pr_theta && !g.Hm && !g.bias && g.N <= 16 && g.M <= 256 && g.sAm == 1 && g.sBn == 1 && g.sCn == 1 &&
+         (!g.rowsum || g.pr_theta_b || !g.lf_p);
+}
+
 static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry);
 
 // One product, split where that saves padded work: a weight gradient whose N is a few columns past a multiple of 128
@@ -721,6 +831,17 @@ static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry);
 // cursor: next free slot of the fused leapfrog update's partial sums (g.lf_p set), advanced by the blocks launched;
 // dry: only advance the cursor (the host sizes the slot buffer with the same dispatch logic it launches with).
 static int bgemm(const BG& g, int batch, hipStream_t s, int* cursor = nullptr, bool dry = false) {
+  if (dw_smalln_ok(g)) {
+    BG h = g;
+    if (cursor && (g.lf_p || dry)) {
+      h.lf_slot0 = *cursor;
+      *cursor += 1;
+      if (dry) return EY_OK;
+    }
+    hipLaunchKernelGGL(k_dw_smalln, dim3(batch), dim3(256), 0, s, h);
+    EY_HIP(hipGetLastError());
+    return EY_OK;
+  }
   if (const int kind = smallk_kind(g)) {
     const dim3 grid((g.M + DH_ROWS - 1) / DH_ROWS, 1, batch);
     const size_t lds = (size_t)(g.K + 1) * g.N * sizeof(float);
@@ -1463,7 +1584,11 @@ static int leap_fuse_slots(const EyModel& m, bool tail) {
   int cursor = tail ? 1 : 0;
   for (int l = (tail ? m.nl - 2 : m.nl - 1); l >= 0; --l) {
     BG g = {};
+    // the fields the dispatcher looks at, as eval_chunk sets them for a weight-gradient product
     g.M = m.dims[l + 1]; g.N = m.dims[l]; g.K = m.N; g.sCm = m.dims[l]; g.sCn = 1;
+    g.sAm = 1; g.sAk = m.dims[l + 1]; g.sBk = m.dims[l]; g.sBn = 1;
+    g.pr_theta = (const float*)m.mu; g.pr_theta_b = m.boff[l] >= 0 ? (const float*)m.mu : nullptr;
+    g.rowsum = m.boff[l] >= 0 ? (float*)m.mu : nullptr;  // never dereferenced in a dry run
     bgemm(g, 1, nullptr, &cursor, true);
   }
   return cursor;
