@@ -1342,7 +1342,7 @@ __device__ __forceinline__ void tail_wrow(const float* wl, int j, int q, float (
   }
 }
 template <int F, bool GRAD>
-__global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
+__global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
   __shared__ float red[4][TAIL_DK * 16 * F];
   __shared__ __attribute__((aligned(16))) float wl[(F >= 4 ? F / 4 : 1) * TAIL_DK * 64];
   __shared__ float redb[4][TAIL_DK];
@@ -1365,10 +1365,9 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
 #pragma unroll
   for (int j = 0; j < TAIL_DK; ++j) bias[j] = (j < dK && a.boff >= 0) ? th[a.boff + j] : 0.0f;
   __syncthreads();
-  float acc[TAIL_DK][F], dbacc[TAIL_DK];
+  float acc[TAIL_DK][F], dbq = 0.0f;  // dbq: lane q of a row keeps the bias-gradient sum of output q (one register, not d_K)
 #pragma unroll
   for (int j = 0; j < TAIL_DK; ++j) {
-    dbacc[j] = 0.0f;
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[j][f] = 0.0f;
   }
@@ -1451,7 +1450,7 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
         for (int j = 0; j < TAIL_DK; ++j) {
           float wj[F];
           tail_wrow<F>(wl, j, qv, wj);
-          dbacc[j] += dl[j];
+          dbq += j == q ? dl[j] : 0.0f;
 #pragma unroll
           for (int f = 0; f < F; ++f) {
             acc[j][f] += dl[j] * h[f];
@@ -1474,12 +1473,14 @@ __global__ void __launch_bounds__(256, 2) k_tail(TailArgs a) {
   lv += __shfl_xor(lv, 32, 64);
   if (lane == 0) redl[wave] = lv;
   if (GRAD) {
-#pragma unroll
-    for (int j = 0; j < TAIL_DK; ++j) {
-      float b = dbacc[j];
+    {
+      float b = dbq;  // lanes q, q + 16, q + 32, q + 48: the wave's four rows
       b += __shfl_xor(b, 16, 64);
       b += __shfl_xor(b, 32, 64);
-      if (lane == 0) redb[wave][j] = b;
+      if (lane < TAIL_DK) redb[wave][lane] = b;
+    }
+#pragma unroll
+    for (int j = 0; j < TAIL_DK; ++j) {
 #pragma unroll
       for (int f = 0; f < F; ++f) {
         float v = acc[j][f];
