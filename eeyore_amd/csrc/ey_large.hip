@@ -1326,28 +1326,39 @@ __device__ __forceinline__ void tail_store(float* p, int room, const float (&h)[
     if (room > 0) p[0] = h[0];
   }
 }
-template <int F>
+template <int F, int WS>
 __device__ __forceinline__ void tail_wrow(const float* wl, int j, int q, float (&w)[F]) {
   if constexpr (F >= 4) {
 #pragma unroll
     for (int p = 0; p < F / 4; ++p) {
-      const float4 v = *reinterpret_cast<const float4*>(wl + (p * TAIL_DK + j) * 64 + 4 * q);
+      const float4 v = *reinterpret_cast<const float4*>(wl + (p * TAIL_DK + j) * WS + 4 * q);
       w[4 * p] = v.x; w[4 * p + 1] = v.y; w[4 * p + 2] = v.z; w[4 * p + 3] = v.w;
     }
   } else if constexpr (F == 2) {
-    const float2 v = *reinterpret_cast<const float2*>(wl + j * 64 + 2 * q);
+    const float2 v = *reinterpret_cast<const float2*>(wl + j * WS + 2 * q);
     w[0] = v.x; w[1] = v.y;
   } else {
-    w[0] = wl[j * 64 + q];
+    w[0] = wl[j * WS + q];
   }
 }
-template <int F, bool GRAD>
+// sum over the LPR lanes of a row, result in every lane of the row
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+  v = row16_sum(v);
+  if (LPR == 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+// LPR lanes per row, RPP = 256 / LPR rows per pass.  LPR = 16 is what runs: for d > 64 that means 8 features per lane, 80
+// accumulators and two waves per SIMD; the alternative (32 lanes x 4 features, three waves per SIMD) measured 5-10 %
+// slower -- the loss is computed redundantly by every lane of a row and the row sums cross a DPP row boundary.
+template <int F, int LPR, bool GRAD>
 __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
-  __shared__ float red[4][TAIL_DK * 16 * F];
-  __shared__ __attribute__((aligned(16))) float wl[(F >= 4 ? F / 4 : 1) * TAIL_DK * 64];
+  constexpr int RPP = 256 / LPR, WS = LPR * 4;  // rows per pass; floats per row of a W plane
+  __shared__ float red[4][TAIL_DK * LPR * F];
+  __shared__ __attribute__((aligned(16))) float wl[(F >= 4 ? F / 4 : 1) * TAIL_DK * WS];
   __shared__ float redb[4][TAIL_DK];
   __shared__ float redl[4];
-  const int tid = threadIdx.x, q = tid & 15, rs = tid >> 4, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, q = tid & (LPR - 1), rs = tid / LPR, wave = tid >> 6, lane = tid & 63;
   const long c = blockIdx.x;
   const int N = a.N, d = a.d, dK = a.dK;
   const float* Hc = a.H + c * (long)N * d + F * q;
@@ -1356,9 +1367,9 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
   // W_{K-1} in LDS (rows beyond d_K zero), laid out so that the 16 lanes of a row read consecutive 16-byte pieces:
   // plane p holds features F q + 4 p .. + 3 of lane q.  (In registers it would cost 10 F of them next to the 10 F
   // accumulators; the reads are broadcasts over the wave's four rows and cost a few LDS cycles per pass.)
-  for (int idx = tid; idx < TAIL_DK * 16 * F; idx += 256) {
-    const int j = idx / (16 * F), i = idx - j * (16 * F), qq = i / F, f = i - qq * F;
-    const int dst = F >= 4 ? ((f >> 2) * TAIL_DK + j) * 64 + 4 * qq + (f & 3) : j * 64 + F * qq + f;
+  for (int idx = tid; idx < TAIL_DK * LPR * F; idx += 256) {
+    const int j = idx / (LPR * F), i = idx - j * (LPR * F), qq = i / F, f = i - qq * F;
+    const int dst = F >= 4 ? ((f >> 2) * TAIL_DK + j) * WS + 4 * qq + (f & 3) : j * WS + F * qq + f;
     wl[dst] = (j < dK && i < d) ? th[a.woff + j * d + i] : 0.0f;
   }
   float bias[TAIL_DK];
@@ -1373,11 +1384,11 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
   }
   float lik = 0.0f;
   const float rowscale = a.rows_temp && a.temp ? a.temp[c] : 1.0f;
-  const int passes = (N + 15) >> 4;
+  const int passes = (N + RPP - 1) / RPP;
   float hb[TAIL_PF][F];
 #pragma unroll
   for (int u = 0; u < TAIL_PF; ++u) {
-    const int n = 16 * u + rs;
+    const int n = RPP * u + rs;
     tail_load<F>(Hc + (long)n * d, u < passes && n < N, room, hb[u]);
   }
   for (int t0 = 0; t0 < passes; t0 += TAIL_PF) {
@@ -1385,7 +1396,7 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
     for (int u = 0; u < TAIL_PF; ++u) {
       const int t = t0 + u;
       if (t >= passes) break;  // uniform
-      const int n = 16 * t + rs;
+      const int n = RPP * t + rs;
       const bool live = n < N;
       float h[F];
 #pragma unroll
@@ -1393,7 +1404,7 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
       int qv = q;  // opaque per pass: keeps the W reads below in the loop (hoisted, they would occupy 10 F registers)
       asm volatile("" : "+v"(qv));
       {  // refill this slot with the row TAIL_PF passes ahead
-        const int n2 = n + 16 * TAIL_PF;
+        const int n2 = n + RPP * TAIL_PF;
         tail_load<F>(Hc + (long)n2 * d, t + TAIL_PF < passes && n2 < N, room, hb[u]);
       }
       // logits: partial dot products over this lane's features, combined over the row's 16 lanes; rows of W beyond d_K
@@ -1402,10 +1413,10 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
 #pragma unroll
       for (int j = 0; j < TAIL_DK; ++j) {
         float wj[F], pz = 0.0f;
-        tail_wrow<F>(wl, j, qv, wj);
+        tail_wrow<F, WS>(wl, j, qv, wj);
 #pragma unroll
         for (int f = 0; f < F; ++f) pz += h[f] * wj[f];
-        z[j] = row16_sum(pz) + bias[j];
+        z[j] = row_sum<LPR>(pz) + bias[j];
       }
       act_vec<TAIL_DK>(a.act_last, z);
       dact_vec<TAIL_DK>(a.act_last, z, da);
@@ -1449,7 +1460,7 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
 #pragma unroll
         for (int j = 0; j < TAIL_DK; ++j) {
           float wj[F];
-          tail_wrow<F>(wl, j, qv, wj);
+          tail_wrow<F, WS>(wl, j, qv, wj);
           dbq += j == q ? dl[j] : 0.0f;
 #pragma unroll
           for (int f = 0; f < F; ++f) {
@@ -1469,13 +1480,13 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
   }
   // ---- reductions over rows: slots of a wave (lane bits 4, 5), then the four waves, in that order
   float lv = q == 0 ? lik : 0.0f;
-  lv += __shfl_xor(lv, 16, 64);
+  if (LPR == 16) lv += __shfl_xor(lv, 16, 64);
   lv += __shfl_xor(lv, 32, 64);
   if (lane == 0) redl[wave] = lv;
   if (GRAD) {
     {
       float b = dbq;  // lanes q, q + 16, q + 32, q + 48: the wave's four rows
-      b += __shfl_xor(b, 16, 64);
+      if (LPR == 16) b += __shfl_xor(b, 16, 64);
       b += __shfl_xor(b, 32, 64);
       if (lane < TAIL_DK) redb[wave][lane] = b;
     }
@@ -1484,9 +1495,9 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
 #pragma unroll
       for (int f = 0; f < F; ++f) {
         float v = acc[j][f];
-        v += __shfl_xor(v, 16, 64);
+        if (LPR == 16) v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < 16) red[wave][j * (16 * F) + F * q + f] = v;
+        if (lane < LPR) red[wave][j * (LPR * F) + F * q + f] = v;
       }
     }
   }
@@ -1517,8 +1528,8 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
     };
     for (int e = tid; e < dK * d; e += 256) {
       const int j = e / d, i = e - j * d;
-      emit(a.woff + e, ((red[0][j * (16 * F) + i] + red[1][j * (16 * F) + i]) + red[2][j * (16 * F) + i]) +
-                           red[3][j * (16 * F) + i]);
+      emit(a.woff + e, ((red[0][j * (LPR * F) + i] + red[1][j * (LPR * F) + i]) + red[2][j * (LPR * F) + i]) +
+                           red[3][j * (LPR * F) + i]);
     }
     if (a.boff >= 0 && tid < dK) emit(a.boff + tid, ((redb[0][tid] + redb[1][tid]) + redb[2][tid]) + redb[3][tid]);
     if (fuse) {  // uniform over the workgroup
@@ -1532,7 +1543,7 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
   }
 }
 // d_{K-1} <= 128 and a multiple of the lanes' vector piece: the 16 lanes of a row span 16 F >= d features
-static int tail_f(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 64 ? 4 : 8)); }
+static int tail_f(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 64 ? 4 : 8)); }  // features per lane, 16 lanes per row
 static bool tail_ok(const EyModel& m) {
   const int K = m.nl, d = m.dims[K - 1];
   if (K < 2 || m.dims[K] > TAIL_DK || d < 1 || d > 128) return false;
@@ -1541,12 +1552,10 @@ static bool tail_ok(const EyModel& m) {
 }
 template <bool GRAD>
 static void tail_launch(const TailArgs& a, int C, hipStream_t s) {
-  switch (tail_f(a.d)) {
-    case 1: hipLaunchKernelGGL((k_tail<1, GRAD>), dim3(C), dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_tail<2, GRAD>), dim3(C), dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_tail<4, GRAD>), dim3(C), dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_tail<8, GRAD>), dim3(C), dim3(256), 0, s, a); break;
-  }
+  if (a.d <= 16) hipLaunchKernelGGL((k_tail<1, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
+  else if (a.d <= 32) hipLaunchKernelGGL((k_tail<2, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
+  else if (a.d <= 64) hipLaunchKernelGGL((k_tail<4, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_tail<8, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
 }
 std::atomic<int> g_ey_no_tail{0};  // ey_debug_set_variant bit 6: the last layer as separate launches (A/B, tests)
 
