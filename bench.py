@@ -285,7 +285,7 @@ def main():
                 line["roofline"]["traffic"] = ((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024.0 * ipl
                                                / pm.get("iterations_per_launch", 1))
                 line["roofline"]["traffic_source"] = pm.get("source", "profiles/pmc_latest.json")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 figure (the other ranks would wait for it)
             line["cpu_baseline"] = cpu_baseline(xs, ys, sigma)
             line["cpu_baseline"]["reference_faithful"] = cpu_reference_faithful(xs, ys, sigma)
         print(json.dumps(line), flush=True)
