@@ -196,42 +196,48 @@ __device__ __forceinline__ float l_tanh_fast(float g) {
   return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * g)) - 1.0f;
 }
 // activation / derivative over a small register array with the switch OUTSIDE the element loop
-template <int n>
-__device__ __forceinline__ void act_vec(int code, float (&v)[n]) {
-  switch (code) {
-    case EY_ACT_SIGMOID:
+template <int n, class T>
+__device__ __forceinline__ void act_vec(int code, T (&v)[n]) {
+  if constexpr (sizeof(T) == 4) {
+    switch (code) {
+      case EY_ACT_SIGMOID:
 #pragma unroll
-      for (int i = 0; i < n; ++i) v[i] = l_sigmoid_fast(v[i]);
-      break;
-    case EY_ACT_TANH:
+        for (int i = 0; i < n; ++i) v[i] = l_sigmoid_fast(v[i]);
+        break;
+      case EY_ACT_TANH:
 #pragma unroll
-      for (int i = 0; i < n; ++i) v[i] = l_tanh_fast(v[i]);
-      break;
-    case EY_ACT_RELU:
+        for (int i = 0; i < n; ++i) v[i] = l_tanh_fast(v[i]);
+        break;
+      case EY_ACT_RELU:
 #pragma unroll
-      for (int i = 0; i < n; ++i) v[i] = fmaxf(v[i], 0.0f);
-      break;
-    default: break;
+        for (int i = 0; i < n; ++i) v[i] = fmaxf(v[i], 0.0f);
+        break;
+      default: break;
+    }
+  } else {
+    if (code == EY_ACT_NONE) return;
+#pragma unroll
+    for (int i = 0; i < n; ++i) v[i] = l_act(code, v[i]);
   }
 }
-template <int n>
-__device__ __forceinline__ void dact_vec(int code, const float (&h)[n], float (&o)[n]) {
+template <int n, class T>
+__device__ __forceinline__ void dact_vec(int code, const T (&h)[n], T (&o)[n]) {
   switch (code) {
     case EY_ACT_SIGMOID:
 #pragma unroll
-      for (int i = 0; i < n; ++i) o[i] = h[i] * (1.0f - h[i]);
+      for (int i = 0; i < n; ++i) o[i] = h[i] * (T(1) - h[i]);
       break;
     case EY_ACT_TANH:
 #pragma unroll
-      for (int i = 0; i < n; ++i) o[i] = 1.0f - h[i] * h[i];
+      for (int i = 0; i < n; ++i) o[i] = T(1) - h[i] * h[i];
       break;
     case EY_ACT_RELU:
 #pragma unroll
-      for (int i = 0; i < n; ++i) o[i] = h[i] > 0.0f ? 1.0f : 0.0f;
+      for (int i = 0; i < n; ++i) o[i] = h[i] > T(0) ? T(1) : T(0);
       break;
     default:
 #pragma unroll
-      for (int i = 0; i < n; ++i) o[i] = 1.0f;
+      for (int i = 0; i < n; ++i) o[i] = T(1);
   }
 }
 #define EPI_AT(base, byte_off) (*(decltype(base))((const char*)(base) + (byte_off)))
@@ -659,52 +665,56 @@ static bool dma_ok(const BG& g, bool& kfast) {
 // with K = d_0 (tabular data: Iris has 4 features).  One thread per four consecutive outputs of a row; the chain's
 // K x N operand is staged in LDS (whatever its strides), the row's K values of A come through the scalar path.
 #define DH_ROWS 128  // rows per workgroup (the staged operand is reused across them)
-template <bool FWD>
-__global__ void __launch_bounds__(256) k_smallk(BG g) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [K][N] (+ [N] bias)
+template <class T>
+struct alignas(16) Vec4 { T x, y, z, w; };
+template <class T, bool FWD>
+__global__ void __launch_bounds__(256) k_smallk(BGT<T> g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm_raw[];
+  T* wsm = reinterpret_cast<T*>(wsm_raw);  // [K][N] (+ [N] bias)
   const long b = blockIdx.z;
-  const float* A = g.A + b * g.bA;
-  const float* B = g.B + b * g.bB;
-  float* C = g.C + b * g.bC;
+  const T* A = g.A + b * g.bA;
+  const T* B = g.B + b * g.bB;
+  T* C = g.C + b * g.bC;
   const int N4 = g.N >> 2;
   for (int i = threadIdx.x; i < g.K * g.N; i += 256) {
     const int k = i / g.N, n = i - k * g.N;
     wsm[i] = B[(long)k * g.sBk + (long)n * g.sBn];
   }
-  float* bsm = wsm + g.K * g.N;
+  T* bsm = wsm + g.K * g.N;
   if (FWD)
-    for (int i = threadIdx.x; i < g.N; i += 256) bsm[i] = g.bias ? g.bias[b * g.bBias + i] : 0.0f;
+    for (int i = threadIdx.x; i < g.N; i += 256) bsm[i] = g.bias ? g.bias[b * g.bBias + i] : T(0);
   __syncthreads();
   const int rows_per_pass = 256 / N4;
   const int n = (threadIdx.x % N4) * 4;
   if (threadIdx.x >= rows_per_pass * N4) return;
   const int m_end = min(g.M, ((int)blockIdx.x + 1) * DH_ROWS);
   for (int m = blockIdx.x * DH_ROWS + threadIdx.x / N4; m < m_end; m += rows_per_pass) {
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    T acc[4] = {T(0), T(0), T(0), T(0)};
     for (int k = 0; k < g.K; ++k) {
-      const float a = A[(long)m * g.sAm + k];
-      const float4 w = *reinterpret_cast<const float4*>(wsm + k * g.N + n);
+      const T a = A[(long)m * g.sAm + k];
+      const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(wsm + k * g.N + n);
       acc[0] += a * w.x; acc[1] += a * w.y; acc[2] += a * w.z; acc[3] += a * w.w;
     }
     if (FWD) {
-      const float4 bv = *reinterpret_cast<const float4*>(bsm + n);
+      const Vec4<T> bv = *reinterpret_cast<const Vec4<T>*>(bsm + n);
       acc[0] += bv.x; acc[1] += bv.y; acc[2] += bv.z; acc[3] += bv.w;
       act_vec<4>(g.act, acc);
     } else {
-      const float4 hv = *reinterpret_cast<const float4*>(g.Hm + b * g.bH + (long)m * g.sHm + n);
-      const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
-      float da[4];
+      const Vec4<T> hv = *reinterpret_cast<const Vec4<T>*>(g.Hm + b * g.bH + (long)m * g.sHm + n);
+      const T hh[4] = {hv.x, hv.y, hv.z, hv.w};
+      T da[4];
       dact_vec<4>(g.act_h, hh, da);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] *= da[j];
     }
-    *reinterpret_cast<float4*>(C + (long)m * g.sCm + n) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<Vec4<T>*>(C + (long)m * g.sCm + n) = Vec4<T>{acc[0], acc[1], acc[2], acc[3]};
   }
 }
 // 0 = not this kernel's product, 1 = input gradient, 2 = forward
-static int smallk_kind(const BG& g) {
+template <class T>
+static int smallk_kind(const BGT<T>& g) {
   if (g.pr_theta || g.rowsum || g.K > 16 || g.N % 4 != 0 || g.N < 4 || g.N > 1024 || g.sAk != 1 || g.sCn != 1 ||
-      g.sCm % 4 != 0 || g.bC % 4 != 0 || ((uintptr_t)g.C & 15) != 0 || (size_t)(g.K + 1) * g.N * 4 > 48 * 1024)
+      g.sCm % 4 != 0 || g.bC % 4 != 0 || ((uintptr_t)g.C & 15) != 0 || (size_t)(g.K + 1) * g.N * sizeof(T) > 48 * 1024)
     return 0;
   if (g.Hm) {
     if (g.bias || g.sHn != 1 || g.sHm % 4 != 0 || g.bH % 4 != 0 || ((uintptr_t)g.Hm & 15) != 0) return 0;
@@ -721,42 +731,43 @@ static int smallk_kind(const BG& g) {
 // gradient (the sum of delta over rows), prior gradient, temperature and, when asked, the leapfrog update with the
 // workgroup's partial prior sum in ONE slot.
 #define DWN_XROWS 64
-__global__ void __launch_bounds__(256) k_dw_smalln(BG g) {
-  __shared__ __attribute__((aligned(16))) float xs[DWN_XROWS * 16];
-  __shared__ float part[256 * 17];  // [grp][m][N + 1], reused for the reduction of q
+template <class T>
+__global__ void __launch_bounds__(256) k_dw_smalln(BGT<T> g) {
+  __shared__ __attribute__((aligned(16))) T xs[DWN_XROWS * 16];
+  __shared__ T part[256 * 17];  // [grp][m][N + 1], reused for the reduction of q
   const int tid = threadIdx.x;
   const long b = blockIdx.x;
   const int M = g.M, N = g.N, K = g.K;
   const int Mp = (M + 63) & ~63, G = 256 / Mp;
   const int m = tid % Mp, grp = tid / Mp;
   const bool live = m < M && grp < G;
-  const float* A = g.A + b * g.bA;   // delta: [k][m], m contiguous
-  const float* B = g.B + b * g.bB;   // X: [k][n], n contiguous
-  float acc[16], rs = 0.0f;
+  const T* A = g.A + b * g.bA;   // delta: [k][m], m contiguous
+  const T* B = g.B + b * g.bB;   // X: [k][n], n contiguous
+  T acc[16], rs = T(0.0);
 #pragma unroll
-  for (int n = 0; n < 16; ++n) acc[n] = 0.0f;
+  for (int n = 0; n < 16; ++n) acc[n] = T(0.0);
   for (int k0 = 0; k0 < K; k0 += DWN_XROWS) {
     const int kn = min(DWN_XROWS, K - k0);
     __syncthreads();
     for (int i = tid; i < kn * 16; i += 256) {
       const int kk = i >> 4, n = i & 15;
-      xs[i] = n < N ? B[(long)(k0 + kk) * g.sBk + n] : 0.0f;
+      xs[i] = n < N ? B[(long)(k0 + kk) * g.sBk + n] : T(0.0);
     }
     __syncthreads();
     if (live) {
       // eight rows' delta values are fetched before any is used: the loop is bound by the latency of these loads
       for (int kk = grp; kk < kn; kk += 8 * G) {
-        float a[8];
+        T a[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = kk + u * G < kn ? A[(long)(k0 + kk + u * G) * g.sAk + m] : 0.0f;
+        for (int u = 0; u < 8; ++u) a[u] = kk + u * G < kn ? A[(long)(k0 + kk + u * G) * g.sAk + m] : T(0.0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           if (kk + u * G >= kn) break;
           rs += a[u];
-          const float4* xr = reinterpret_cast<const float4*>(xs + (kk + u * G) * 16);
+          const Vec4<T>* xr = reinterpret_cast<const Vec4<T>*>(xs + (kk + u * G) * 16);
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const float4 xv = xr[v];
+            const Vec4<T> xv = xr[v];
             acc[4 * v] += a[u] * xv.x; acc[4 * v + 1] += a[u] * xv.y; acc[4 * v + 2] += a[u] * xv.z;
             acc[4 * v + 3] += a[u] * xv.w;
           }
@@ -772,37 +783,37 @@ __global__ void __launch_bounds__(256) k_dw_smalln(BG g) {
   }
   __syncthreads();
   // ---- epilogue: thread e handles output element e of the M x N block, then the M bias elements
-  const float tscale = g.pr_temp ? g.pr_temp[b] : 1.0f;
+  const T tscale = g.pr_temp ? g.pr_temp[b] : T(1.0);
   const bool fuse = g.lf_p != nullptr;
-  const float eps = fuse ? (g.lf_step_vec ? g.lf_step_vec[b] : g.lf_step) : 0.0f;
-  const float ep = g.lf_wp * eps, et = g.lf_wt * eps;
-  float q = 0.0f;
-  auto emit = [&](float v, float* gout, float* theta, float* pmom, const float* mu, const float* iv) {
-    const float m_ = *mu, i_ = *iv;
-    float tv = *theta;
-    const float gv = (v - (tv - m_) * i_) * tscale;
+  const T eps = fuse ? (g.lf_step_vec ? g.lf_step_vec[b] : g.lf_step) : T(0.0);
+  const T ep = g.lf_wp * eps, et = g.lf_wt * eps;
+  T q = T(0.0);
+  auto emit = [&](T v, T* gout, T* theta, T* pmom, const T* mu, const T* iv) {
+    const T m_ = *mu, i_ = *iv;
+    T tv = *theta;
+    const T gv = (v - (tv - m_) * i_) * tscale;
     if (!fuse) { *gout = gv; return; }
     if (g.lf_store_g) *gout = gv;
-    const float pv = *pmom + ep * gv;
+    const T pv = *pmom + ep * gv;
     *pmom = pv;
-    if (g.lf_wt != 0.0f) { tv = tv + et * pv; *theta = tv; }
-    const float dd = tv - m_;
+    if (g.lf_wt != T(0.0)) { tv = tv + et * pv; *theta = tv; }
+    const T dd = tv - m_;
     q += dd * dd * i_;
   };
   for (int e = tid; e < M * N; e += 256) {
     const int mm = e / N, n = e - mm * N;
-    float v = 0.0f;
+    T v = T(0.0);
     for (int gg = 0; gg < G; ++gg) v += part[(gg * Mp + mm) * 17 + n];
     const long ci = (long)mm * g.sCm + n;
-    emit(v, g.C + b * g.bC + ci, const_cast<float*>(g.pr_theta) + b * g.bC + ci, fuse ? g.lf_p + b * g.bC + ci : nullptr,
+    emit(v, g.C + b * g.bC + ci, const_cast<T*>(g.pr_theta) + b * g.bC + ci, fuse ? g.lf_p + b * g.bC + ci : nullptr,
          g.pr_mu + ci, g.pr_iv + ci);
   }
   if (g.rowsum) {
     for (int mm = tid; mm < M; mm += 256) {
-      float v = 0.0f;
+      T v = T(0.0);
       for (int gg = 0; gg < G; ++gg) v += part[(gg * Mp + mm) * 17 + 16];
       if (g.pr_theta_b)
-        emit(v, g.rowsum + b * g.bRow + mm, const_cast<float*>(g.pr_theta_b) + b * g.bRow + mm,
+        emit(v, g.rowsum + b * g.bRow + mm, const_cast<T*>(g.pr_theta_b) + b * g.bRow + mm,
              fuse ? g.lf_p_b + b * g.bRow + mm : nullptr, g.pr_mu_b + mm, g.pr_iv_b + mm);
       else
         g.rowsum[b * g.bRow + mm] = v;
@@ -818,7 +829,8 @@ __global__ void __launch_bounds__(256) k_dw_smalln(BG g) {
   }
 }
 // a weight-gradient product (pr_theta set) of a layer with at most 16 inputs and 256 outputs, both operands row-major
-static bool dw_smalln_ok(const BG& g) {
+template <class T>
+static bool dw_smalln_ok(const BGT<T>& g) {
   return g.pr_theta && !g.Hm && !g.bias && g.N <= 16 && g.M <= 256 && g.sAm == 1 && g.sBn == 1 && g.sCn == 1 &&
          (!g.rowsum || g.pr_theta_b || !g.lf_p);
 }
@@ -830,25 +842,37 @@ static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry);
 // 32-wide kernel.
 // cursor: next free slot of the fused leapfrog update's partial sums (g.lf_p set), advanced by the blocks launched;
 // dry: only advance the cursor (the host sizes the slot buffer with the same dispatch logic it launches with).
-static int bgemm(const BG& g, int batch, hipStream_t s, int* cursor = nullptr, bool dry = false) {
+// the products that do not go through a matrix-core kernel (both dtypes); *handled says whether this was one
+template <class T>
+static int bgemm_narrow(const BGT<T>& g, int batch, hipStream_t s, int* cursor, bool dry, bool* handled) {
+  *handled = true;
   if (dw_smalln_ok(g)) {
-    BG h = g;
+    BGT<T> h = g;
     if (cursor && (g.lf_p || dry)) {
       h.lf_slot0 = *cursor;
       *cursor += 1;
       if (dry) return EY_OK;
     }
-    hipLaunchKernelGGL(k_dw_smalln, dim3(batch), dim3(256), 0, s, h);
+    hipLaunchKernelGGL((k_dw_smalln<T>), dim3(batch), dim3(256), 0, s, h);
     EY_HIP(hipGetLastError());
     return EY_OK;
   }
   if (const int kind = smallk_kind(g)) {
     const dim3 grid((g.M + DH_ROWS - 1) / DH_ROWS, 1, batch);
-    const size_t lds = (size_t)(g.K + 1) * g.N * sizeof(float);
-    if (kind == 1) hipLaunchKernelGGL(k_smallk<false>, grid, dim3(256), lds, s, g);
-    else hipLaunchKernelGGL(k_smallk<true>, grid, dim3(256), lds, s, g);
+    const size_t lds = (size_t)(g.K + 1) * g.N * sizeof(T);
+    if (kind == 1) hipLaunchKernelGGL((k_smallk<T, false>), grid, dim3(256), lds, s, g);
+    else hipLaunchKernelGGL((k_smallk<T, true>), grid, dim3(256), lds, s, g);
     EY_HIP(hipGetLastError());
     return EY_OK;
+  }
+  *handled = false;
+  return EY_OK;
+}
+static int bgemm(const BG& g, int batch, hipStream_t s, int* cursor = nullptr, bool dry = false) {
+  {
+    bool handled;
+    const int rc = bgemm_narrow(g, batch, s, cursor, dry, &handled);
+    if (handled) return rc;
   }
   const int rem = g.N % 128;
   if (g.M > 32 && g.N > 128 && rem > 0 && rem <= 32 && !g.bias && !g.Hm) {
@@ -1029,7 +1053,12 @@ __global__ void __launch_bounds__(256) k_bgemm_f64(BGT<double> g) {
     }
   }
 }
-static int bgemm(const BGT<double>& g, int batch, hipStream_t s, int* = nullptr, bool = false) {
+static int bgemm(const BGT<double>& g, int batch, hipStream_t s, int* cursor = nullptr, bool dry = false) {
+  {
+    bool handled;
+    const int rc = bgemm_narrow(g, batch, s, cursor, dry, &handled);
+    if (handled) return rc;
+  }
   dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, batch);
   hipLaunchKernelGGL(k_bgemm_f64, grid, dim3(256), 0, s, g);
   EY_HIP(hipGetLastError());
