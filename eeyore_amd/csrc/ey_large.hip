@@ -667,6 +667,8 @@ static bool dma_ok(const BG& g, bool& kfast) {
 #define DH_ROWS 128  // rows per workgroup (the staged operand is reused across them)
 template <class T>
 struct alignas(16) Vec4 { T x, y, z, w; };
+template <class T>
+struct alignas(8) Vec2 { T x, y; };
 template <class T, bool FWD>
 __global__ void __launch_bounds__(256) k_smallk(BGT<T> g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm_raw[];
@@ -1292,14 +1294,15 @@ bool ey_large_needed(const ey_plan* pl, int nvec) {
 // order (slots inside a wave, then waves): reproducible.
 #define TAIL_DK 10
 #define TAIL_PF 3
-struct TailArgs {
-  const float* H; float* Dout; const float* theta; float* grad; const float* mu; const float* iv;
-  const float* y; const int* labels; const float* temp; float* lik_o; float* rows_o;
+template <class T>
+struct TailArgsT {
+  const T* H; T* Dout; const T* theta; T* grad; const T* mu; const T* iv;
+  const T* y; const int* labels; const T* temp; T* lik_o; T* rows_o;
   long P; int woff, boff, N, d, dK, lik, act_last, act_prev, rows_temp;
   // the leapfrog update fused into the gradient write-out, as BGT's lf_* (the workgroup's slot is lf_slot0)
-  float *lf_p, *lf_q;
-  const float* lf_step_vec;
-  float lf_step, lf_wp, lf_wt;
+  T *lf_p, *lf_q;
+  const T* lf_step_vec;
+  T lf_step, lf_wp, lf_wt;
   int lf_slot0, lf_nslots, lf_store_g;
 };
 __device__ __forceinline__ float l_act_fast(int code, float g) {
@@ -1319,60 +1322,72 @@ __device__ __forceinline__ float row16_sum(float v) {
   v = dpp_add<0x128>(v); v = dpp_add<0x124>(v); v = dpp_add<0x122>(v); v = dpp_add<0x121>(v);
   return v;
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {  // the two halves of the rotated value move separately
+  const long long bits = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, true);
+  return v + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v = dpp_add<0x128>(v); v = dpp_add<0x124>(v); v = dpp_add<0x122>(v); v = dpp_add<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ double l_act_fast(int code, double g) { return l_act(code, g); }
 // `room` = how many of this lane's F features exist (d - F q: the layer may be narrower than the 16 F the lanes span;
 // its width is a multiple of the vector piece -- 4, 2 or 1 floats -- so a piece is whole or absent)
-template <int F>
-__device__ __forceinline__ void tail_load(const float* p, bool ok, int room, float (&h)[F]) {
+template <int F, class T>
+__device__ __forceinline__ void tail_load(const T* p, bool ok, int room, T (&h)[F]) {
 #pragma unroll
-  for (int f = 0; f < F; ++f) h[f] = 0.0f;
+  for (int f = 0; f < F; ++f) h[f] = T(0.0);
   if (!ok) return;
   if constexpr (F >= 4) {
 #pragma unroll
     for (int f = 0; f < F; f += 4) {
       if (f < room) {
-        const float4 v = *reinterpret_cast<const float4*>(p + f);
+        const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(p + f);
         h[f] = v.x; h[f + 1] = v.y; h[f + 2] = v.z; h[f + 3] = v.w;
       }
     }
   } else if constexpr (F == 2) {
     if (room > 0) {
-      const float2 v = *reinterpret_cast<const float2*>(p);
+      const Vec2<T> v = *reinterpret_cast<const Vec2<T>*>(p);
       h[0] = v.x; h[1] = v.y;
     }
   } else {
     if (room > 0) h[0] = p[0];
   }
 }
-template <int F>
-__device__ __forceinline__ void tail_store(float* p, int room, const float (&h)[F]) {
+template <int F, class T>
+__device__ __forceinline__ void tail_store(T* p, int room, const T (&h)[F]) {
   if constexpr (F >= 4) {
 #pragma unroll
     for (int f = 0; f < F; f += 4)
-      if (f < room) *reinterpret_cast<float4*>(p + f) = make_float4(h[f], h[f + 1], h[f + 2], h[f + 3]);
+      if (f < room) *reinterpret_cast<Vec4<T>*>(p + f) = Vec4<T>{h[f], h[f + 1], h[f + 2], h[f + 3]};
   } else if constexpr (F == 2) {
-    if (room > 0) *reinterpret_cast<float2*>(p) = make_float2(h[0], h[1]);
+    if (room > 0) *reinterpret_cast<Vec2<T>*>(p) = Vec2<T>{h[0], h[1]};
   } else {
     if (room > 0) p[0] = h[0];
   }
 }
-template <int F, int WS>
-__device__ __forceinline__ void tail_wrow(const float* wl, int j, int q, float (&w)[F]) {
+template <int F, int WS, class T>
+__device__ __forceinline__ void tail_wrow(const T* wl, int j, int q, T (&w)[F]) {
   if constexpr (F >= 4) {
 #pragma unroll
     for (int p = 0; p < F / 4; ++p) {
-      const float4 v = *reinterpret_cast<const float4*>(wl + (p * TAIL_DK + j) * WS + 4 * q);
+      const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(wl + (p * TAIL_DK + j) * WS + 4 * q);
       w[4 * p] = v.x; w[4 * p + 1] = v.y; w[4 * p + 2] = v.z; w[4 * p + 3] = v.w;
     }
   } else if constexpr (F == 2) {
-    const float2 v = *reinterpret_cast<const float2*>(wl + j * WS + 2 * q);
+    const Vec2<T> v = *reinterpret_cast<const Vec2<T>*>(wl + j * WS + 2 * q);
     w[0] = v.x; w[1] = v.y;
   } else {
     w[0] = wl[j * WS + q];
   }
 }
 // sum over the LPR lanes of a row, result in every lane of the row
-template <int LPR>
-__device__ __forceinline__ float row_sum(float v) {
+template <int LPR, class T>
+__device__ __forceinline__ T row_sum(T v) {
   v = row16_sum(v);
   if (LPR == 32) v += __shfl_xor(v, 16, 64);
   return v;
@@ -1380,41 +1395,41 @@ __device__ __forceinline__ float row_sum(float v) {
 // LPR lanes per row, RPP = 256 / LPR rows per pass.  LPR = 16 is what runs: for d > 64 that means 8 features per lane, 80
 // accumulators and two waves per SIMD; the alternative (32 lanes x 4 features, three waves per SIMD) measured 5-10 %
 // slower -- the loss is computed redundantly by every lane of a row and the row sums cross a DPP row boundary.
-template <int F, int LPR, bool GRAD>
-__global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
+template <class T, int F, int LPR, bool GRAD>
+__global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(TailArgsT<T> a) {
   constexpr int RPP = 256 / LPR, WS = LPR * 4;  // rows per pass; floats per row of a W plane
-  __shared__ float red[4][TAIL_DK * LPR * F];
-  __shared__ __attribute__((aligned(16))) float wl[(F >= 4 ? F / 4 : 1) * TAIL_DK * WS];
-  __shared__ float redb[4][TAIL_DK];
-  __shared__ float redl[4];
+  __shared__ T red[4][TAIL_DK * LPR * F];
+  __shared__ __attribute__((aligned(16))) T wl[(F >= 4 ? F / 4 : 1) * TAIL_DK * WS];
+  __shared__ T redb[4][TAIL_DK];
+  __shared__ T redl[4];
   const int tid = threadIdx.x, q = tid & (LPR - 1), rs = tid / LPR, wave = tid >> 6, lane = tid & 63;
   const long c = blockIdx.x;
   const int N = a.N, d = a.d, dK = a.dK;
-  const float* Hc = a.H + c * (long)N * d + F * q;
+  const T* Hc = a.H + c * (long)N * d + F * q;
   const int room = d - F * q;  // this lane's features that exist
-  const float* th = a.theta + c * a.P;
+  const T* th = a.theta + c * a.P;
   // W_{K-1} in LDS (rows beyond d_K zero), laid out so that the 16 lanes of a row read consecutive 16-byte pieces:
   // plane p holds features F q + 4 p .. + 3 of lane q.  (In registers it would cost 10 F of them next to the 10 F
   // accumulators; the reads are broadcasts over the wave's four rows and cost a few LDS cycles per pass.)
   for (int idx = tid; idx < TAIL_DK * LPR * F; idx += 256) {
     const int j = idx / (LPR * F), i = idx - j * (LPR * F), qq = i / F, f = i - qq * F;
     const int dst = F >= 4 ? ((f >> 2) * TAIL_DK + j) * WS + 4 * qq + (f & 3) : j * WS + F * qq + f;
-    wl[dst] = (j < dK && i < d) ? th[a.woff + j * d + i] : 0.0f;
+    wl[dst] = (j < dK && i < d) ? th[a.woff + j * d + i] : T(0.0);
   }
-  float bias[TAIL_DK];
+  T bias[TAIL_DK];
 #pragma unroll
-  for (int j = 0; j < TAIL_DK; ++j) bias[j] = (j < dK && a.boff >= 0) ? th[a.boff + j] : 0.0f;
+  for (int j = 0; j < TAIL_DK; ++j) bias[j] = (j < dK && a.boff >= 0) ? th[a.boff + j] : T(0.0);
   __syncthreads();
-  float acc[TAIL_DK][F], dbq = 0.0f;  // dbq: lane q of a row keeps the bias-gradient sum of output q (one register, not d_K)
+  T acc[TAIL_DK][F], dbq = T(0.0);  // dbq: lane q of a row keeps the bias-gradient sum of output q (one register, not d_K)
 #pragma unroll
   for (int j = 0; j < TAIL_DK; ++j) {
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[j][f] = 0.0f;
+    for (int f = 0; f < F; ++f) acc[j][f] = T(0.0);
   }
-  float lik = 0.0f;
-  const float rowscale = a.rows_temp && a.temp ? a.temp[c] : 1.0f;
+  T lik = T(0.0);
+  const T rowscale = a.rows_temp && a.temp ? a.temp[c] : T(1.0);
   const int passes = (N + RPP - 1) / RPP;
-  float hb[TAIL_PF][F];
+  T hb[TAIL_PF][F];
 #pragma unroll
   for (int u = 0; u < TAIL_PF; ++u) {
     const int n = RPP * u + rs;
@@ -1427,7 +1442,7 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
       if (t >= passes) break;  // uniform
       const int n = RPP * t + rs;
       const bool live = n < N;
-      float h[F];
+      T h[F];
 #pragma unroll
       for (int f = 0; f < F; ++f) h[f] = hb[u][f];
       int qv = q;  // opaque per pass: keeps the W reads below in the loop (hoisted, they would occupy 10 F registers)
@@ -1438,10 +1453,10 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
       }
       // logits: partial dot products over this lane's features, combined over the row's 16 lanes; rows of W beyond d_K
       // are zero.  The activation switches sit OUTSIDE the element loops (one uniform branch per pass, not per element).
-      float z[TAIL_DK], da[TAIL_DK];
+      T z[TAIL_DK], da[TAIL_DK];
 #pragma unroll
       for (int j = 0; j < TAIL_DK; ++j) {
-        float wj[F], pz = 0.0f;
+        T wj[F], pz = T(0.0);
         tail_wrow<F, WS>(wl, j, qv, wj);
 #pragma unroll
         for (int f = 0; f < F; ++f) pz += h[f] * wj[f];
@@ -1450,47 +1465,47 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
       act_vec<TAIL_DK>(a.act_last, z);
       dact_vec<TAIL_DK>(a.act_last, z, da);
       // the row's loss term and dL/dz (same arithmetic as k_loss), in every lane of the row
-      float row = 0.0f, dl[TAIL_DK];
+      T row = T(0.0), dl[TAIL_DK];
       if (a.lik == EY_LIK_BCE_SUM) {
 #pragma unroll
         for (int j = 0; j < TAIL_DK; ++j) {
-          dl[j] = 0.0f;
+          dl[j] = T(0.0);
           if (j < dK && live) {
-            const float p = z[j], yy = a.y[(long)n * dK + j];
-            row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
-            dl[j] = (yy / p - (1.0f - yy) / (1.0f - p)) * da[j];
+            const T p = z[j], yy = a.y[(long)n * dK + j];
+            row += l_log(p) * yy + l_log(T(1.0) - p) * (T(1.0) - yy);  // naive logs (eeyore/stats/loss.py:2)
+            dl[j] = (yy / p - (T(1.0) - yy) / (T(1.0) - p)) * da[j];
           }
         }
       } else {
         const int lab = live ? a.labels[n] : 0;
-        float mx = z[0];
+        T mx = z[0];
 #pragma unroll
-        for (int j = 1; j < TAIL_DK; ++j) mx = j < dK ? fmaxf(mx, z[j]) : mx;
-        float e[TAIL_DK], ssum = 0.0f, zlab = 0.0f;
+        for (int j = 1; j < TAIL_DK; ++j) mx = j < dK ? l_max(mx, z[j]) : mx;
+        T e[TAIL_DK], ssum = T(0.0), zlab = T(0.0);
 #pragma unroll
         for (int j = 0; j < TAIL_DK; ++j) {
-          e[j] = j < dK ? __expf(z[j] - mx) : 0.0f;
+          e[j] = j < dK ? l_exp(z[j] - mx) : T(0.0);
           ssum += e[j];
           zlab = j == lab ? z[j] : zlab;
         }
-        row = zlab - (mx + __logf(ssum));
-        const float rsum = live ? 1.0f / ssum : 0.0f;
+        row = zlab - (mx + l_log(ssum));
+        const T rsum = live ? T(1.0) / ssum : T(0.0);
 #pragma unroll
-        for (int j = 0; j < TAIL_DK; ++j) dl[j] = ((j == lab && live ? 1.0f : 0.0f) - e[j] * rsum) * da[j];
+        for (int j = 0; j < TAIL_DK; ++j) dl[j] = ((j == lab && live ? T(1.0) : T(0.0)) - e[j] * rsum) * da[j];
       }
       if (live) {
         lik += row;
         if (a.rows_o && q == 0) a.rows_o[c * (long)N + n] = row * rowscale;
       }
       if (GRAD) {
-        float dh[F];
+        T dh[F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) dh[f] = 0.0f;
+        for (int f = 0; f < F; ++f) dh[f] = T(0.0);
 #pragma unroll
         for (int j = 0; j < TAIL_DK; ++j) {
-          float wj[F];
+          T wj[F];
           tail_wrow<F, WS>(wl, j, qv, wj);
-          dbq += j == q ? dl[j] : 0.0f;
+          dbq += j == q ? dl[j] : T(0.0);
 #pragma unroll
           for (int f = 0; f < F; ++f) {
             acc[j][f] += dl[j] * h[f];
@@ -1498,7 +1513,7 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
           }
         }
         if (a.Dout && live) {
-          float dp[F];
+          T dp[F];
           dact_vec<F>(a.act_prev, h, dp);
 #pragma unroll
           for (int f = 0; f < F; ++f) dh[f] *= dp[f];
@@ -1508,13 +1523,13 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
     }
   }
   // ---- reductions over rows: slots of a wave (lane bits 4, 5), then the four waves, in that order
-  float lv = q == 0 ? lik : 0.0f;
+  T lv = q == 0 ? lik : T(0.0);
   if (LPR == 16) lv += __shfl_xor(lv, 16, 64);
   lv += __shfl_xor(lv, 32, 64);
   if (lane == 0) redl[wave] = lv;
   if (GRAD) {
     {
-      float b = dbq;  // lanes q, q + 16, q + 32, q + 48: the wave's four rows
+      T b = dbq;  // lanes q, q + 16, q + 32, q + 48: the wave's four rows
       if (LPR == 16) b += __shfl_xor(b, 16, 64);
       b += __shfl_xor(b, 32, 64);
       if (lane < TAIL_DK) redb[wave][lane] = b;
@@ -1523,7 +1538,7 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
     for (int j = 0; j < TAIL_DK; ++j) {
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        float v = acc[j][f];
+        T v = acc[j][f];
         if (LPR == 16) v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (lane < LPR) red[wave][j * (LPR * F) + F * q + f] = v;
@@ -1533,26 +1548,26 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
   __syncthreads();
   if (tid == 0) a.lik_o[c] = ((redl[0] + redl[1]) + redl[2]) + redl[3];
   if (GRAD) {
-    const float tscale = a.temp ? a.temp[c] : 1.0f;
-    float* gc = a.grad + c * a.P;
+    const T tscale = a.temp ? a.temp[c] : T(1.0);
+    T* gc = a.grad + c * a.P;
     const bool fuse = a.lf_p != nullptr;
-    float* thw = const_cast<float*>(th);
-    float* pc = fuse ? a.lf_p + c * a.P : nullptr;
-    const float eps = fuse ? (a.lf_step_vec ? a.lf_step_vec[c] : a.lf_step) : 0.0f;
-    const float ep = a.lf_wp * eps, et = a.lf_wt * eps;
-    float q = 0.0f;
+    T* thw = const_cast<T*>(th);
+    T* pc = fuse ? a.lf_p + c * a.P : nullptr;
+    const T eps = fuse ? (a.lf_step_vec ? a.lf_step_vec[c] : a.lf_step) : T(0.0);
+    const T ep = a.lf_wp * eps, et = a.lf_wt * eps;
+    T q = T(0.0);
     // one gradient element: the prior term and the temperature; with the leapfrog update fused in (see BGT) the
     // momentum and the position of the element move here and q collects the new position's prior quadratic form
-    auto emit = [&](int k, float v) {
-      const float m_ = a.mu[k], i_ = a.iv[k];
-      float tv = th[k];
-      const float gv = (v - (tv - m_) * i_) * tscale;
+    auto emit = [&](int k, T v) {
+      const T m_ = a.mu[k], i_ = a.iv[k];
+      T tv = th[k];
+      const T gv = (v - (tv - m_) * i_) * tscale;
       if (!fuse) { gc[k] = gv; return; }
       if (a.lf_store_g) gc[k] = gv;
-      const float pv = pc[k] + ep * gv;
+      const T pv = pc[k] + ep * gv;
       pc[k] = pv;
-      if (a.lf_wt != 0.0f) { tv = tv + et * pv; thw[k] = tv; }
-      const float dd = tv - m_;
+      if (a.lf_wt != T(0.0)) { tv = tv + et * pv; thw[k] = tv; }
+      const T dd = tv - m_;
       q += dd * dd * i_;
     };
     for (int e = tid; e < dK * d; e += 256) {
@@ -1562,7 +1577,7 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
     }
     if (a.boff >= 0 && tid < dK) emit(a.boff + tid, ((redb[0][tid] + redb[1][tid]) + redb[2][tid]) + redb[3][tid]);
     if (fuse) {  // uniform over the workgroup
-      __shared__ float redq[4];
+      __shared__ T redq[4];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
       if (lane == 0) redq[wave] = q;
@@ -1572,19 +1587,20 @@ __global__ void __launch_bounds__(256, F == 8 ? 2 : 3) k_tail(TailArgs a) {
   }
 }
 // d_{K-1} <= 128 and a multiple of the lanes' vector piece: the 16 lanes of a row span 16 F >= d features
-static int tail_f(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 64 ? 4 : 8)); }  // features per lane, 16 lanes per row
+// (f64 beyond d = 64 takes 32 lanes x 4 features per row: eight doubles per lane would be 160 accumulator registers)
+static int tail_f(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : 4); }  // vector piece: features that must come whole
 static bool tail_ok(const EyModel& m) {
   const int K = m.nl, d = m.dims[K - 1];
   if (K < 2 || m.dims[K] > TAIL_DK || d < 1 || d > 128) return false;
-  const int F = tail_f(d);
-  return d % (F >= 4 ? 4 : F) == 0;
+  return d % tail_f(d) == 0;
 }
-template <bool GRAD>
-static void tail_launch(const TailArgs& a, int C, hipStream_t s) {
-  if (a.d <= 16) hipLaunchKernelGGL((k_tail<1, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
-  else if (a.d <= 32) hipLaunchKernelGGL((k_tail<2, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
-  else if (a.d <= 64) hipLaunchKernelGGL((k_tail<4, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_tail<8, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
+template <class T, bool GRAD>
+static void tail_launch(const TailArgsT<T>& a, int C, hipStream_t s) {
+  if (a.d <= 16) hipLaunchKernelGGL((k_tail<T, 1, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
+  else if (a.d <= 32) hipLaunchKernelGGL((k_tail<T, 2, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
+  else if (a.d <= 64) hipLaunchKernelGGL((k_tail<T, 4, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
+  else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_tail<T, 8, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_tail<T, 4, 32, GRAD>), dim3(C), dim3(256), 0, s, a);
 }
 std::atomic<int> g_ey_no_tail{0};  // ey_debug_set_variant bit 6: the last layer as separate launches (A/B, tests)
 
@@ -1655,6 +1671,8 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
     }
   }
   int rc, cursor = 0;
+  // f32 only: in f64 the fused kernel measured SLOWER than the separate launches (every lane of a row repeats the
+  // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
   const bool tail = sizeof(T) == 4 && tail_ok(m) && !g_ey_no_tail.load();
   for (int l = 0; l < (tail ? K - 1 : K); ++l) {
     BGT<T> g = {};
@@ -1669,9 +1687,9 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
     g.act = m.act[l];
     if ((rc = bgemm(g, C, s))) return rc;
   }
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (sizeof(T) == 4) {  // (the kernel is written for both types; only float is instantiated, see above)
     if (tail) {
-      TailArgs t = {};
+      TailArgsT<T> t = {};
       t.H = H[K - 1]; t.Dout = grad ? D[K - 1] : nullptr; t.theta = theta; t.grad = grad;
       t.mu = (const T*)m.mu; t.iv = (const T*)m.inv_var; t.y = (const T*)m.y; t.labels = m.labels;
       t.temp = temp; t.lik_o = lik_tmp; t.rows_o = rows_o; t.P = P; t.woff = m.woff[K - 1]; t.boff = m.boff[K - 1];
@@ -1681,8 +1699,8 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
         t.lf_p = lf->p; t.lf_q = lf->q_out; t.lf_step_vec = lf->step_vec; t.lf_step = lf->step; t.lf_wp = lf->wp;
         t.lf_wt = lf->wt; t.lf_slot0 = cursor++; t.lf_nslots = lf->nslots; t.lf_store_g = lf->store_g;
       }
-      if (grad) tail_launch<true>(t, C, s);
-      else tail_launch<false>(t, C, s);
+      if (grad) tail_launch<T, true>(t, C, s);
+      else tail_launch<T, false>(t, C, s);
     }
   }
   if (!tail)
@@ -1776,6 +1794,8 @@ static int large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const v
   // of the prior quadratic form (one being read by the evaluation at theta_k while its epilogues fill the other for
   // theta_{k+1})
   const int nblk = leap_blocks(P);
+  // f32 only: in f64 the fused kernel measured SLOWER than the separate launches (every lane of a row repeats the
+  // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
   const bool tail = sizeof(T) == 4 && tail_ok(m) && !g_ey_no_tail.load();
   const bool fuse = sizeof(T) == 4 && !g_ey_no_fuse.load();
   const int nslots = fuse ? leap_fuse_slots(m, tail) : 0;
