@@ -683,17 +683,23 @@ __global__ void __launch_bounds__(256) k_smallk(BGT<T> g) {
     wsm[i] = B[(long)k * g.sBk + (long)n * g.sBn];
   }
   T* bsm = wsm + g.K * g.N;
+  T* asm_ = bsm + g.N;  // the workgroup's DH_ROWS rows of A, [row][K]: the inner loop then waits for LDS, not for memory
   if (FWD)
     for (int i = threadIdx.x; i < g.N; i += 256) bsm[i] = g.bias ? g.bias[b * g.bBias + i] : T(0);
+  const int m_lo = blockIdx.x * DH_ROWS, m_end = min(g.M, m_lo + DH_ROWS);
+  for (int i = threadIdx.x; i < (m_end - m_lo) * g.K; i += 256) {
+    const int r = i / g.K, k = i - r * g.K;
+    asm_[i] = A[(long)(m_lo + r) * g.sAm + k];
+  }
   __syncthreads();
   const int rows_per_pass = 256 / N4;
   const int n = (threadIdx.x % N4) * 4;
   if (threadIdx.x >= rows_per_pass * N4) return;
-  const int m_end = min(g.M, ((int)blockIdx.x + 1) * DH_ROWS);
-  for (int m = blockIdx.x * DH_ROWS + threadIdx.x / N4; m < m_end; m += rows_per_pass) {
+  for (int m = m_lo + threadIdx.x / N4; m < m_end; m += rows_per_pass) {
     T acc[4] = {T(0), T(0), T(0), T(0)};
+    const T* ar = asm_ + (m - m_lo) * g.K;
     for (int k = 0; k < g.K; ++k) {
-      const T a = A[(long)m * g.sAm + k];
+      const T a = ar[k];
       const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(wsm + k * g.N + n);
       acc[0] += a * w.x; acc[1] += a * w.y; acc[2] += a * w.z; acc[3] += a * w.w;
     }
@@ -716,7 +722,7 @@ __global__ void __launch_bounds__(256) k_smallk(BGT<T> g) {
 template <class T>
 static int smallk_kind(const BGT<T>& g) {
   if (g.pr_theta || g.rowsum || g.K > 16 || g.N % 4 != 0 || g.N < 4 || g.N > 1024 || g.sAk != 1 || g.sCn != 1 ||
-      g.sCm % 4 != 0 || g.bC % 4 != 0 || ((uintptr_t)g.C & 15) != 0 || (size_t)(g.K + 1) * g.N * sizeof(T) > 48 * 1024)
+      g.sCm % 4 != 0 || g.bC % 4 != 0 || ((uintptr_t)g.C & 15) != 0 || ((size_t)(g.K + 1) * g.N + (size_t)DH_ROWS * g.K) * sizeof(T) > 48 * 1024)
     return 0;
   if (g.Hm) {
     if (g.bias || g.sHn != 1 || g.sHm % 4 != 0 || g.bH % 4 != 0 || ((uintptr_t)g.Hm & 15) != 0) return 0;
@@ -861,7 +867,7 @@ static int bgemm_narrow(const BGT<T>& g, int batch, hipStream_t s, int* cursor, 
   }
   if (const int kind = smallk_kind(g)) {
     const dim3 grid((g.M + DH_ROWS - 1) / DH_ROWS, 1, batch);
-    const size_t lds = (size_t)(g.K + 1) * g.N * sizeof(T);
+    const size_t lds = ((size_t)(g.K + 1) * g.N + (size_t)DH_ROWS * g.K) * sizeof(T);
     if (kind == 1) hipLaunchKernelGGL((k_smallk<T, false>), grid, dim3(256), lds, s, g);
     else hipLaunchKernelGGL((k_smallk<T, true>), grid, dim3(256), lds, s, g);
     EY_HIP(hipGetLastError());
