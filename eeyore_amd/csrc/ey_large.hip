@@ -1399,8 +1399,8 @@ __device__ __forceinline__ T row_sum(T v) {
   return v;
 }
 // LPR lanes per row, RPP = 256 / LPR rows per pass.  LPR = 16 is what runs: for d > 64 that means 8 features per lane, 80
-// accumulators and two waves per SIMD; the alternative (32 lanes x 4 features, three waves per SIMD) measured 5-10 %
-// slower -- the loss is computed redundantly by every lane of a row and the row sums cross a DPP row boundary.
+// accumulators and two waves per SIMD; the alternative (32 lanes x 4 features, three waves per SIMD, W in registers)
+// measured 2-6 % slower -- the loss is computed redundantly by every lane of a row and the row sums cross a DPP row.
 template <class T, int F, int LPR, bool GRAD>
 __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(TailArgsT<T> a) {
   constexpr int RPP = 256 / LPR, WS = LPR * 4;  // rows per pass; floats per row of a W plane
@@ -1451,8 +1451,11 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
       T h[F];
 #pragma unroll
       for (int f = 0; f < F; ++f) h[f] = hb[u][f];
-      int qv = q;  // opaque per pass: keeps the W reads below in the loop (hoisted, they would occupy 10 F registers)
-      asm volatile("" : "+v"(qv));
+      // eight features per lane: q is made opaque per pass to keep the W reads below in the loop (hoisted they would
+      // occupy 80 registers next to the 80 accumulators); with four or fewer the compiler hoists them, W lives in
+      // registers and the loop has no LDS traffic
+      int qv = q;
+      if constexpr (F * sizeof(T) >= 32) asm volatile("" : "+v"(qv));
       {  // refill this slot with the row TAIL_PF passes ahead
         const int n2 = n + RPP * TAIL_PF;
         tail_load<F>(Hc + (long)n2 * d, t + TAIL_PF < passes && n2 < N, room, hb[u]);
