@@ -1417,10 +1417,23 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
   // W_{K-1} in LDS (rows beyond d_K zero), laid out so that the 16 lanes of a row read consecutive 16-byte pieces:
   // plane p holds features F q + 4 p .. + 3 of lane q.  (In registers it would cost 10 F of them next to the 10 F
   // accumulators; the reads are broadcasts over the wave's four rows and cost a few LDS cycles per pass.)
-  for (int idx = tid; idx < TAIL_DK * LPR * F; idx += 256) {
-    const int j = idx / (LPR * F), i = idx - j * (LPR * F), qq = i / F, f = i - qq * F;
-    const int dst = F >= 4 ? ((f >> 2) * TAIL_DK + j) * WS + 4 * qq + (f & 3) : j * WS + F * qq + f;
-    wl[dst] = (j < dK && i < d) ? th[a.woff + j * d + i] : T(0.0);
+  {  // all of a thread's elements are fetched before any is stored: the loads overlap (this is per-chain latency)
+    constexpr int NW = (TAIL_DK * LPR * F + 255) / 256;
+    T wv[NW];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int idx = tid + 256 * u, j = idx / (LPR * F), i = idx - j * (LPR * F);
+      wv[u] = (idx < TAIL_DK * LPR * F && j < dK && i < d) ? th[a.woff + j * d + i] : T(0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < TAIL_DK * LPR * F) {
+        const int j = idx / (LPR * F), i = idx - j * (LPR * F), qq = i / F, f = i - qq * F;
+        const int dst = F >= 4 ? ((f >> 2) * TAIL_DK + j) * WS + 4 * qq + (f & 3) : j * WS + F * qq + f;
+        wl[dst] = wv[u];
+      }
+    }
   }
   T bias[TAIL_DK];
 #pragma unroll
@@ -1567,24 +1580,40 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
     T q = T(0.0);
     // one gradient element: the prior term and the temperature; with the leapfrog update fused in (see BGT) the
     // momentum and the position of the element move here and q collects the new position's prior quadratic form
-    auto emit = [&](int k, T v) {
-      const T m_ = a.mu[k], i_ = a.iv[k];
-      T tv = th[k];
+    auto emit = [&](int k, T v, T m_, T i_, T tv, T pin) {
       const T gv = (v - (tv - m_) * i_) * tscale;
       if (!fuse) { gc[k] = gv; return; }
       if (a.lf_store_g) gc[k] = gv;
-      const T pv = pc[k] + ep * gv;
+      const T pv = pin + ep * gv;
       pc[k] = pv;
       if (a.lf_wt != T(0.0)) { tv = tv + et * pv; thw[k] = tv; }
       const T dd = tv - m_;
       q += dd * dd * i_;
     };
-    for (int e = tid; e < dK * d; e += 256) {
-      const int j = e / d, i = e - j * d;
-      emit(a.woff + e, ((red[0][j * (LPR * F) + i] + red[1][j * (LPR * F) + i]) + red[2][j * (LPR * F) + i]) +
-                           red[3][j * (LPR * F) + i]);
+    // the operands of all of a thread's elements are fetched before the first is written (per-chain latency again)
+    constexpr int NE = (TAIL_DK * LPR * F + 255) / 256;
+    T em[NE], ei[NE], et_[NE], epn[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u, k = a.woff + e;
+      const bool in = e < dK * d;
+      em[u] = in ? a.mu[k] : T(0.0); ei[u] = in ? a.iv[k] : T(0.0); et_[u] = in ? th[k] : T(0.0);
+      epn[u] = in && fuse ? pc[k] : T(0.0);
     }
-    if (a.boff >= 0 && tid < dK) emit(a.boff + tid, ((redb[0][tid] + redb[1][tid]) + redb[2][tid]) + redb[3][tid]);
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u;
+      if (e < dK * d) {
+        const int j = e / d, i = e - j * d;
+        emit(a.woff + e, ((red[0][j * (LPR * F) + i] + red[1][j * (LPR * F) + i]) + red[2][j * (LPR * F) + i]) +
+                             red[3][j * (LPR * F) + i], em[u], ei[u], et_[u], epn[u]);
+      }
+    }
+    if (a.boff >= 0 && tid < dK) {
+      const int k = a.boff + tid;
+      emit(k, ((redb[0][tid] + redb[1][tid]) + redb[2][tid]) + redb[3][tid], a.mu[k], a.iv[k], th[k],
+           fuse ? pc[k] : T(0.0));
+    }
     if (fuse) {  // uniform over the workgroup
       __shared__ T redq[4];
 #pragma unroll
