@@ -6,6 +6,8 @@ within 2e-4 relative / 2e-3 absolute on log-targets that are O(100) (f32 has ~7 
 |u - rate| (or |log u - log_rate|) exceeds the stated margin; the number of in-margin draws is asserted to be 0
 for the committed traces.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1390,6 +1392,67 @@ def test_bgemm_hmc_fused_leapfrog_equals_separate_kernel(dims, acts, bias, N):
     # the cached target / gradient of the fused run are those of its final state
     np.testing.assert_allclose(a[1].cpu().numpy(), a[3].cpu().numpy(), rtol=2e-5, atol=2e-3)
     np.testing.assert_allclose(a[2].cpu().numpy(), a[4].cpu().numpy(), rtol=1e-3, atol=1e-4 * gs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("forced", [True, False])
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EY_FUZZ_SEEDS", "16"))))
+def test_random_architectures_vs_oracle(seed, forced):
+    """Seeded random MLPs (1-4 layers, widths 1-140, odd row counts, with and without bias, every activation, both
+    likelihoods, both dtypes), once forced onto the layerwise path -- whatever mix of kernels its dispatcher picks for the
+    shape (matrix-core GEMMs, narrow-product kernels, fused last layer, N-remainder split) -- and once on the family the
+    plan routes them to by itself (generic, fused16 with padded widths, layerwise): value, gradient and one HMC draw with
+    recorded randomness must match the C oracle.  (EY_FUZZ_SEEDS=300 has been run.)"""
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(1000 + seed)
+    nl = int(rng.integers(1, 5))
+    widths = [1, 2, 3, 4, 5, 8, 12, 16, 20, 33, 36, 64, 70, 100, 128, 140]
+    dims = [int(rng.choice([1, 2, 4, 7, 10, 16, 30]))] + [int(rng.choice(widths)) for _ in range(nl - 1)]
+    lik = int(rng.integers(0, 2))
+    dims.append(int(rng.choice([1, 2, 3])) if lik == 0 else int(rng.choice([2, 3, 5, 10])))
+    acts = [int(rng.integers(1, 4)) for _ in range(nl - 1)] + [1 if lik == 0 else 0]
+    bias = [int(rng.integers(0, 2)) for _ in range(nl)]
+    N = int(rng.choice([1, 5, 17, 64, 97, 150]))
+    f64 = bool(seed % 2)
+    npdt, dt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+    x = rng.standard_normal((N, dims[0]))
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(float)
+    P = sum((dims[l] + bias[l]) * dims[l + 1] for l in range(nl))
+    mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+    co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, bias=bias, nthreads=4)
+    _force_large(forced)
+    try:
+        pl = Plan(dims, bias, acts, lik, dt, DEV)
+        pl.set_data(_t(x, dt), _t(y, dt))
+        pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+        assert not forced or pl.kernel == "bgemm", (dims, acts, bias, lik, N)
+        C = 5
+        th0 = (0.3 / np.sqrt(max(dims)) * 4 * rng.standard_normal((C, P))).astype(npdt)
+        t, g = pl.log_target_grad(_t(th0, dt))
+        rt, at = (1e-9, 1e-9) if f64 else (3e-4, 3e-3)
+        for c in range(C):
+            to, go, _, _ = co.log_target_grad(th0[c])
+            info = (dims, acts, bias, lik, N, str(dt))
+            np.testing.assert_allclose(t[c].item(), to, rtol=rt, atol=at, err_msg=str(info))
+            np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=rt * 10, atol=at / 10 * max(1.0, np.abs(go).max()),
+                                       err_msg=str(info))
+        p0 = rng.standard_normal((C, P)).astype(npdt); u = rng.random(C).astype(npdt)
+        th, tv, gg = _t(th0, dt).clone(), t.clone(), g.clone()
+        out = pl.hmc_step(th, tv, gg, 0.01, 4, p0=_t(p0, dt), u=_t(u, dt))
+        # the yardstick for the decision is the f64 oracle on the same inputs (a sequential f32 sum over thousands of
+        # parameters is itself off by more than the kernel); the margin covers the f32 resolution of the Hamiltonian
+        co64 = co if f64 else COracle(dims, acts, lik, x, y, mu, sigma, dtype=np.float64, bias=bias, nthreads=4)
+        f8 = lambda a_: np.asarray(a_, dtype=np.float64).copy()
+        tho, tvo, go = f8(th0), f8(t.cpu().numpy()), f8(g.cpu().numpy())
+        acc, hc, hp = co64.hmc_draw(tho, tvo, go, f8(p0), f8(u), 0.01, 4)
+        rate = np.minimum(np.exp(np.minimum(hc - hp, 0)), 1)
+        margin = 1e-9 if f64 else np.maximum(5e-3, 8 * np.finfo(np.float32).eps * np.abs(hc))
+        decided = np.isfinite(hp) & (np.abs(u - rate) > margin)
+        np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+        same = (out["accepted"].cpu().numpy() == acc) & np.isfinite(hp)
+        np.testing.assert_allclose(th.cpu().numpy()[same], tho[same], rtol=rt * 10, atol=at / 10)
+    finally:
+        _force_large(False)
 
 
 def test_config5_shape_mnist_like_model_runs_on_bgemm_path():
