@@ -1451,6 +1451,26 @@ def test_random_architectures_vs_oracle(seed, forced):
         np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
         same = (out["accepted"].cpu().numpy() == acc) & np.isfinite(hp)
         np.testing.assert_allclose(th.cpu().numpy()[same], tho[same], rtol=rt * 10, atol=at / 10)
+        # the other entry points on the same plan: one MALA and one random-walk MH draw (log-rates against the f64
+        # oracle), the rows of the log-likelihood against its sum
+        z = rng.standard_normal((C, P)).astype(npdt)
+        th, tv, gg = _t(th0, dt).clone(), t.clone(), g.clone()
+        o1 = pl.mala_step(th, tv, gg, 1e-4, z=_t(z, dt), u=_t(u, dt))
+        _, lr = co64.mala_draw(f8(th0), f8(t.cpu().numpy()), f8(g.cpu().numpy()), f8(z), f8(u), 1e-4)
+        ok = np.isfinite(lr)
+        tol = (1e-7 if f64 else F32_DECISION_TOL) * np.maximum(1.0, np.abs(lr[ok])) + (0 if f64 else 8e-7 * np.abs(hc[ok]))
+        assert (np.abs(o1["log_rate"].cpu().numpy()[ok] - lr[ok]) <= tol).all(), (dims, acts, bias, lik, N, str(dt))
+        th, tv = _t(th0, dt).clone(), t.clone()
+        o2 = pl.mh_step(th, tv, 1e-3, z=_t(z, dt), u=_t(u, dt))
+        _, lr = co64.mh_draw(f8(th0), f8(t.cpu().numpy()), f8(z), f8(u), 1e-3)
+        ok = np.isfinite(lr)
+        tol = (1e-7 if f64 else F32_DECISION_TOL) * np.maximum(1.0, np.abs(lr[ok])) + (0 if f64 else 8e-7 * np.abs(hc[ok]))
+        assert (np.abs(o2["log_rate"].cpu().numpy()[ok] - lr[ok]) <= tol).all(), (dims, acts, bias, lik, N, str(dt))
+        rows = pl.log_lik_rows(_t(th0, dt))
+        lk, _ = pl.log_target(_t(th0, dt))
+        fin = torch.isfinite(lk)
+        np.testing.assert_allclose(rows.sum(1)[fin].cpu().numpy(), lk[fin].cpu().numpy(), rtol=1e-9 if f64 else 2e-4,
+                                   atol=1e-9 if f64 else 2e-3)
     finally:
         _force_large(False)
 
