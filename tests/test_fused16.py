@@ -1,6 +1,8 @@
 """The fused 16x16x4 matrix-core kernels (ey_fused16.hip: d0-H-H-dK, H in {16, 32, 64}, f32 and f64, CE or BCE, sigmoid /
 tanh / relu) through the C ABI against the C oracle, and against the generic kernels on the same inputs.
 f64 within 1e-10 relative (the reference's default dtype, eeyore/models/model.py:7), f32 within the stated 2e-4."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -30,6 +32,28 @@ CASES = [
     ([3, 7, 12, 1], [2, 1, 1], 0, "f64", 40),     # 7 x 12 = 84 >= 256 / 8: still worth the 16 x 16 grid
     ([6, 33, 64, 4], [1, 3, 0], 1, "f32", 45),
 ]
+
+
+def _random_cases(n, seed=2024):
+    """Shapes the fused kernels take, drawn at random: hidden widths on and off the 16 / 32 / 64 tile grid (within the
+    dispatcher's padding limit), d0 <= 8, dK <= 4, every hidden activation, CE or BCE, f32 or f64 (f64: widths <= 32)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        tag = "f64" if rng.random() < 0.5 else "f32"
+        hmax = 32 if tag == "f64" else 64
+        h1, h2 = int(rng.integers(3, hmax + 1)), int(rng.integers(3, hmax + 1))
+        hp = 16 if max(h1, h2) <= 16 else (32 if max(h1, h2) <= 32 else 64)
+        if 8 * h1 * h2 < hp * hp:
+            continue
+        lik = int(rng.integers(0, 2))
+        dims = [int(rng.integers(1, 9)), h1, h2, int(rng.integers(1, 5)) if lik == 0 else int(rng.integers(2, 5))]
+        acts = [int(rng.integers(1, 4)), int(rng.integers(1, 4)), 1 if lik == 0 else 0]
+        out.append((dims, acts, lik, tag, int(rng.choice([1, 7, 16, 33, 90, 150]))))
+    return out
+
+
+CASES += _random_cases(int(os.environ.get("EY_FUZZ_SEEDS", "10")))
 
 
 def _t(a, dt):
