@@ -38,6 +38,7 @@ template <typename T>
 struct F16Args {
   int d0, dK, act0, act1, lik, P;
   int h1, h2;  // true widths of the two hidden layers (<= H, the template's tile grid; the rest is zero padding)
+  int two;     // a model with ONE hidden layer (d0-h-dK): the middle layer is skipped, its slots hold no parameter
   int iW0, iB0, iW1, iB1, iW2, iB2;  // offsets of the layers in theta (weights row-major, then the bias, per layer)
   const T* xpack;                    // [ntiles][xt] operand-order data image (k_f16_pack)
   int ntiles, ks0, xt;
@@ -237,7 +238,7 @@ __device__ __forceinline__ F16Slot f16_slot(int k, const A& a, int c, int g, int
   if (k < K::S_W0) {
     const int r = k & 3, n = (k >> 2) % K::MT, mo = (k >> 2) / K::MT;
     const int out = 16 * mo + Lay<T>::fi(g, r), in = 16 * n + c;
-    const bool v = out < a.h2 && in < a.h1;
+    const bool v = !a.two && out < a.h2 && in < a.h1;
     return {a.iW1 + out * a.h1 + in, v, v};
   }
   if (k < K::S_W2) {
@@ -254,7 +255,7 @@ __device__ __forceinline__ F16Slot f16_slot(int k, const A& a, int c, int g, int
   }
   if (k < K::S_B0) {
     const int f = 16 * (k - K::S_B1) + c;
-    return {a.iB1 + f, f < a.h2, g == 0 && f < a.h2};
+    return {a.iB1 + f, !a.two && f < a.h2, !a.two && g == 0 && f < a.h2};
   }
   if (k < K::S_B2) {
     const int f = 16 * (k - K::S_B0) + c;
@@ -356,17 +357,22 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
         for (int r = 0; r < 4; ++r) lw[K::O_TB1 + (16 * m + L::fi(g, r)) * F16_TS + pc] = H0[m][r];
     }
-    // ---- F1: H1^T = act1(W1 H0^T + b1)
+    // ---- F1: H1^T = act1(W1 H0^T + b1)   (one hidden layer: H1 is H0, and a.act1 = a.act0 for the derivative below)
+    if (a.two) {
 #pragma unroll
-    for (int mo = 0; mo < MT; ++mo) {
-      v4<T> acc = f16_ld4(lw + K::O_B1 + 16 * mo + 4 * g);
+      for (int mo = 0; mo < MT; ++mo) H1[mo] = H0[mo];
+    } else {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int mo = 0; mo < MT; ++mo) {
+        v4<T> acc = f16_ld4(lw + K::O_B1 + 16 * mo + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16<T>(lw[K::O_W1A + ((mo * MT + m) * 4 + r) * 64 + lane], H0[m][r], acc);
-      H1[mo] = acc;
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma16<T>(lw[K::O_W1A + ((mo * MT + m) * 4 + r) * 64 + lane], H0[m][r], acc);
+        H1[mo] = acc;
+      }
+      f16_act_tiles<T, MT>(a.act1, H1);
     }
-    f16_act_tiles<T, MT>(a.act1, H1);
     if (GRAD) {
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo)
@@ -460,26 +466,32 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
     f16_fence();
     // ---- dH0 = delta1 W1 untransposed (A = delta1 T tiles with M = rows, B = theta's own W1 registers): U tiles
     v4<T> h0u[MT], d0u[MT];
+    if (a.two) {
+      // one hidden layer: "delta1" above already is delta0 (act1 = act0, H1 = H0); its U tiles come back from the buffer
 #pragma unroll
-    for (int n = 0; n < MT; ++n) {
-      h0u[n] = f16_ld4(lw + K::O_TB1 + (16 * n + c) * F16_TS + 4 * g);
-      v4<T> acc = {0, 0, 0, 0};
+      for (int n = 0; n < MT; ++n) d0u[n] = f16_ld4(lw + K::O_TB0 + (16 * n + c) * F16_TS + 4 * g);
+    } else {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int n = 0; n < MT; ++n) {
+        h0u[n] = f16_ld4(lw + K::O_TB1 + (16 * n + c) * F16_TS + 4 * g);
+        v4<T> acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16<T>(D1[m][r], th[(m * MT + n) * 4 + r], acc);
-      d0u[n] = acc;
-    }
-    f16_dact_tiles<T, MT>(a.act0, d0u, h0u);
-    // ---- dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int mo = 0; mo < MT; ++mo) {
-      const v4<T> d1u = f16_ld4(lw + K::O_TB0 + (16 * mo + c) * F16_TS + 4 * g);
+          for (int r = 0; r < 4; ++r) acc = mfma16<T>(D1[m][r], th[(m * MT + n) * 4 + r], acc);
+        d0u[n] = acc;
+      }
+      f16_dact_tiles<T, MT>(a.act0, d0u, h0u);
+      // ---- dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
 #pragma unroll
-      for (int n = 0; n < MT; ++n)
+      for (int mo = 0; mo < MT; ++mo) {
+        const v4<T> d1u = f16_ld4(lw + K::O_TB0 + (16 * mo + c) * F16_TS + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dW1[mo * MT + n] = mfma16<T>(d1u[r], h0u[n][r], dW1[mo * MT + n]);
-      db1[mo] += (d1u[0] + d1u[1]) + (d1u[2] + d1u[3]);
+        for (int n = 0; n < MT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dW1[mo * MT + n] = mfma16<T>(d1u[r], h0u[n][r], dW1[mo * MT + n]);
+        db1[mo] += (d1u[0] + d1u[1]) + (d1u[2] + d1u[3]);
+      }
     }
     // ---- dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
     {
@@ -817,19 +829,23 @@ __global__ void k_f16_pack(const T* __restrict__ x, const T* __restrict__ y, con
 
 bool ey_fused16_supports(const ey_plan* pl) {
   const EyModel& m = pl->m;
-  if (m.nl != 3) return false;
-  const int H = std::max(m.dims[1], m.dims[2]);  // the tile grid is the next of 16 / 32 / 64; narrower layers are padded
-  if (m.dims[1] < 1 || m.dims[2] < 1 || H > 64) return false;
+  if (m.nl != 3 && m.nl != 2) return false;
+  const int K = m.nl;              // two hidden layers, or one (the middle layer of the kernel is then skipped)
+  const int h1 = m.dims[1], h2 = m.dims[K - 1];
+  const int H = std::max(h1, h2);  // the tile grid is the next of 16 / 32 / 64; narrower layers are padded
+  if (h1 < 1 || h2 < 1 || H > 64) return false;
   // padded tiles are worth it while the padded W1 is at most eight times the real one (MLP(2-3-2-1) on a 16 x 16 grid
-  // would do 43 times its work: measured half the generic kernel's rate at 65 536 chains)
+  // would do 43 times its work: measured half the generic kernel's rate at 65 536 chains); with one hidden layer the
+  // same bound on the width squared
   const int Hp = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
-  if (8 * m.dims[1] * m.dims[2] < Hp * Hp) return false;
-  if (m.dims[0] < 1 || m.dims[0] > 8 || m.dims[3] < 1 || m.dims[3] > 4) return false;
-  if (!m.bias[0] || !m.bias[1] || !m.bias[2]) return false;
-  for (int l = 0; l < 2; ++l)
+  if (8 * h1 * h2 < Hp * Hp) return false;
+  if (m.dims[0] < 1 || m.dims[0] > 8 || m.dims[K] < 1 || m.dims[K] > 4) return false;
+  for (int l = 0; l < K; ++l)
+    if (!m.bias[l]) return false;
+  for (int l = 0; l < K - 1; ++l)
     if (m.act[l] != EY_ACT_SIGMOID && m.act[l] != EY_ACT_TANH && m.act[l] != EY_ACT_RELU) return false;
-  if (m.lik == EY_LIK_CE_SUM && m.act[2] != EY_ACT_NONE) return false;
-  if (m.lik == EY_LIK_BCE_SUM && m.act[2] != EY_ACT_SIGMOID) return false;
+  if (m.lik == EY_LIK_CE_SUM && m.act[K - 1] != EY_ACT_NONE) return false;
+  if (m.lik == EY_LIK_BCE_SUM && m.act[K - 1] != EY_ACT_SIGMOID) return false;
   if (pl->dtype == EY_F64 && H > 32) return false;  // theta and the gradient alone would take 428 of 512 registers
   return true;
 }
@@ -852,10 +868,10 @@ int ey_fused16_set_data(ey_plan* pl, hipStream_t s) {
   const dim3 grid((ntiles * 64 + 255) / 256);
   if (es == 4)
     hipLaunchKernelGGL(k_f16_pack<float>, grid, dim3(256), 0, s, (const float*)pl->d_x, (const float*)pl->d_y,
-                       (const int*)pl->d_labels, m.N, m.dims[0], m.dims[3], m.lik, ntiles, ks0, xt, (float*)pl->d_xpack16);
+                       (const int*)pl->d_labels, m.N, m.dims[0], m.dims[m.nl], m.lik, ntiles, ks0, xt, (float*)pl->d_xpack16);
   else
     hipLaunchKernelGGL(k_f16_pack<double>, grid, dim3(256), 0, s, (const double*)pl->d_x, (const double*)pl->d_y,
-                       (const int*)pl->d_labels, m.N, m.dims[0], m.dims[3], m.lik, ntiles, ks0, xt, (double*)pl->d_xpack16);
+                       (const int*)pl->d_labels, m.N, m.dims[0], m.dims[m.nl], m.lik, ntiles, ks0, xt, (double*)pl->d_xpack16);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
@@ -874,8 +890,11 @@ static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
 template <typename T>
 static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
   const EyModel& m = pl->m;
-  a.d0 = m.dims[0]; a.dK = m.dims[3]; a.act0 = m.act[0]; a.act1 = m.act[1]; a.lik = m.lik; a.P = m.P;
-  a.iW0 = m.woff[0]; a.iB0 = m.boff[0]; a.iW1 = m.woff[1]; a.iB1 = m.boff[1]; a.iW2 = m.woff[2]; a.iB2 = m.boff[2];
+  const int K = m.nl;
+  a.two = K == 2;
+  a.d0 = m.dims[0]; a.dK = m.dims[K]; a.act0 = m.act[0]; a.act1 = a.two ? m.act[0] : m.act[1]; a.lik = m.lik; a.P = m.P;
+  a.iW0 = m.woff[0]; a.iB0 = m.boff[0]; a.iW1 = a.two ? 0 : m.woff[1]; a.iB1 = a.two ? 0 : m.boff[1];
+  a.iW2 = m.woff[K - 1]; a.iB2 = m.boff[K - 1];
   a.xpack = (const T*)pl->d_xpack16;
   a.ntiles = (m.N + 15) / 16;
   a.ks0 = (m.dims[0] + 3) / 4;
@@ -883,7 +902,7 @@ static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
   a.mu = (const T*)m.mu;
   a.inv_var = (const T*)m.inv_var;
   a.prior_const = (T)m.prior_const;
-  a.h1 = m.dims[1]; a.h2 = m.dims[2];
+  a.h1 = m.dims[1]; a.h2 = m.dims[K - 1];
   const int H = std::max(a.h1, a.h2);
   // waves per CU by what the per-wave LDS region and the register file allow
   if constexpr (sizeof(T) == 4) {

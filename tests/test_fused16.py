@@ -31,6 +31,11 @@ CASES = [
     ([5, 50, 30, 2], [1, 2, 0], 1, "f32", 77),
     ([3, 7, 12, 1], [2, 1, 1], 0, "f64", 40),     # 7 x 12 = 84 >= 256 / 8: still worth the 16 x 16 grid
     ([6, 33, 64, 4], [1, 3, 0], 1, "f32", 45),
+    # one hidden layer: the kernel's middle layer is skipped
+    ([4, 16, 3], [1, 0], 1, "f64", 150),
+    ([8, 32, 2], [2, 0], 1, "f32", 77),
+    ([4, 50, 1], [3, 1], 0, "f32", 40),
+    ([3, 9, 4], [1, 0], 1, "f64", 33),
 ]
 
 
@@ -47,8 +52,14 @@ def _random_cases(n, seed=2024):
         if 8 * h1 * h2 < hp * hp:
             continue
         lik = int(rng.integers(0, 2))
-        dims = [int(rng.integers(1, 9)), h1, h2, int(rng.integers(1, 5)) if lik == 0 else int(rng.integers(2, 5))]
-        acts = [int(rng.integers(1, 4)), int(rng.integers(1, 4)), 1 if lik == 0 else 0]
+        dK = int(rng.integers(1, 5)) if lik == 0 else int(rng.integers(2, 5))
+        if rng.random() < 0.35:   # one hidden layer (the kernel's middle layer is skipped)
+            if 8 * h1 * h1 < (16 if h1 <= 16 else (32 if h1 <= 32 else 64)) ** 2:
+                continue
+            dims, acts = [int(rng.integers(1, 9)), h1, dK], [int(rng.integers(1, 4)), 1 if lik == 0 else 0]
+        else:
+            dims = [int(rng.integers(1, 9)), h1, h2, dK]
+            acts = [int(rng.integers(1, 4)), int(rng.integers(1, 4)), 1 if lik == 0 else 0]
         out.append((dims, acts, lik, tag, int(rng.choice([1, 7, 16, 33, 90, 150]))))
     return out
 
@@ -66,9 +77,9 @@ def _setup(dims, acts, lik, tag, N, seed=0):
     rng = np.random.default_rng(sum(dims) + N + seed)
     x = rng.standard_normal((N, dims[0]))
     y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(np.float64)
-    P = sum((dims[l] + 1) * dims[l + 1] for l in range(3))
+    P = sum((dims[l] + 1) * dims[l + 1] for l in range(len(dims) - 1))
     mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
-    pl = Plan(dims, [1, 1, 1], acts, lik, dt, DEV)
+    pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV)
     pl.set_data(_t(x, dt), _t(y, dt))
     pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
     co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, nthreads=4)

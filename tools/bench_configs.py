@@ -99,9 +99,14 @@ for dims, acts, lik, dtype, C in (([4, 32, 32, 3], [1, 1, 0], 1, torch.float64, 
                                   # hidden widths off the tile grid (zero-padded to the next of 16 / 32 / 64)
                                   ([4, 20, 20, 3], [1, 1, 0], 1, torch.float32, 4096),
                                   ([4, 50, 40, 3], [1, 1, 0], 1, torch.float32, 4096),
-                                  ([4, 24, 24, 3], [1, 1, 0], 1, torch.float64, 4096)):
+                                  ([4, 24, 24, 3], [1, 1, 0], 1, torch.float64, 4096),
+                                  # one hidden layer (the kernel's middle layer skipped)
+                                  ([4, 16, 3], [1, 0], 1, torch.float32, 4096),
+                                  ([4, 32, 3], [1, 0], 1, torch.float32, 4096),
+                                  ([4, 64, 3], [1, 0], 1, torch.float32, 4096),
+                                  ([4, 32, 3], [1, 0], 1, torch.float64, 4096)):
     y = ys if lik == 1 else ys[:, :1]
-    pl = Plan(dims, [1, 1, 1], acts, lik, dtype, dev)
+    pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dtype, dev)
     pl.set_data(torch.tensor(xs, dtype=dtype, device=dev), torch.tensor(y, dtype=dtype, device=dev))
     pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), float(np.sqrt(3.0))))
     th = 0.1 * pl.philox_normal(C, seed=0, it=0)
