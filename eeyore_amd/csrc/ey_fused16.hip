@@ -229,37 +229,43 @@ struct F16Slot {
 };
 // canonical element k of lane (c, g): its index in theta, whether this lane holds anything there, and whether this
 // lane's copy is the one that enters sums over parameters
-template <int H, typename T, bool TWO, typename A>
+template <int H, typename T, int V, typename A>
 __device__ __forceinline__ F16Slot f16_slot(int k, const A& a, int c, int g, int lane) {
   typedef F16Cfg<H> K;
-  // Hidden widths h1, h2 below the tile grid H: the slots of features beyond them hold no parameter (theta 0, gradient
-  // masked, no momentum).  A padded hidden unit is act(0) -- not 0 for a sigmoid -- but every weight that reads it is a
-  // padding slot, so it reaches nothing; the weight gradients it produces land in padding slots and are dropped.
+  // V & 1 (TWO): one hidden layer, the middle layer's slots hold nothing.  V & 2 (PAD): hidden widths h1, h2 below the
+  // tile grid H -- the slots of features beyond them hold no parameter (theta 0, gradient masked, no momentum).  A
+  // padded hidden unit is act(0), not 0 for a sigmoid, but every weight that reads it is a padding slot, so it reaches
+  // nothing; the weight gradients it produces land in padding slots and are dropped.  Without PAD the widths ARE H and
+  // the strides are compile-time constants (the run-time form cost the exact shapes up to 4.5 %).
+  constexpr bool TWO = (V & 1) != 0, PAD = (V & 2) != 0;
+  const int h1 = PAD ? a.h1 : H, h2 = PAD ? a.h2 : H;
   if (k < K::S_W0) {
     const int r = k & 3, n = (k >> 2) % K::MT, mo = (k >> 2) / K::MT;
     const int out = 16 * mo + Lay<T>::fi(g, r), in = 16 * n + c;
-    const bool v = !TWO && out < a.h2 && in < a.h1;  // TWO: one hidden layer, the middle layer holds nothing
-    return {a.iW1 + out * a.h1 + in, v, v};
+    const bool v = !TWO && (!PAD || (out < h2 && in < h1));
+    return {a.iW1 + out * h1 + in, v, v};
   }
   if (k < K::S_W2) {
     const int kk = k - K::S_W0, r = kk & 3, m = kk >> 2;
     const int out = 16 * m + Lay<T>::fi(g, r);
-    const bool v = c < a.d0 && out < a.h1;
+    const bool v = c < a.d0 && (!PAD || out < h1);
     return {a.iW0 + out * a.d0 + c, v, v};
   }
   if (k < K::S_B1) {
     const int kk = k - K::S_W2, r = kk & 3, n = kk >> 2;
     const int in = 16 * n + c;
-    const bool v = Lay<T>::fi(g, r) < a.dK && in < a.h2;
-    return {a.iW2 + Lay<T>::fi(g, r) * a.h2 + in, v, v};
+    const bool v = Lay<T>::fi(g, r) < a.dK && (!PAD || in < h2);
+    return {a.iW2 + Lay<T>::fi(g, r) * h2 + in, v, v};
   }
   if (k < K::S_B0) {
     const int f = 16 * (k - K::S_B1) + c;
-    return {a.iB1 + f, !TWO && f < a.h2, !TWO && g == 0 && f < a.h2};
+    const bool v = !TWO && (!PAD || f < h2);
+    return {a.iB1 + f, v, v && g == 0};
   }
   if (k < K::S_B2) {
     const int f = 16 * (k - K::S_B0) + c;
-    return {a.iB0 + f, f < a.h1, g == 0 && f < a.h1};
+    const bool v = !PAD || f < h1;
+    return {a.iB0 + f, v, v && g == 0};
   }
   const int o = k - K::S_B2;
   return {a.iB2 + o, o < a.dK, lane == 0 && o < a.dK};
@@ -313,7 +319,7 @@ __device__ __forceinline__ v4<T> f16_ld4(const T* p) {
 // log-target and gradient of the position whose images are staged in lw; returns the (tempered) log-target.
 // GRAD (wave-uniform) = false: the value only (random-walk MH).  Inlined at its three call sites: theta and the gradient
 // are register arrays, which a call would force into scratch memory.
-template <typename T, int H, bool TWO, typename A>
+template <typename T, int H, int V, typename A>
 __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>::NREG],
                                       T (&gr)[F16Cfg<H>::NREG], const bool GRAD, bool has_temp, T temp, int c, int g,
                                       int lane, T* lik_out = nullptr, T* prior_out = nullptr) {
@@ -358,7 +364,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
         for (int r = 0; r < 4; ++r) lw[K::O_TB1 + (16 * m + L::fi(g, r)) * F16_TS + pc] = H0[m][r];
     }
     // ---- F1: H1^T = act1(W1 H0^T + b1)   (one hidden layer: H1 is H0, and a.act1 = a.act0 for the derivative below)
-    if constexpr (TWO) {
+    if constexpr ((V & 1) != 0) {
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo) H1[mo] = H0[mo];
     } else {
@@ -466,7 +472,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
     f16_fence();
     // ---- dH0 = delta1 W1 untransposed (A = delta1 T tiles with M = rows, B = theta's own W1 registers): U tiles
     v4<T> h0u[MT], d0u[MT];
-    if constexpr (TWO) {
+    if constexpr ((V & 1) != 0) {
       // one hidden layer: "delta1" above already is delta0 (act1 = act0, H1 = H0); its U tiles come back from the buffer
 #pragma unroll
       for (int n = 0; n < MT; ++n) d0u[n] = f16_ld4(lw + K::O_TB0 + (16 * n + c) * F16_TS + 4 * g);
@@ -529,7 +535,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
   // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
   T qsum = T(0);
   F16_EACH(k) {
-    const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+    const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
     if (s.valid) {
       const T d = th[k] - a.mu[s.idx];
       const T iv = a.inv_var[s.idx];
@@ -552,7 +558,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 }
 
 // One chain of one launch: everything between reading theta and writing the accepted state back.
-template <typename T, int H, bool TWO, typename A>
+template <typename T, int H, int V, typename A>
 __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t chain, const int it, const int c,
                                               const int g, const int lane) {
   typedef F16Cfg<H> K;
@@ -569,7 +575,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
 
   T th[K::NREG], gr[K::NREG];
   F16_EACH(k) {
-    const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+    const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
     th[k] = s.valid ? thg[s.idx] : T(0);
     gr[k] = T(0);
   }
@@ -577,10 +583,10 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   if (mode == F16_GRAD) {
     f16_write_images<T, H>(lw, th, a, c, g);
     T lik, prior;
-    const T t = f16_eval<T, H, TWO>(a, lw, th, gr, a.grad != nullptr, has_temp, temp, c, g, lane, &lik, &prior);
+    const T t = f16_eval<T, H, V>(a, lw, th, gr, a.grad != nullptr, has_temp, temp, c, g, lane, &lik, &prior);
     if (a.grad) {
       F16_EACH(k) {
-        const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+        const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
         if (s.counts) grg[s.idx] = gr[k];
       }
     }
@@ -621,7 +627,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     T gp[K::NREG];
     T qf = T(0);
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+      const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
       p[k] = T(0);
       gp[k] = T(0);
       if (s.valid) {
@@ -639,13 +645,13 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     }
     f16_fence();  // the staged normals have been read; the evaluation reuses that LDS
     f16_write_images<T, H>(lw, p, a, c, g);
-    const T tv = f16_eval<T, H, TWO>(a, lw, p, gp, mode == F16_MALA, has_temp, temp, c, g, lane);
+    const T tv = f16_eval<T, H, V>(a, lw, p, gp, mode == F16_MALA, has_temp, temp, c, g, lane);
     const T t_old = a.target[chain];
     T log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
     if (mode == F16_MALA) {
       T qb = T(0);
       F16_EACH(k) {
-        const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+        const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
         if (s.counts) {
           const T d = th[k] - (p[k] + T(0.5) * eps * gp[k]);
           qb += d * d;
@@ -659,7 +665,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     const bool acc = Nm<T>::log(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
     T* so = a.rec_samples ? a.rec_samples + ((int64_t)it * a.C + chain) * P : nullptr;
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+      const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
       if (s.counts) {
         if (acc) {
           thg[s.idx] = p[k];
@@ -684,7 +690,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   T t_cur = T(0), kin = T(0);
   if (mode == F16_HMC) {
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+      const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
       p[k] = s.valid ? st[s.idx] : T(0);   // hmc.py:134
       if (s.counts) kin += p[k] * p[k];
       if (s.valid && !a.recompute) gr[k] = grg[s.idx];
@@ -695,7 +701,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   } else {
     const T* pin = a.pio + chain * P;
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+      const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
       p[k] = s.valid ? pin[s.idx] : T(0);
     }
   }
@@ -713,7 +719,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
       F16_EACH(k) th[k] = th[k] + eps * p[k];
     }
     f16_write_images<T, H>(lw, th, a, c, g);
-    t = f16_eval<T, H, TWO>(a, lw, th, gr, true, has_temp, temp, c, g, lane);
+    t = f16_eval<T, H, V>(a, lw, th, gr, true, has_temp, temp, c, g, lane);
     const T w = (kk > 0 && kk < a.L) ? eps : T(0.5) * eps;
     F16_EACH(k) p[k] = p[k] + w * gr[k];
   }
@@ -721,7 +727,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   if (mode == F16_LEAPFROG) {
     T* pout = a.pio + chain * P;
     F16_EACH(k) {
-      const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+      const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
       if (s.counts) {
         thg[s.idx] = th[k];
         pout[s.idx] = -p[k];  // hmc.py:122
@@ -734,7 +740,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
 
   kin = T(0);
   F16_EACH(k) {
-    const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+    const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
     if (s.counts) kin += p[k] * p[k];
   }
   kin = f16_wsum(kin);
@@ -746,7 +752,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   const bool acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
   T* so = a.rec_samples ? a.rec_samples + ((int64_t)it * a.C + chain) * P : nullptr;
   F16_EACH(k) {
-    const F16Slot s = f16_slot<H, T, TWO>(k, a, c, g, lane);
+    const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
     if (s.counts) {
       if (so) so[s.idx] = acc ? th[k] : thg[s.idx];  // the state this chain is left in (chain_list.py:64-67)
       if (acc) {
@@ -773,7 +779,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
 
 // Persistent launch: one WAVES-wave workgroup per CU, every wave walks over chains blockIdx + gridDim * wave, ... and
 // takes each through all iterations of the launch (chain-major, as ey_mfma32.hip).
-template <typename T, int H, int WAVES, bool TWO>
+template <typename T, int H, int WAVES, int V>
 __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4) k_fused16(F16Args<T> a) {
   typedef F16Cfg<H> K;
   extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
@@ -795,7 +801,7 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4) k_fused16(F16Args
       // all stay live in scalar registers for the whole kernel and spill into vector registers
       KA* ap = (KA*)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ap));
-      f16_run_chain<T, H, TWO>(*ap, lw, chain, it, c, g, lane);
+      f16_run_chain<T, H, V>(*ap, lw, chain, it, c, g, lane);
     }
 }
 
@@ -876,21 +882,30 @@ int ey_fused16_set_data(ey_plan* pl, hipStream_t s) {
   return EY_OK;
 }
 
-template <typename T, int H, int WAVES, bool TWO>
+template <typename T, int H, int WAVES, int V>
 static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
   const size_t bytes = sizeof(T) * (size_t)WAVES * F16Cfg<H>::WAVE_ELEMS;
-  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, TWO>),
+  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, V>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   const unsigned grid = (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256);
-  hipLaunchKernelGGL((k_fused16<T, H, WAVES, TWO>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+  hipLaunchKernelGGL((k_fused16<T, H, WAVES, V>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
-// TWO (a model with ONE hidden layer, d0-h-dK) is a separate instantiation: as a run-time flag it cost the
-// two-hidden-layer kernels 1-12 % (A/B of whole-library builds in one session, tools/ab_fused16.py)
+// The variant V = TWO | 2 PAD is a template parameter: one hidden layer (the middle layer skipped) and hidden widths
+// below the tile grid are separate instantiations -- as run-time flags they cost the exact two-hidden-layer shapes
+// 1-12 % and up to 4.5 % (A/B of whole-library builds in one session, tools/ab_fused16.py).
 template <typename T, int H, int WAVES>
 static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
-  return a.two ? f16_launch_t<T, H, WAVES, true>(a, n_cu, s) : f16_launch_t<T, H, WAVES, false>(a, n_cu, s);
+  // (the exact 64-wide shape also takes the PAD instantiation: its register allocation happens to come out 19 % faster,
+  // 8.7e6 against 7.3e6 leapfrog-steps/s x chains on MLP(4-64-64-3), same session)
+  const bool pad = a.h1 != H || a.h2 != H || H == 64;
+  switch ((a.two ? 1 : 0) | (pad ? 2 : 0)) {
+    case 0: return f16_launch_t<T, H, WAVES, 0>(a, n_cu, s);
+    case 1: return f16_launch_t<T, H, WAVES, 1>(a, n_cu, s);
+    case 2: return f16_launch_t<T, H, WAVES, 2>(a, n_cu, s);
+    default: return f16_launch_t<T, H, WAVES, 3>(a, n_cu, s);
+  }
 }
 
 template <typename T>
