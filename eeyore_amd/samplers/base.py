@@ -171,8 +171,15 @@ class SingleChainSerialSampler(SerialSampler):
                                                                   device=self._theta.device)))
             rec = dict(samples=views.get('sample'), targets=views.get('target_val'),
                        accepted_rec=views.get('accepted'))
-        out = self._run_block(plan, k, rec)
-        self._iter += k
+        if not savestate and k > 1 and plan._moments is not None and plan.kernel != 'mfma32':
+            # attached chain moments (ChainStats.attach) outside the mfma32 kernel are accumulated from the recorded
+            # samples of a block; a burn-in block records nothing, so it goes iteration by iteration
+            for _ in range(k):
+                out = self._run_block(plan, 1, {})
+                self._iter += 1
+        else:
+            out = self._run_block(plan, k, rec)
+            self._iter += k
         self._publish(out['accepted'])
         self.last = out
         if savestate:

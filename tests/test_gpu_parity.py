@@ -640,6 +640,40 @@ def test_set_temperature_rescales_the_cached_state():
     assert torch.isfinite(s.get_chain().get_target_vals()).all()
 
 
+def test_run_with_attached_moments_and_in_kernel_tuner_off_the_mfma32_kernel():
+    """ChainStats.attach + a per-chain dual-averaging tuner + HMC.run with burn-in on the 16x16x4 fused family (a
+    one-hidden-layer model) and on the layerwise path: the burn-in blocks record nothing, so with attached moments they go
+    iteration by iteration instead of failing (moments on these families are replayed from a block's records)."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.distributed import ChainStats
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    from eeyore_amd.tuners import PerChainDATuner
+    data = synthetic.iris_shaped(dtype=torch.float32, device=DEV)
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    for dims, kernel in (([4, 16, 3], "fused16"), ([4, 100, 3], "bgemm")):
+        model = mlp.MLP(loss=loss_functions['multiclass_classification'],
+                        hparams=mlp.Hyperparameters(dims=dims, activations=[torch.sigmoid, None]), dtype=torch.float32,
+                        device=DEV)
+        P = model.num_params()
+        model.prior = Normal(torch.zeros(P, device=DEV), torch.ones(P, device=DEV))
+        C = 64
+        s = HMC(model, theta0=0.1 * torch.randn(C, P, device=DEV), dataloader=loader, step=0.01, num_steps=5, seed=3)
+        s.tuner = PerChainDATuner(torch.full((C,), 0.01, dtype=torch.float64, device=DEV), num_steps=5)
+        plan = model._plan(*next(iter(loader)))
+        assert plan.kernel == kernel
+        st = ChainStats(C, P, DEV)
+        st.attach(plan)
+        s.run(num_epochs=24, num_burnin_epochs=8)
+        ch = s.get_chain()
+        assert ch.get_samples().shape == (16, C, P) and torch.isfinite(ch.get_target_vals()).all()
+        summ = st.summary()
+        assert torch.isfinite(summ["mean"]).all() and 0 < summ["acceptance"] <= 1
+
+
 def test_hmc_fused_run_loop_gives_the_same_chains():
     """HMC.run with blocks of iterations per launch (ey_hmc_run, records written straight into the chain buffer)
     against the same run with one launch per iteration: identical chains, targets and accept flags; with a per-chain
