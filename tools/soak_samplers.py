@@ -81,7 +81,12 @@ for dims, acts, lik, dt in (([4, 16, 3], [torch.sigmoid, None], 'multiclass_clas
     s = MALA(model, theta0=0.1 * torch.randn(8, P, dtype=dt, device=DEV), dataloader=mini, step=1e-4, seed=2)
     s.run(num_epochs=6, num_burnin_epochs=2)
     assert s.get_chain().get_samples().shape[0] == 12, s.get_chain().get_samples().shape
-    notes.append("minibatch MALA ok")
+    # ... and batches of unequal size (40, 40, 10 rows) through HMC: the plan's data images follow every change
+    ragged = DataLoader(data, batch_size=40, shuffle=True)
+    s = HMC(model, theta0=0.1 * torch.randn(8, P, dtype=dt, device=DEV), dataloader=ragged, step=0.005, num_steps=3, seed=2)
+    s.run(num_epochs=5, num_burnin_epochs=1)
+    assert s.get_chain().get_samples().shape[0] == 12 and torch.isfinite(s.get_chain().get_target_vals()).all()
+    notes.append("minibatch MALA / ragged HMC ok")
     # parallel tempering: 4 temperatures x 5 replicas
     pt = PowerPosteriorSampler(model, full, [['HMC', {'step': 0.01, 'num_steps': 3}] for _ in range(4)],
                                theta0=0.1 * torch.randn(5, P, dtype=dt, device=DEV), between_step=2, seed=4)
