@@ -913,7 +913,7 @@ def test_mfma32_mala_and_mh_vs_oracle_and_generic():
         b = [th0.clone(), t0.clone(), g0.clone()]
         oa = pl.mala_step(*a, step, z=z, u=u)
         ob = pl.mala_step(*b, step, z=z, u=u, flags=L.EY_FORCE_GENERIC)
-        # the yardstick is the f64 oracle on the same f32 inputs: measured on the box (tools/margin_probe.py) both HIP
+        # the yardstick is the f64 oracle on the same f32 inputs: measured on the box (tests/tools/margin_probe.py) both HIP
         # kernels stay within 6e-4 of it at P = 1315, while the f32 C oracle itself is off by up to 1e-2 (it sums the
         # 1315 squared proposal residuals in one running f32 sum; the kernels sum per lane, then across lanes)
         tho, tvo, go = (a_.cpu().numpy().astype(np.float64) for a_ in (th0, t0, g0))

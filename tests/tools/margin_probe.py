@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from eeyore_amd import _lib as L  # noqa: E402
 from eeyore_amd.plan import Plan  # noqa: E402
 from oracle.c_oracle import COracle  # noqa: E402

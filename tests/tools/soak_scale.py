@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Large row counts (up to 50 000) and chain counts (up to 100 000) on every kernel family: value and gradient against the f64
-C oracle, one HMC draw finite.  usage: python tools/soak_scale.py"""
+C oracle, one HMC draw finite.  usage: python tests/tools/soak_scale.py (under tests/: it uses the oracle as its checker)"""
 import os, sys, numpy as np, torch, time
 sys.path.insert(0, '.')
 from oracle.c_oracle import COracle
