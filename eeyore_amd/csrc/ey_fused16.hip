@@ -212,8 +212,8 @@ struct F16Cfg {
   static constexpr int O_W1A = 0;                       // [(mo MT + m) 4 + r][lane]: A operands of F1
   static constexpr int O_TB0 = H * H;                   // [H][TS] transpose buffer: H1, then delta1
   static constexpr int O_TB1 = O_TB0 + H * F16_TS;      // [H][TS] transpose buffer: H0
-  static constexpr int O_W0A = O_TB1 + H * F16_TS;      // [m][s < 2][lane]: A operands of F0
-  static constexpr int O_W2A = O_W0A + MT * 2 * 64;     // [m][r][lane]: A operands of the logits
+  static constexpr int O_W0A = O_TB1 + H * F16_TS;      // [m][s < 4][lane]: A operands of F0 (up to 16 inputs)
+  static constexpr int O_W2A = O_W0A + MT * 4 * 64;     // [m][r][lane]: A operands of the logits
   static constexpr int O_W2T = O_W2A + MT * 4 * 64;     // [m][lane]: A operands of dH1
   static constexpr int O_B0 = O_W2T + MT * 64;          // [H]
   static constexpr int O_B1 = O_B0 + H;                 // [H]
@@ -290,7 +290,7 @@ __device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>:
 #pragma unroll
     for (int k = 0; k < K::NW0; ++k) {  // W0[16m + fi(g, r)][c]: A operand of F0, k-step c >> 2, k-slot c & 3 (as k_f16_pack lays x out)
       const int r = k & 3, m = k >> 2;
-      lw[K::O_W0A + (m * 2 + (c >> 2)) * 64 + L::fi(g, r) + 16 * (c & 3)] = th[K::S_W0 + k];
+      lw[K::O_W0A + (m * 4 + (c >> 2)) * 64 + L::fi(g, r) + 16 * (c & 3)] = th[K::S_W0 + k];
     }
   }
 #pragma unroll
@@ -342,9 +342,12 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll 1
   for (int t = 0; t < a.ntiles; ++t) {
     const T* xt = a.xpack + (size_t)t * a.xt;
-    T xb[2];
-    xb[0] = xt[lane];
-    xb[1] = a.ks0 > 1 ? xt[64 + lane] : T(0);
+    // k-steps of F0 (four inputs each): two in the exact-shape instantiations (d0 <= 8), four in the padded ones, which
+    // also serve 9 .. 16 inputs
+    constexpr int KS = (V & 2) ? 4 : 2;
+    T xb[KS];
+#pragma unroll
+    for (int s4 = 0; s4 < KS; ++s4) xb[s4] = s4 < a.ks0 ? xt[s4 * 64 + lane] : T(0);
     const int lab = (int)xt[off_lab + c];  // -1 marks a padding row
     const bool valid = lab >= 0;
     // ---- F0: H0^T = act0(W0 X^T + b0)                                  (mlp.py:45-50)
@@ -352,8 +355,10 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       v4<T> acc = f16_ld4(lw + K::O_B0 + 16 * m + 4 * g);
-      acc = mfma16<T>(lw[K::O_W0A + (m * 2) * 64 + lane], xb[0], acc);
-      if (a.ks0 > 1) acc = mfma16<T>(lw[K::O_W0A + (m * 2 + 1) * 64 + lane], xb[1], acc);
+      acc = mfma16<T>(lw[K::O_W0A + (m * 4) * 64 + lane], xb[0], acc);
+#pragma unroll
+      for (int s4 = 1; s4 < KS; ++s4)
+        if (s4 < a.ks0) acc = mfma16<T>(lw[K::O_W0A + (m * 4 + s4) * 64 + lane], xb[s4], acc);
       H0[m] = acc;
     }
     f16_act_tiles<T, MT>(a.act0, H0);
@@ -845,7 +850,7 @@ bool ey_fused16_supports(const ey_plan* pl) {
   // same bound on the width squared
   const int Hp = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
   if (8 * h1 * h2 < Hp * Hp) return false;
-  if (m.dims[0] < 1 || m.dims[0] > 8 || m.dims[K] < 1 || m.dims[K] > 4) return false;
+  if (m.dims[0] < 1 || m.dims[0] > 16 || m.dims[K] < 1 || m.dims[K] > 4) return false;
   for (int l = 0; l < K; ++l)
     if (!m.bias[l]) return false;
   for (int l = 0; l < K - 1; ++l)
@@ -899,7 +904,7 @@ template <typename T, int H, int WAVES>
 static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   // (the exact 64-wide shape also takes the PAD instantiation: its register allocation happens to come out 19 % faster,
   // 8.7e6 against 7.3e6 leapfrog-steps/s x chains on MLP(4-64-64-3), same session)
-  const bool pad = a.h1 != H || a.h2 != H || H == 64;
+  const bool pad = a.h1 != H || a.h2 != H || H == 64 || a.d0 > 8;  // (more than 8 inputs: the padded forms' four k-steps)
   switch ((a.two ? 1 : 0) | (pad ? 2 : 0)) {
     case 0: return f16_launch_t<T, H, WAVES, 0>(a, n_cu, s);
     case 1: return f16_launch_t<T, H, WAVES, 1>(a, n_cu, s);

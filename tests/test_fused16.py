@@ -41,7 +41,7 @@ CASES = [
 
 def _random_cases(n, seed=2024):
     """Shapes the fused kernels take, drawn at random: hidden widths on and off the 16 / 32 / 64 tile grid (within the
-    dispatcher's padding limit), d0 <= 8, dK <= 4, every hidden activation, CE or BCE, f32 or f64 (f64: widths <= 32)."""
+    dispatcher's padding limit), d0 <= 16, dK <= 4, every hidden activation, CE or BCE, f32 or f64 (f64: widths <= 32)."""
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
@@ -56,9 +56,9 @@ def _random_cases(n, seed=2024):
         if rng.random() < 0.35:   # one hidden layer (the kernel's middle layer is skipped)
             if 8 * h1 * h1 < (16 if h1 <= 16 else (32 if h1 <= 32 else 64)) ** 2:
                 continue
-            dims, acts = [int(rng.integers(1, 9)), h1, dK], [int(rng.integers(1, 4)), 1 if lik == 0 else 0]
+            dims, acts = [int(rng.integers(1, 17)), h1, dK], [int(rng.integers(1, 4)), 1 if lik == 0 else 0]
         else:
-            dims = [int(rng.integers(1, 9)), h1, h2, dK]
+            dims = [int(rng.integers(1, 17)), h1, h2, dK]
             acts = [int(rng.integers(1, 4)), int(rng.integers(1, 4)), 1 if lik == 0 else 0]
         out.append((dims, acts, lik, tag, int(rng.choice([1, 7, 16, 33, 90, 150]))))
     return out
