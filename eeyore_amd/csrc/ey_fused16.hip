@@ -202,7 +202,9 @@ __device__ __forceinline__ void f16_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int H>
+// KSM: k-steps (of four inputs) the first layer's operand image is laid out for -- 2 in the exact-shape instantiations
+// (their LDS layout is untouched by the wider forms), 4 in the padded ones
+template <int H, int KSM = 2>
 struct F16Cfg {
   static constexpr int MT = H / 16;
   static constexpr int NW1 = MT * MT * 4, NW0 = MT * 4, NW2 = MT * 4;
@@ -212,8 +214,8 @@ struct F16Cfg {
   static constexpr int O_W1A = 0;                       // [(mo MT + m) 4 + r][lane]: A operands of F1
   static constexpr int O_TB0 = H * H;                   // [H][TS] transpose buffer: H1, then delta1
   static constexpr int O_TB1 = O_TB0 + H * F16_TS;      // [H][TS] transpose buffer: H0
-  static constexpr int O_W0A = O_TB1 + H * F16_TS;      // [m][s < 4][lane]: A operands of F0 (up to 16 inputs)
-  static constexpr int O_W2A = O_W0A + MT * 4 * 64;     // [m][r][lane]: A operands of the logits
+  static constexpr int O_W0A = O_TB1 + H * F16_TS;      // [m][s < KSM][lane]: A operands of F0 (up to 4 KSM inputs)
+  static constexpr int O_W2A = O_W0A + MT * KSM * 64;   // [m][r][lane]: A operands of the logits
   static constexpr int O_W2T = O_W2A + MT * 4 * 64;     // [m][lane]: A operands of dH1
   static constexpr int O_B0 = O_W2T + MT * 64;          // [H]
   static constexpr int O_B1 = O_B0 + H;                 // [H]
@@ -275,9 +277,9 @@ __device__ __forceinline__ F16Slot f16_slot(int k, const A& a, int c, int g, int
 // stage the operand images of the position `th` in this wave's LDS region (the zero padding of the images was
 // written once at kernel start and is never overwritten).  An element W[out][in] this lane holds goes where the lane
 // that feeds it to the product will read it: A operand lane (i & 15, k-slot), one image row of 64 per k-step.
-template <typename T, int H, typename A>
+template <typename T, int H, int KSM, typename A>
 __device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>::NREG], const A& a, int c, int g) {
-  typedef F16Cfg<H> K;
+  typedef F16Cfg<H, KSM> K;
   typedef Lay<T> L;
   // the k-step register rk and k-slot gk at which input feature (16n +) c enters a product whose B operand is a T tile
   const int pc = L::perm(c), rk = pc & 3, gk = pc >> 2;
@@ -290,7 +292,7 @@ __device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>:
 #pragma unroll
     for (int k = 0; k < K::NW0; ++k) {  // W0[16m + fi(g, r)][c]: A operand of F0, k-step c >> 2, k-slot c & 3 (as k_f16_pack lays x out)
       const int r = k & 3, m = k >> 2;
-      lw[K::O_W0A + (m * 4 + (c >> 2)) * 64 + L::fi(g, r) + 16 * (c & 3)] = th[K::S_W0 + k];
+      lw[K::O_W0A + (m * KSM + (c >> 2)) * 64 + L::fi(g, r) + 16 * (c & 3)] = th[K::S_W0 + k];
     }
   }
 #pragma unroll
@@ -323,7 +325,7 @@ template <typename T, int H, int V, typename A>
 __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>::NREG],
                                       T (&gr)[F16Cfg<H>::NREG], const bool GRAD, bool has_temp, T temp, int c, int g,
                                       int lane, T* lik_out = nullptr, T* prior_out = nullptr) {
-  typedef F16Cfg<H> K;
+  typedef F16Cfg<H, (V & 2) ? 4 : 2> K;
   typedef Lay<T> L;
   constexpr int MT = K::MT;
   const int pc = L::perm(c);  // this lane's row c sits at column pc of the transpose buffers
@@ -355,10 +357,10 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       v4<T> acc = f16_ld4(lw + K::O_B0 + 16 * m + 4 * g);
-      acc = mfma16<T>(lw[K::O_W0A + (m * 4) * 64 + lane], xb[0], acc);
+      acc = mfma16<T>(lw[K::O_W0A + (m * KS) * 64 + lane], xb[0], acc);
 #pragma unroll
       for (int s4 = 1; s4 < KS; ++s4)
-        if (s4 < a.ks0) acc = mfma16<T>(lw[K::O_W0A + (m * 4 + s4) * 64 + lane], xb[s4], acc);
+        if (s4 < a.ks0) acc = mfma16<T>(lw[K::O_W0A + (m * KS + s4) * 64 + lane], xb[s4], acc);
       H0[m] = acc;
     }
     f16_act_tiles<T, MT>(a.act0, H0);
@@ -566,7 +568,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 template <typename T, int H, int V, typename A>
 __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t chain, const int it, const int c,
                                               const int g, const int lane) {
-  typedef F16Cfg<H> K;
+  typedef F16Cfg<H, (V & 2) ? 4 : 2> K;
   // later iterations of one launch read what this wave's lanes wrote at the end of the previous one
   if (it > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const uint64_t iter = a.iter + (uint64_t)it;
@@ -586,7 +588,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   }
 
   if (mode == F16_GRAD) {
-    f16_write_images<T, H>(lw, th, a, c, g);
+    f16_write_images<T, H, (V & 2) ? 4 : 2>(lw, th, a, c, g);
     T lik, prior;
     const T t = f16_eval<T, H, V>(a, lw, th, gr, a.grad != nullptr, has_temp, temp, c, g, lane, &lik, &prior);
     if (a.grad) {
@@ -649,7 +651,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
       }
     }
     f16_fence();  // the staged normals have been read; the evaluation reuses that LDS
-    f16_write_images<T, H>(lw, p, a, c, g);
+    f16_write_images<T, H, (V & 2) ? 4 : 2>(lw, p, a, c, g);
     const T tv = f16_eval<T, H, V>(a, lw, p, gp, mode == F16_MALA, has_temp, temp, c, g, lane);
     const T t_old = a.target[chain];
     T log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
@@ -723,7 +725,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     if (kk > 0) {
       F16_EACH(k) th[k] = th[k] + eps * p[k];
     }
-    f16_write_images<T, H>(lw, th, a, c, g);
+    f16_write_images<T, H, (V & 2) ? 4 : 2>(lw, th, a, c, g);
     t = f16_eval<T, H, V>(a, lw, th, gr, true, has_temp, temp, c, g, lane);
     const T w = (kk > 0 && kk < a.L) ? eps : T(0.5) * eps;
     F16_EACH(k) p[k] = p[k] + w * gr[k];
@@ -786,7 +788,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
 // takes each through all iterations of the launch (chain-major, as ey_mfma32.hip).
 template <typename T, int H, int WAVES, int V>
 __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4) k_fused16(F16Args<T> a) {
-  typedef F16Cfg<H> K;
+  typedef F16Cfg<H, (V & 2) ? 4 : 2> K;
   extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int lane = threadIdx.x & 63;
@@ -889,7 +891,7 @@ int ey_fused16_set_data(ey_plan* pl, hipStream_t s) {
 
 template <typename T, int H, int WAVES, int V>
 static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
-  const size_t bytes = sizeof(T) * (size_t)WAVES * F16Cfg<H>::WAVE_ELEMS;
+  const size_t bytes = sizeof(T) * (size_t)WAVES * F16Cfg<H, (V & 2) ? 4 : 2>::WAVE_ELEMS;
   EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, V>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   const unsigned grid = (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256);
