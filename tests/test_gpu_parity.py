@@ -1953,6 +1953,41 @@ def test_generic_run_with_attached_moments_fails_before_it_advances_the_chains()
 
 
 # --------------------------------------------------------------------------------------------- multivariate diagnostics
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EY_FUZZ_SEEDS", "8"))))
+def test_multivariate_inse_on_random_chains_vs_the_reference_port(seed):
+    """ey_inse_multivariate on random AR(1)-like chains of every width the kernel takes (p = 1 .. 16), short and long, both
+    layouts, against the per-chain port of the reference's estimator (stats.inse_mc_cov, pinned by G7); chains for which
+    the reference raises 'Not enough samples' must come back as NaN."""
+    import eeyore_amd.stats as st
+    from eeyore_amd.stats import batched
+    rng = np.random.default_rng(500 + seed)
+    p = int(rng.choice([1, 2, 3, 7, 12, 16]))
+    n = int(rng.choice([4, 9, 30, 121, 500]))
+    C = int(rng.choice([1, 5, 33]))
+    phi = rng.uniform(-0.5, 0.95, size=(C, 1, p))
+    e = rng.standard_normal((C, n, p))
+    y = np.empty_like(e)
+    y[:, 0] = e[:, 0]
+    for t in range(1, n):
+        y[:, t] = phi[:, 0] * y[:, t - 1] + e[:, t]
+    y = y @ rng.standard_normal((p, p)) * 0.3 + rng.standard_normal((C, 1, p))  # correlated components, shifted means
+    for layout, xs in (("cnp", _t(y)), ("ncp", _t(y).permute(1, 0, 2).contiguous())):
+        r = batched.inse_multivariate(xs, layout)
+        sig = r["sig"].cpu().numpy()
+        np.testing.assert_allclose(r["mean"].cpu().numpy(), y.mean(1), rtol=1e-11, atol=1e-13)
+        for i in range(C):
+            try:
+                want = st.inse_mc_cov(torch.tensor(y[i])).numpy()
+            except RuntimeError:  # 'Not enough samples' (inse_mc_cov.py:45-46)
+                assert np.isnan(sig[i]).all(), (seed, i, p, n)
+                continue
+            # entries that cancel to rounding noise of the data's own scale are compared on that scale
+            scale = max(np.abs(want).max(), float(st.cov(torch.tensor(y[i]), rowvar=False).abs().max()))
+            np.testing.assert_allclose(sig[i], want, rtol=1e-8, atol=1e-11 * scale, err_msg=str((seed, i, p, n, layout)))
+            np.testing.assert_allclose(r["cov"][i].cpu().numpy(), st.cov(torch.tensor(y[i]), rowvar=False).numpy(),
+                                       rtol=1e-10, atol=1e-13)
+
+
 def test_multivariate_inse_ess_rhat_on_the_device_match_the_reference():
     """ey_inse_multivariate (one workgroup per chain) against the reference's own numbers on its examples/stats chains
     (G7: inse_mc_cov, cov, multi_ess per chain, multi_rhat with W and B), in both storage layouts and in f32 storage."""
