@@ -26,6 +26,7 @@
 //   w2[o]    = W2[o][k = c]                 (ditto)      b1 = b1[c], b0 = b0[c], b2[o] uniform
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "ey_common.h"
 
@@ -70,6 +71,7 @@ struct MfArgs {
   float mu0, iv0;
   float prior_const;
   int ntiles;
+  int short_last;      // 1: the last row tile holds at most 24 rows (its fourth 8-row k-group is all padding)
   int64_t C;
   float* theta;        // [C,P] in/out
   float* target;       // [C]
@@ -353,8 +355,10 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
   const bool ph_on = (blockIdx.x & 63) == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
   unsigned long long ph_t = ph_on ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
-#pragma unroll 1
-  for (int t = 0; t < A.ntiles; ++t) {
+  // One 32-row tile.  SG = the 8-row k-groups of the row-contracting products (dW2, dW1, dW0) that hold rows: 4, or 3
+  // in the copy the last tile of a batch takes when its rows 24..31 are all padding (a quarter of its dW1 product).
+  auto tile = [&](const int t, auto sg_tag) __attribute__((always_inline)) {
+    constexpr int SG = decltype(sg_tag)::value;
     const float* xt = xs + t * XTILE_FLOATS;
     const int pace_theirs = pace_post(pc, lane);
     // ---- F0: H0^T = sigmoid(W0 X^T + b0)                                  (mlp.py:45-50)
@@ -410,7 +414,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     const float ssum = e0 + e1 + e2;
     const float llab = lab == 0 ? l0 : (lab == 1 ? l1 : l2);
     if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
-    if (!GRAD) continue;  // nothing was written to LDS in this tile
+    if (!GRAD) return;  // nothing was written to LDS in this tile
     const float rs = __builtin_amdgcn_rcpf(ssum);
     float d2[3];
     d2[0] = valid ? ((lab == 0 ? 1.0f : 0.0f) - e0 * rs) : 0.0f;
@@ -429,7 +433,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     PH(3);
     // ---- B2(2): dW2[o][k] += sum_n delta2[n][o] H1[n][k]                    (contracts over rows: transposed reads)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SG; ++s) {
       const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
       const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_D2BUF + jj * D2S + h * 16 + 4 * s);
       dW2a = mfma4(du[0], hu[0], dW2a);
@@ -459,7 +463,9 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
     f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int r = 4 * SG; r < 16; ++r) H0U[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SG; ++s) {
       const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
       const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB1 + c * TS36 + 8 * s + 4 * h);
 #pragma unroll
@@ -483,7 +489,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
     const float* x2 = xt + 160 + jj * D2S + h * 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SG; ++s) {
       const f32x4 du = {D0u[4 * s], D0u[4 * s + 1], D0u[4 * s + 2], D0u[4 * s + 3]};
       const f32x4 xu = *reinterpret_cast<const f32x4*>(x2 + 4 * s);
       dW0a = mfma4(du[0], xu[0], dW0a);
@@ -494,7 +500,11 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     }
     wave_lds_fence();
     PH(9);
-  }
+  };
+  const int nfull = A.ntiles - A.short_last;
+#pragma unroll 1
+  for (int t = 0; t < nfull; ++t) tile(t, std::integral_constant<int, 4>());
+  if (A.short_last) tile(nfull, std::integral_constant<int, 3>());
   if (PARK) {
     int at = WAVE_FLOATS + lane;
     asm volatile("" : "+v"(at));  // an offset the compiler cannot match with the stores above: no forwarding
@@ -1011,6 +1021,7 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.iv0 = (float)pl->prior_iv0;
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
+  a.short_last = (m.N - 32 * (a.ntiles - 1)) <= 24 ? 1 : 0;
   a.balance = (g_variant.load() & 2) ? 0 : 1;
   if (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) {
     a.mom_s1 = pl->mom_s1;
