@@ -14,6 +14,8 @@
 // LDS); the weight gradient is parameter-parallel (lane <-> parameter, contraction over the tile's rows);
 // the input gradient is row-parallel again.  Tile columns use a stride of 65 elements so that the
 // parameter-parallel reads (different rows j, same column n) hit different LDS banks.
+#include <atomic>
+
 #include "ey_common.h"
 
 #define TS 65
@@ -92,6 +94,222 @@ static size_t lds_bytes(const EyModel& m, int nvec, size_t esz) {
   return esz * (nvec * Ppad + (size_t)m.hrows * TS + 2 * (size_t)m.dmax * TS);
 }
 
+// ------------------------------------------------------------------ register-resident evaluation of tiny models
+// The models of the reference's own tests and examples are tiny (MLP(2-2-1), (2-3-2-1), (4-3-3): P = 9 .. 27).  The
+// tile loop of eval_target below walks such a model through LDS one dependent round trip after the other (a (j, i)
+// loop nest of runtime extents, every load behind the previous store): ~20 000 cycles per 64-row tile of MLP(2-3-2-1).
+// For at most three layers, at most 8 inputs and every other width at most 4, the same arithmetic fits in registers:
+// lane <-> row, the weights as wave-uniform register copies (read once per evaluation from the position in LDS), a row's
+// activations and deltas in registers, the weight gradient accumulated PER LANE over the lane's rows and summed over
+// the lanes once per evaluation (DPP adds in a fixed order: deterministic).  Every loop is unrolled to its maximum
+// extent with wave-uniform guards, so all register arrays are indexed by constants.
+#define TINY_D0 8
+#define TINY_DH 4
+bool ey_generic_tiny_ok(const EyModel& m) {
+  if (m.nl < 1 || m.nl > 3 || m.dims[0] > TINY_D0) return false;
+  for (int k = 1; k <= m.nl; ++k)
+    if (m.dims[k] > TINY_DH) return false;
+  return true;
+}
+
+template <int CTRL, int ROWMASK, typename T>
+__device__ __forceinline__ T tiny_dpp(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+  } else {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  }
+}
+// wave total as a uniform value: adds inside each 16-lane row, then row_bcast:15 / :31 carry the row totals to lane 63
+template <typename T>
+__device__ __forceinline__ T tiny_wsum(T v) {
+  v += tiny_dpp<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += tiny_dpp<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += tiny_dpp<0x141, 0xF>(v);  // row_half_mirror
+  v += tiny_dpp<0x140, 0xF>(v);  // row_mirror
+  v += tiny_dpp<0x142, 0xA>(v);  // row_bcast:15 (a masked-off row adds the 0 of update_dpp's old value)
+  v += tiny_dpp<0x143, 0xC>(v);  // row_bcast:31
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  } else {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  }
+}
+
+// activation of up to four values with the (wave-uniform) switch outside the element loop
+template <typename T>
+__device__ __forceinline__ void tiny_act(int code, T (&h)[TINY_DH], int n) {
+  if (code == EY_ACT_NONE) return;
+#pragma unroll
+  for (int j = 0; j < TINY_DH; ++j)
+    if (j < n) h[j] = act_fn<T>(code, h[j]);
+}
+
+// The row loop of eval_target for a tiny model: the sum of the rows' log-likelihood terms (per lane: the caller adds
+// the lanes) and, when GRAD, the gradient of the log-likelihood in gr (LDS, canonical layout).
+template <typename T, bool GRAD>
+__device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, bool has_temp, T temp, T* row_out) {
+  const int lane = threadIdx.x;
+  const T* x = static_cast<const T*>(m.x);
+  const T* y = static_cast<const T*>(m.y);
+  const int nl = m.nl, dK = m.dims[nl], d0 = m.dims[0];
+  // wave-uniform register copies of the position, padded to [3][4][8 | 4] (+ [3][4] biases)
+  T W[3][TINY_DH][TINY_D0], B[3][TINY_DH], G[3][TINY_DH][TINY_D0], GB[3][TINY_DH];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k < nl) {
+      const int din = m.dims[k], dout = m.dims[k + 1];
+#pragma unroll
+      for (int j = 0; j < TINY_DH; ++j) {
+#pragma unroll
+        for (int i = 0; i < (k == 0 ? TINY_D0 : TINY_DH); ++i) {
+          W[k][j][i] = (j < dout && i < din) ? th[m.woff[k] + j * din + i] : T(0);
+          G[k][j][i] = T(0);
+        }
+        B[k][j] = (j < dout && m.boff[k] >= 0) ? th[m.boff[k] + j] : T(0);
+        GB[k][j] = T(0);
+      }
+    }
+  }
+  T lik = T(0);
+  for (int n0 = 0; n0 < m.N; n0 += WAVE) {
+    const int n = n0 + lane;
+    const bool valid = n < m.N;
+    T h0[TINY_D0], h[3][TINY_DH];  // h[k] = output of layer k
+#pragma unroll
+    for (int i = 0; i < TINY_D0; ++i) h0[i] = (i < d0 && valid) ? x[(size_t)n * d0 + i] : T(0);
+    // ---- forward (mlp.py:45-50)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k < nl) {
+        const int din = m.dims[k], dout = m.dims[k + 1];
+#pragma unroll
+        for (int j = 0; j < TINY_DH; ++j) {
+          T g = T(0);
+          if (j < dout) {
+#pragma unroll
+            for (int i = 0; i < (k == 0 ? TINY_D0 : TINY_DH); ++i)
+              if (i < din) g += (k == 0 ? h0[i] : h[k == 0 ? 0 : k - 1][i]) * W[k][j][i];
+            g += B[k][j];  // 0 when the layer has no bias
+          }
+          h[k][j] = g;
+        }
+        tiny_act<T>(m.act[k], h[k], dout);
+      }
+    }
+    // ---- likelihood and output delta (constants.py:15-18, loss.py:1-11): the arithmetic of eval_target
+    T out[TINY_DH], d[TINY_DH];
+#pragma unroll
+    for (int j = 0; j < TINY_DH; ++j) {
+      out[j] = nl == 1 ? h[0][j] : (nl == 2 ? h[1][j] : h[2][j]);
+      d[j] = T(0);
+    }
+    const int act_out = m.act[nl - 1];
+    T row_lik = T(0);
+    if (m.lik == EY_LIK_BCE_SUM) {
+#pragma unroll
+      for (int j = 0; j < TINY_DH; ++j)
+        if (j < dK) {
+          const T o = out[j];
+          const T yy = valid ? y[(size_t)n * dK + j] : T(0);
+          const T term = Num<T>::log(o) * yy + Num<T>::log(T(1) - o) * (T(1) - yy);
+          if (valid) lik += term;
+          row_lik += term;
+          if (GRAD) {
+            const T dd = (yy / o - (T(1) - yy) / (T(1) - o)) * dact_fn<T>(act_out, o);
+            d[j] = valid ? dd : T(0);
+          }
+        }
+    } else {
+      const int lab = valid ? m.labels[n] : 0;
+      T mx = out[0];
+#pragma unroll
+      for (int j = 1; j < TINY_DH; ++j)
+        if (j < dK) mx = fmax(mx, out[j]);
+      T ssum = T(0), olab = out[0];
+#pragma unroll
+      for (int j = 0; j < TINY_DH; ++j)
+        if (j < dK) {
+          ssum += Num<T>::exp(out[j] - mx);
+          if (j == lab) olab = out[j];
+        }
+      row_lik = olab - (mx + Num<T>::log(ssum));
+      if (valid) lik += row_lik;
+      if (GRAD) {
+#pragma unroll
+        for (int j = 0; j < TINY_DH; ++j)
+          if (j < dK) {
+            const T dd = ((j == lab ? T(1) : T(0)) - Num<T>::exp(out[j] - mx) / ssum) * dact_fn<T>(act_out, out[j]);
+            d[j] = valid ? dd : T(0);
+          }
+      }
+    }
+    if (row_out && valid) row_out[n] = has_temp ? row_lik * temp : row_lik;
+    if (GRAD) {
+      // ---- backward: dW_k += delta_k (x) h_{k-1}, db_k += delta_k, delta_{k-1} = (W_k^T delta_k) * act'(h_{k-1})
+#pragma unroll
+      for (int k = 2; k >= 0; --k) {
+        if (k < nl) {
+          const int din = m.dims[k], dout = m.dims[k + 1];
+#pragma unroll
+          for (int j = 0; j < TINY_DH; ++j)
+            if (j < dout) {
+#pragma unroll
+              for (int i = 0; i < (k == 0 ? TINY_D0 : TINY_DH); ++i)
+                if (i < din) G[k][j][i] += d[j] * (k == 0 ? h0[i] : h[k == 0 ? 0 : k - 1][i]);
+              GB[k][j] += d[j];
+            }
+          if (k > 0) {
+            T dn[TINY_DH];
+#pragma unroll
+            for (int i = 0; i < TINY_DH; ++i) {
+              T a = T(0);
+              if (i < din) {
+#pragma unroll
+                for (int j = 0; j < TINY_DH; ++j)
+                  if (j < dout) a += d[j] * W[k][j][i];
+                a *= dact_fn<T>(m.act[k - 1], h[k - 1][i]);
+              }
+              dn[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < TINY_DH; ++i) d[i] = dn[i];
+          }
+        }
+      }
+    }
+  }
+  if (GRAD) {
+    // ---- the lanes' partial gradients, summed in a fixed order, into the canonical layout
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k < nl) {
+        const int din = m.dims[k], dout = m.dims[k + 1];
+#pragma unroll
+        for (int j = 0; j < TINY_DH; ++j)
+          if (j < dout) {
+#pragma unroll
+            for (int i = 0; i < (k == 0 ? TINY_D0 : TINY_DH); ++i)
+              if (i < din) {
+                const T tot = tiny_wsum<T>(G[k][j][i]);
+                if (lane == 0) gr[m.woff[k] + j * din + i] = tot;
+              }
+            if (m.boff[k] >= 0) {
+              const T tot = tiny_wsum<T>(GB[k][j]);
+              if (lane == 0) gr[m.boff[k] + j] = tot;
+            }
+          }
+      }
+    }
+  }
+  return lik;
+}
+
 // log-target (and gradient when GRAD) of the position in `th`; result broadcast to every lane.
 // gr receives the gradient of the (tempered) log-target.  lik/prior are the tempered parts.
 // the chain's N(0,1) stream for elements 0..P-1 into an LDS array, one block of four per lane and round
@@ -107,7 +325,7 @@ __device__ inline void fill_normals(T* dst, const EyRng& rn, int P) {
   __syncthreads();
 }
 
-template <typename T, bool GRAD>
+template <typename T, bool GRAD, bool TINY = false>
 __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, bool has_temp, T temp, T* lik_out,
                          T* prior_out, T* row_out = nullptr) {
   const int lane = threadIdx.x;
@@ -115,10 +333,14 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
   const T* y = static_cast<const T*>(m.y);
   const int nl = m.nl;
   const int dK = m.dims[nl];
+  T lik = T(0);
+  if constexpr (TINY) {
+    __syncthreads();  // the position written by the caller is visible
+    lik = tiny_rows<T, GRAD>(m, th, gr, has_temp, temp, row_out);
+  } else {
   if (GRAD) {
     for (int i = lane; i < m.P; i += WAVE) gr[i] = T(0);
   }
-  T lik = T(0);
   for (int n0 = 0; n0 < m.N; n0 += WAVE) {
     const int rows = min(WAVE, m.N - n0);
     const int n = n0 + lane;
@@ -212,6 +434,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
       }
     }
   }
+  }  // !TINY
   __syncthreads();
   lik = wave_sum(lik);
   // ---- prior (bayesian_model.py:46-50), elementwise Normal(mu, sigma)
@@ -237,7 +460,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
 }
 
 // ----------------------------------------------------------------------------------------------- kernels
-template <typename T, bool GRAD>
+template <typename T, bool GRAD, bool TINY>
 __global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, const T* temp, T* lik_o, T* prior_o,
                                                      T* target_o, T* grad_o, T* rows_o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -248,7 +471,7 @@ __global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, 
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
   T lik, prior;
-  const T t = eval_target<T, GRAD>(m, l, l.th, l.gr, ht, tc, &lik, &prior, rows_o ? rows_o + c * m.N : nullptr);
+  const T t = eval_target<T, GRAD, TINY>(m, l, l.th, l.gr, ht, tc, &lik, &prior, rows_o ? rows_o + c * m.N : nullptr);
   if (lane == 0) {
     if (lik_o) lik_o[c] = lik;
     if (prior_o) prior_o[c] = prior;
@@ -259,7 +482,7 @@ __global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, 
   }
 }
 
-template <typename T>
+template <typename T, bool TINY>
 __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T* grad, const T* p0, const T* u_in,
                                               T step, const T* step_vec, int L, const T* temp, uint64_t seed,
                                               uint64_t iter0, uint64_t chain_offset, int recompute,
@@ -296,12 +519,12 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
   const T h_cur = -t_cur + T(0.5) * kin;  // hmc.py:91-98,137
   __syncthreads();
   T t = t_cur;
-  if (recompute) t = eval_target<T, true>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);  // hmc.py:104
+  if (recompute) t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);  // hmc.py:104
   // leapfrog (hmc.py:100-124); grad_potential = -grad
   for (int i = lane; i < P; i += WAVE) p[i] = p[i] + T(0.5) * eps * l.gr[i];
   for (int k = 1; k <= L; ++k) {
     for (int i = lane; i < P; i += WAVE) l.th[i] = l.th[i] + eps * p[i];
-    t = eval_target<T, true>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+    t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
     const T w = (k < L) ? eps : T(0.5) * eps;
     for (int i = lane; i < P; i += WAVE) p[i] = p[i] + w * l.gr[i];
   }
@@ -340,7 +563,7 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
 }
 
 // HMC.leapfrog as a standalone operator (hmc.py:100-124): L+1 evaluations, momentum negated.
-template <typename T>
+template <typename T, bool TINY>
 __global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, T step, const T* step_vec, int L,
                                                    const T* temp, T* target, T* grad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -357,11 +580,11 @@ __global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, 
     p[i] = pio[c * P + i];
   }
   __syncthreads();
-  T t = eval_target<T, true>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+  T t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
   for (int i = lane; i < P; i += WAVE) p[i] = p[i] + T(0.5) * eps * l.gr[i];
   for (int k = 1; k <= L; ++k) {
     for (int i = lane; i < P; i += WAVE) l.th[i] = l.th[i] + eps * p[i];
-    t = eval_target<T, true>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+    t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
     const T w = (k < L) ? eps : T(0.5) * eps;
     for (int i = lane; i < P; i += WAVE) p[i] = p[i] + w * l.gr[i];
   }
@@ -373,7 +596,7 @@ __global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, 
   if (lane == 0) target[c] = t;
 }
 
-template <typename T>
+template <typename T, bool TINY>
 __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T* grad, const T* z_in, const T* u_in,
                                                T step, T sqrt_step, const T* step_vec, const T* temp, uint64_t seed,
                                                uint64_t iter0, uint64_t chain_offset, unsigned char* accepted,
@@ -410,7 +633,7 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
     qf += d * d;
   }
   __syncthreads();
-  const T tv = eval_target<T, true>(m, l, prop, gp, ht, tc, nullptr, nullptr);
+  const T tv = eval_target<T, true, TINY>(m, l, prop, gp, ht, tc, nullptr, nullptr);
   T qb = T(0);
   for (int i = lane; i < P; i += WAVE) {
     const T loc2 = prop[i] + T(0.5) * eps * gp[i];
@@ -447,7 +670,7 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
   }
 }
 
-template <typename T>
+template <typename T, bool TINY>
 __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, const T* z_in, const T* u_in,
                                              const T* scale, const T* temp, uint64_t seed, uint64_t iter0,
                                              uint64_t chain_offset, unsigned char* accepted, T* log_rate_o, EyRun run,
@@ -469,7 +692,7 @@ __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, con
     l.th[i] = theta[c * P + i] + scale[i] * zi;  // NormalKernel(theta, scale).sample()
   }
   __syncthreads();
-  const T tv = eval_target<T, false>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+  const T tv = eval_target<T, false, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
   const T log_rate = tv - t_state;  // symmetric kernel (metropolis_hastings.py:50)
   const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
   const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
@@ -495,6 +718,21 @@ __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, con
 }
 
 // ----------------------------------------------------------------------------------------------- host launchers
+
+// Where the register-resident evaluation pays (tools/tiny_scan.py, profiles/r02_tiny_scan.txt): it has a fixed cost per
+// evaluation (the register copies of the position, one wave reduction per parameter), so it is taken from two 64-row
+// tiles up: 1.6-2.8 x the LDS loop at a few hundred chains, where that loop's dependent round trips are exposed, 1.1-1.7 x
+// in f32 when the chains fill the chip; in f64 (one wave per SIMD) a chip full of chains is 0.75-1.1 x.  The rule looks
+// at the batch only, not at the number of chains: the arithmetic a chain sees must not depend on how many chains (or
+// GPUs) run beside it.  ey_debug_set_variant bit 8: never (A/B, tests), bit 9: whenever the model qualifies.
+std::atomic<int> g_ey_no_tiny{0}, g_ey_force_tiny{0};
+static bool use_tiny(const ey_plan* pl) {
+  if (!ey_generic_tiny_ok(pl->m) || g_ey_no_tiny.load()) return false;
+  return g_ey_force_tiny.load() || pl->m.N >= 128;
+}
+#define EY_TINY_DISPATCH(fn, ...)                                                                    \
+  (use_tiny(pl) ? (pl->dtype == EY_F32 ? fn<float, true>(__VA_ARGS__) : fn<double, true>(__VA_ARGS__)) \
+                : (pl->dtype == EY_F32 ? fn<float, false>(__VA_ARGS__) : fn<double, false>(__VA_ARGS__)))
 template <typename K>
 static int prep(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) EY_FAIL(EY_ERR_UNSUPPORTED, "generic kernel: model does not fit the 160 KiB LDS of a CU");
@@ -504,18 +742,18 @@ static int prep(K kernel, size_t bytes) {
   return EY_OK;
 }
 
-template <typename T>
+template <typename T, bool TINY>
 static int launch_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                              void* target, void* grad, hipStream_t s, void* rows = nullptr) {
   const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
   int rc;
   if (grad) {
-    if ((rc = prep(k_log_target<T, true>, bytes))) return rc;
-    hipLaunchKernelGGL((k_log_target<T, true>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
+    if ((rc = prep(k_log_target<T, true, TINY>, bytes))) return rc;
+    hipLaunchKernelGGL((k_log_target<T, true, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
                        (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)grad, (T*)nullptr);
   } else {
-    if ((rc = prep(k_log_target<T, false>, bytes))) return rc;
-    hipLaunchKernelGGL((k_log_target<T, false>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
+    if ((rc = prep(k_log_target<T, false, TINY>, bytes))) return rc;
+    hipLaunchKernelGGL((k_log_target<T, false, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
                        (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)nullptr, (T*)rows);
   }
   EY_HIP(hipGetLastError());
@@ -524,25 +762,22 @@ static int launch_log_target(ey_plan* pl, const void* theta, const void* temp, i
 
 int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                           void* target, void* grad, hipStream_t s) {
-  return pl->dtype == EY_F32 ? launch_log_target<float>(pl, theta, temp, C, lik, prior, target, grad, s)
-                             : launch_log_target<double>(pl, theta, temp, C, lik, prior, target, grad, s);
+  return EY_TINY_DISPATCH(launch_log_target, pl, theta, temp, C, lik, prior, target, grad, s);
 }
 
 int ey_generic_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, hipStream_t s) {
-  return pl->dtype == EY_F32
-             ? launch_log_target<float>(pl, theta, temp, C, nullptr, nullptr, nullptr, nullptr, s, rows)
-             : launch_log_target<double>(pl, theta, temp, C, nullptr, nullptr, nullptr, nullptr, s, rows);
+  return EY_TINY_DISPATCH(launch_log_target, pl, theta, temp, C, nullptr, nullptr, nullptr, nullptr, s, rows);
 }
 
-template <typename T>
+template <typename T, bool TINY>
 static int launch_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                       const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                       uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
                       hipStream_t s, const EyRun* run) {
   const size_t bytes = lds_bytes(pl->m, 3, sizeof(T));
   int rc;
-  if ((rc = prep(k_hmc<T>, bytes))) return rc;
-  hipLaunchKernelGGL((k_hmc<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
+  if ((rc = prep(k_hmc<T, TINY>, bytes))) return rc;
+  hipLaunchKernelGGL((k_hmc<T, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
                      (const T*)p0, (const T*)u, (T)step, (const T*)step_vec, L, (const T*)temp, seed, iter,
                      chain_offset, (int)((flags & EY_RECOMPUTE_INITIAL_GRAD) != 0), (unsigned char*)accepted, (T*)rate,
                      (T*)hcur, (T*)hprop, run ? run->n_iters : 1, run ? (T*)run->samples : nullptr,
@@ -556,20 +791,17 @@ int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const voi
                    const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                    uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
                    hipStream_t s, const EyRun* run) {
-  return pl->dtype == EY_F32
-             ? launch_hmc<float>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset,
-                                 flags, accepted, rate, hcur, hprop, s, run)
-             : launch_hmc<double>(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset,
-                                  flags, accepted, rate, hcur, hprop, s, run);
+  return EY_TINY_DISPATCH(launch_hmc, pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset,
+                                 flags, accepted, rate, hcur, hprop, s, run);
 }
 
-template <typename T>
+template <typename T, bool TINY>
 static int launch_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                            int64_t C, void* target, void* grad, hipStream_t s) {
   const size_t bytes = lds_bytes(pl->m, 3, sizeof(T));
   int rc;
-  if ((rc = prep(k_leapfrog<T>, bytes))) return rc;
-  hipLaunchKernelGGL((k_leapfrog<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)p, (T)step,
+  if ((rc = prep(k_leapfrog<T, TINY>, bytes))) return rc;
+  hipLaunchKernelGGL((k_leapfrog<T, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)p, (T)step,
                      (const T*)step_vec, L, (const T*)temp, (T*)target, (T*)grad);
   EY_HIP(hipGetLastError());
   return EY_OK;
@@ -577,20 +809,19 @@ static int launch_leapfrog(ey_plan* pl, void* theta, void* p, double step, const
 
 int ey_generic_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                         int64_t C, void* target, void* grad, hipStream_t s) {
-  return pl->dtype == EY_F32 ? launch_leapfrog<float>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s)
-                             : launch_leapfrog<double>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
+  return EY_TINY_DISPATCH(launch_leapfrog, pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
 }
 
-template <typename T>
+template <typename T, bool TINY>
 static int launch_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                        const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                        uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run) {
   const EyRun one = {1, nullptr, nullptr, nullptr, nullptr};
   const size_t bytes = lds_bytes(pl->m, 4, sizeof(T));
   int rc;
-  if ((rc = prep(k_mala<T>, bytes))) return rc;
+  if ((rc = prep(k_mala<T, TINY>, bytes))) return rc;
   // scale = np.sqrt(step) on the python float, then cast to the model dtype (mala.py:39)
-  hipLaunchKernelGGL((k_mala<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
+  hipLaunchKernelGGL((k_mala<T, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
                      (const T*)z, (const T*)u, (T)step, (T)sqrt(step), (const T*)step_vec, (const T*)temp, seed, iter,
                      chain_offset, (unsigned char*)accepted, (T*)log_rate, run ? *run : one, C);
   EY_HIP(hipGetLastError());
@@ -600,21 +831,19 @@ static int launch_mala(ey_plan* pl, void* theta, void* target, void* grad, const
 int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                     const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                     uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run) {
-  return pl->dtype == EY_F32 ? launch_mala<float>(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter,
-                                                  chain_offset, accepted, log_rate, s, run)
-                             : launch_mala<double>(pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter,
-                                                   chain_offset, accepted, log_rate, s, run);
+  return EY_TINY_DISPATCH(launch_mala, pl, theta, target, grad, z, u, step, step_vec, temp, C, seed, iter,
+                                                  chain_offset, accepted, log_rate, s, run);
 }
 
-template <typename T>
+template <typename T, bool TINY>
 static int launch_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                      const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
                      void* log_rate, hipStream_t s, const EyRun* run) {
   const EyRun one = {1, nullptr, nullptr, nullptr, nullptr};
   const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
   int rc;
-  if ((rc = prep(k_mh<T>, bytes))) return rc;
-  hipLaunchKernelGGL((k_mh<T>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (const T*)z,
+  if ((rc = prep(k_mh<T, TINY>, bytes))) return rc;
+  hipLaunchKernelGGL((k_mh<T, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (const T*)z,
                      (const T*)u, (const T*)scale, (const T*)temp, seed, iter, chain_offset, (unsigned char*)accepted,
                      (T*)log_rate, run ? *run : one, C);
   EY_HIP(hipGetLastError());
@@ -624,8 +853,6 @@ static int launch_mh(ey_plan* pl, void* theta, void* target, const void* z, cons
 int ey_generic_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                   const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
                   void* log_rate, hipStream_t s, const EyRun* run) {
-  return pl->dtype == EY_F32 ? launch_mh<float>(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset,
-                                                accepted, log_rate, s, run)
-                             : launch_mh<double>(pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset,
-                                                 accepted, log_rate, s, run);
+  return EY_TINY_DISPATCH(launch_mh, pl, theta, target, z, u, scale, temp, C, seed, iter, chain_offset,
+                                                accepted, log_rate, s, run);
 }

@@ -943,14 +943,18 @@ extern std::atomic<int> g_ey_force_large;
 extern std::atomic<int> g_ey_no_dma;
 extern std::atomic<int> g_ey_no_tail;
 extern std::atomic<int> g_ey_no_fuse;
+extern std::atomic<int> g_ey_no_tiny, g_ey_force_tiny;
 extern "C" int ey_debug_set_variant(int v) {
   const int old = g_variant.load() | (g_ey_force_large.load() << 4) | (g_ey_no_dma.load() << 5) |
-                  (g_ey_no_tail.load() << 6) | (g_ey_no_fuse.load() << 7);
+                  (g_ey_no_tail.load() << 6) | (g_ey_no_fuse.load() << 7) | (g_ey_no_tiny.load() << 8) |
+                  (g_ey_force_tiny.load() << 9);
   g_variant.store(v & 15);
   g_ey_force_large.store((v >> 4) & 1);
   g_ey_no_dma.store((v >> 5) & 1);
   g_ey_no_tail.store((v >> 6) & 1);
   g_ey_no_fuse.store((v >> 7) & 1);
+  g_ey_no_tiny.store((v >> 8) & 1);
+  g_ey_force_tiny.store((v >> 9) & 1);
   return old;
 }
 

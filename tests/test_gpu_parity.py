@@ -749,7 +749,8 @@ def test_mfma32_serves_config3_and_matches_generic_kernel():
     assert 0 < oa["accepted"].sum().item() < C
 
 
-@pytest.mark.parametrize("N", [1, 31, 32, 33, 150, 160, 384, 768])
+# 24 | 25 and 56 | 57: either side of the peeled last tile (a last tile of at most 24 rows takes the three-k-group copy)
+@pytest.mark.parametrize("N", [1, 24, 25, 31, 32, 33, 56, 57, 150, 160, 384, 768])
 def test_mfma32_row_counts_vs_oracle(N):
     rec, pl = _cfg3_plan(N)
     assert pl.kernel == "mfma32"
@@ -971,6 +972,87 @@ def test_chain_stats_hip_pass_equals_torch_formulas():
         a, b = hip.summary(), ref.summary()
         np.testing.assert_allclose(a["rhat"].cpu().numpy(), b["rhat"].numpy(), rtol=1e-12)
         assert abs(a["acceptance"] - b["acceptance"]) < 1e-15
+
+
+# ------------------------------------------------------------------- tiny models: register-resident evaluation
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("dims,acts,bias,lik", [
+    ([2, 2, 1], [1, 1], [1, 1], 0),            # the reference's XOR net (tests/*mlp221*)
+    ([2, 3, 2, 1], [1, 1, 1], [1, 1, 1], 0),   # BASELINE configs[1]
+    ([4, 3, 3], [1, 0], [1, 1], 1),            # the Iris net of examples/samplers/mlp/iris
+    ([8, 4, 4, 4], [2, 3, 0], [1, 0, 1], 1),   # the largest shape it takes; tanh, relu, a layer without bias
+    ([3, 2], [1], [1], 0),                     # a single layer, two BCE outputs
+])
+def test_tiny_models_register_resident_evaluation(dims, acts, bias, lik, tag):
+    """The register-resident evaluation the generic kernels take for tiny models (ey_generic.hip, tiny_rows; by default
+    from 128 rows up) against the C oracle and against the LDS tile loop it stands in for, on every entry point and on
+    row counts either side of a 64-row tile.  ey_debug_set_variant bit 9 selects it for any batch, bit 8 never."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.plan import Plan
+    npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    tol = 1e-9 if tag == "f64" else 2e-4
+    rng = np.random.default_rng(sum(dims) + len(dims))
+    P = sum((dims[l] + bias[l]) * dims[l + 1] for l in range(len(dims) - 1))
+    mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+    C = 7
+    try:
+        for N in (5, 64, 150, 300):
+            x = rng.standard_normal((N, dims[0]))
+            y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(np.float64)
+            pl = Plan(dims, bias, acts, lik, dt, DEV)
+            assert pl.kernel == "generic"
+            pl.set_data(_t(x, dt), _t(y, dt))
+            pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+            co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, bias=bias, nthreads=4)
+            th0 = (0.4 * rng.standard_normal((C, P))).astype(npdt)
+            temps = np.array([1.0, 0.5, 0.25, 1.0, 0.1, 0.7, 0.3])
+            p0 = rng.standard_normal((C, P)).astype(npdt); u = rng.random(C).astype(npdt)
+            res = {}
+            for variant in (512, 256):
+                L.lib().ey_debug_set_variant(variant)
+                r = {}
+                r["t"], r["g"] = pl.log_target_grad(_t(th0, dt))
+                r["tt"], r["gt"] = pl.log_target_grad(_t(th0, dt), temp=_t(temps, dt))
+                r["lk"], r["pr"] = pl.log_target(_t(th0, dt))
+                r["rows"] = pl.log_lik_rows(_t(th0, dt))
+                th, tv, gg = _t(th0, dt).clone(), r["t"].clone(), r["g"].clone()
+                o = pl.hmc_step(th, tv, gg, 0.02, 4, p0=_t(p0, dt), u=_t(u, dt))
+                r["hmc_th"], r["hmc_hp"], r["hmc_acc"] = th, o["h_prop"], o["accepted"]
+                th, tv, gg = _t(th0, dt).clone(), r["t"].clone(), r["g"].clone()
+                o = pl.mala_step(th, tv, gg, 0.01, z=_t(p0, dt), u=_t(u, dt))
+                r["mala_lr"] = o["log_rate"]
+                th, tv = _t(th0, dt).clone(), r["t"].clone()
+                o = pl.mh_step(th, tv, torch.full((P,), 0.05, dtype=dt), z=_t(p0, dt), u=_t(u, dt))
+                r["mh_lr"] = o["log_rate"]
+                th, pp = _t(th0, dt).clone(), _t(p0, dt).clone()
+                r["lf_t"], r["lf_g"] = pl.leapfrog(th, pp, 0.02, 3)
+                r["lf_th"], r["lf_p"] = th, pp
+                res[variant] = {k: v.cpu().numpy().astype(np.float64) for k, v in r.items()}
+            a, b = res[512], res[256]
+            for k in a:  # the two evaluations differ in summation order only
+                if k == "hmc_acc":
+                    continue
+                scale = max(1.0, np.abs(b[k]).max())
+                np.testing.assert_allclose(a[k], b[k], rtol=0, atol=(1e-11 if tag == "f64" else 3e-5) * scale * 10, err_msg=f"{k} N={N}")
+            for c in range(C):  # and the register-resident one against the oracle
+                to, go, lo, po = co.log_target_grad(th0[c])
+                np.testing.assert_allclose(a["t"][c], to, rtol=tol, atol=tol * 10)
+                np.testing.assert_allclose(a["g"][c], go, rtol=tol * 10, atol=tol * 10 * max(1.0, np.abs(go).max()))
+                np.testing.assert_allclose([a["lk"][c], a["pr"][c]], [lo, po], rtol=tol, atol=tol * 10)
+                np.testing.assert_allclose(a["tt"][c], temps[c] * to, rtol=tol, atol=tol * 10)
+                np.testing.assert_allclose(a["gt"][c], temps[c] * go, rtol=tol * 10, atol=tol * 10 * max(1.0, np.abs(go).max()))
+            assert abs(a["rows"].sum(axis=1) - a["lk"]).max() <= tol * 10 * max(1.0, np.abs(a["lk"]).max())
+            tho, tvo, go = th0.copy(), a["t"].astype(npdt), a["g"].astype(npdt)
+            acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, 0.02, 4)
+            np.testing.assert_allclose(a["hmc_hp"], hp, rtol=tol * 10, atol=tol * 100 * max(1.0, np.abs(hp).max()))
+            rate = np.minimum(np.exp(np.minimum(hc - hp, 0)), 1)
+            decided = np.abs(u - rate) > (1e-8 if tag == "f64" else 5e-3)
+            np.testing.assert_array_equal(a["hmc_acc"][decided], acc[decided])
+            tho, tvo, go = th0.copy(), a["t"].astype(npdt), a["g"].astype(npdt)
+            _, lr = co.mala_draw(tho, tvo, go, p0, u, 0.01)
+            np.testing.assert_allclose(a["mala_lr"], lr, rtol=tol * 100, atol=tol * 1000 * max(1.0, np.abs(lr).max()))
+    finally:
+        L.lib().ey_debug_set_variant(0)
 
 
 # --------------------------------------------------------------------------------------------- generic kernel breadth
