@@ -112,6 +112,26 @@ bool ey_generic_tiny_ok(const EyModel& m) {
   return true;
 }
 
+// Shape policies of the evaluation below: TinyDyn reads the extents from the model at run time (every unrolled
+// iteration behind a wave-uniform guard: ~300 scalar branches per tile of MLP(2-3-2-1)); TinyFix<...> states them at
+// compile time, so the guards fold away and only the registers the shape needs remain.  TinyFix exists for the shapes
+// the reference's own tests and examples use (mlp.py's default 1-2-1, XOR 2-2-1 and 2-3-2-1, 2-3-3-2, Iris 4-3-3 and
+// 4-3-2-3).
+struct TinyOff {
+  static constexpr bool on = false;
+};
+struct TinyDyn {
+  static constexpr bool on = true;
+  static __device__ __forceinline__ int nl(const EyModel& m) { return m.nl; }
+  static __device__ __forceinline__ int dim(const EyModel& m, int k) { return m.dims[k]; }
+};
+template <int NL, int D0, int D1, int D2, int D3>
+struct TinyFix {
+  static constexpr bool on = true;
+  static __device__ __forceinline__ constexpr int nl(const EyModel&) { return NL; }
+  static __device__ __forceinline__ constexpr int dim(const EyModel&, int k) { return k == 0 ? D0 : (k == 1 ? D1 : (k == 2 ? D2 : D3)); }
+};
+
 template <int CTRL, int ROWMASK, typename T>
 __device__ __forceinline__ T tiny_dpp(T v) {
   if constexpr (sizeof(T) == 4) {
@@ -152,18 +172,18 @@ __device__ __forceinline__ void tiny_act(int code, T (&h)[TINY_DH], int n) {
 
 // The row loop of eval_target for a tiny model: the sum of the rows' log-likelihood terms (per lane: the caller adds
 // the lanes) and, when GRAD, the gradient of the log-likelihood in gr (LDS, canonical layout).
-template <typename T, bool GRAD>
+template <typename T, bool GRAD, class S>
 __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, bool has_temp, T temp, T* row_out) {
   const int lane = threadIdx.x;
   const T* x = static_cast<const T*>(m.x);
   const T* y = static_cast<const T*>(m.y);
-  const int nl = m.nl, dK = m.dims[nl], d0 = m.dims[0];
+  const int nl = S::nl(m), dK = S::dim(m, nl), d0 = S::dim(m, 0);
   // wave-uniform register copies of the position, padded to [3][4][8 | 4] (+ [3][4] biases)
   T W[3][TINY_DH][TINY_D0], B[3][TINY_DH], G[3][TINY_DH][TINY_D0], GB[3][TINY_DH];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     if (k < nl) {
-      const int din = m.dims[k], dout = m.dims[k + 1];
+      const int din = S::dim(m, k), dout = S::dim(m, k + 1);
 #pragma unroll
       for (int j = 0; j < TINY_DH; ++j) {
 #pragma unroll
@@ -187,7 +207,7 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (k < nl) {
-        const int din = m.dims[k], dout = m.dims[k + 1];
+        const int din = S::dim(m, k), dout = S::dim(m, k + 1);
 #pragma unroll
         for (int j = 0; j < TINY_DH; ++j) {
           T g = T(0);
@@ -255,7 +275,7 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
 #pragma unroll
       for (int k = 2; k >= 0; --k) {
         if (k < nl) {
-          const int din = m.dims[k], dout = m.dims[k + 1];
+          const int din = S::dim(m, k), dout = S::dim(m, k + 1);
 #pragma unroll
           for (int j = 0; j < TINY_DH; ++j)
             if (j < dout) {
@@ -289,7 +309,7 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (k < nl) {
-        const int din = m.dims[k], dout = m.dims[k + 1];
+        const int din = S::dim(m, k), dout = S::dim(m, k + 1);
 #pragma unroll
         for (int j = 0; j < TINY_DH; ++j)
           if (j < dout) {
@@ -325,7 +345,7 @@ __device__ inline void fill_normals(T* dst, const EyRng& rn, int P) {
   __syncthreads();
 }
 
-template <typename T, bool GRAD, bool TINY = false>
+template <typename T, bool GRAD, class TINY = TinyOff>
 __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, bool has_temp, T temp, T* lik_out,
                          T* prior_out, T* row_out = nullptr) {
   const int lane = threadIdx.x;
@@ -334,9 +354,9 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
   const int nl = m.nl;
   const int dK = m.dims[nl];
   T lik = T(0);
-  if constexpr (TINY) {
+  if constexpr (TINY::on) {
     __syncthreads();  // the position written by the caller is visible
-    lik = tiny_rows<T, GRAD>(m, th, gr, has_temp, temp, row_out);
+    lik = tiny_rows<T, GRAD, TINY>(m, th, gr, has_temp, temp, row_out);
   } else {
   if (GRAD) {
     for (int i = lane; i < m.P; i += WAVE) gr[i] = T(0);
@@ -460,7 +480,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
 }
 
 // ----------------------------------------------------------------------------------------------- kernels
-template <typename T, bool GRAD, bool TINY>
+template <typename T, bool GRAD, class TINY>
 __global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, const T* temp, T* lik_o, T* prior_o,
                                                      T* target_o, T* grad_o, T* rows_o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -482,7 +502,7 @@ __global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, 
   }
 }
 
-template <typename T, bool TINY>
+template <typename T, class TINY>
 __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T* grad, const T* p0, const T* u_in,
                                               T step, const T* step_vec, int L, const T* temp, uint64_t seed,
                                               uint64_t iter0, uint64_t chain_offset, int recompute,
@@ -563,7 +583,7 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
 }
 
 // HMC.leapfrog as a standalone operator (hmc.py:100-124): L+1 evaluations, momentum negated.
-template <typename T, bool TINY>
+template <typename T, class TINY>
 __global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, T step, const T* step_vec, int L,
                                                    const T* temp, T* target, T* grad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -596,7 +616,7 @@ __global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, 
   if (lane == 0) target[c] = t;
 }
 
-template <typename T, bool TINY>
+template <typename T, class TINY>
 __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T* grad, const T* z_in, const T* u_in,
                                                T step, T sqrt_step, const T* step_vec, const T* temp, uint64_t seed,
                                                uint64_t iter0, uint64_t chain_offset, unsigned char* accepted,
@@ -670,7 +690,7 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
   }
 }
 
-template <typename T, bool TINY>
+template <typename T, class TINY>
 __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, const T* z_in, const T* u_in,
                                              const T* scale, const T* temp, uint64_t seed, uint64_t iter0,
                                              uint64_t chain_offset, unsigned char* accepted, T* log_rate_o, EyRun run,
@@ -726,13 +746,41 @@ __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, con
 // at the batch only, not at the number of chains: the arithmetic a chain sees must not depend on how many chains (or
 // GPUs) run beside it.  ey_debug_set_variant bit 8: never (A/B, tests), bit 9: whenever the model qualifies.
 std::atomic<int> g_ey_no_tiny{0}, g_ey_force_tiny{0};
-static bool use_tiny(const ey_plan* pl) {
-  if (!ey_generic_tiny_ok(pl->m) || g_ey_no_tiny.load()) return false;
-  return g_ey_force_tiny.load() || pl->m.N >= 128;
+// 0: the LDS tile loop, 1: TinyDyn, 2..: the compile-time shapes (taken for any batch: their fixed cost is a handful of
+// loads and reductions)
+static int tiny_kind(const ey_plan* pl) {
+  const EyModel& m = pl->m;
+  if (!ey_generic_tiny_ok(m) || g_ey_no_tiny.load()) return 0;
+  auto is = [&](int nl, int a, int b, int c, int d) {
+    return m.nl == nl && m.dims[0] == a && m.dims[1] == b && (nl < 2 || m.dims[2] == c) && (nl < 3 || m.dims[3] == d);
+  };
+  if (is(2, 2, 2, 1, 0)) return 2;
+  if (is(3, 2, 3, 2, 1)) return 3;
+  if (is(2, 4, 3, 3, 0)) return 4;
+  if (is(3, 4, 3, 2, 3)) return 5;
+  if (is(2, 1, 2, 1, 0)) return 6;
+  if (is(3, 2, 3, 3, 2)) return 7;
+  return (g_ey_force_tiny.load() || m.N >= 128) ? 1 : 0;
 }
-#define EY_TINY_DISPATCH(fn, ...)                                                                    \
-  (use_tiny(pl) ? (pl->dtype == EY_F32 ? fn<float, true>(__VA_ARGS__) : fn<double, true>(__VA_ARGS__)) \
-                : (pl->dtype == EY_F32 ? fn<float, false>(__VA_ARGS__) : fn<double, false>(__VA_ARGS__)))
+template <typename F>
+static int tiny_dispatch(const ey_plan* pl, F f) {
+  switch (tiny_kind(pl)) {
+    case 1: return f(TinyDyn{});
+    case 2: return f(TinyFix<2, 2, 2, 1, 0>{});
+    case 3: return f(TinyFix<3, 2, 3, 2, 1>{});
+    case 4: return f(TinyFix<2, 4, 3, 3, 0>{});
+    case 5: return f(TinyFix<3, 4, 3, 2, 3>{});
+    case 6: return f(TinyFix<2, 1, 2, 1, 0>{});
+    case 7: return f(TinyFix<3, 2, 3, 3, 2>{});
+    default: return f(TinyOff{});
+  }
+}
+#define EY_TINY_DISPATCH(fn, ...)                                                                      \
+  tiny_dispatch(pl, [&](auto tiny_tag) {                                                               \
+    typedef decltype(tiny_tag) TinyS;                                                                  \
+    return pl->dtype == EY_F32 ? fn<float, TinyS>(__VA_ARGS__) : fn<double, TinyS>(__VA_ARGS__);       \
+  })
+
 template <typename K>
 static int prep(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) EY_FAIL(EY_ERR_UNSUPPORTED, "generic kernel: model does not fit the 160 KiB LDS of a CU");
@@ -742,7 +790,7 @@ static int prep(K kernel, size_t bytes) {
   return EY_OK;
 }
 
-template <typename T, bool TINY>
+template <typename T, class TINY>
 static int launch_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                              void* target, void* grad, hipStream_t s, void* rows = nullptr) {
   const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
@@ -769,7 +817,7 @@ int ey_generic_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, in
   return EY_TINY_DISPATCH(launch_log_target, pl, theta, temp, C, nullptr, nullptr, nullptr, nullptr, s, rows);
 }
 
-template <typename T, bool TINY>
+template <typename T, class TINY>
 static int launch_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                       const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                       uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
@@ -795,7 +843,7 @@ int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const voi
                                  flags, accepted, rate, hcur, hprop, s, run);
 }
 
-template <typename T, bool TINY>
+template <typename T, class TINY>
 static int launch_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                            int64_t C, void* target, void* grad, hipStream_t s) {
   const size_t bytes = lds_bytes(pl->m, 3, sizeof(T));
@@ -812,7 +860,7 @@ int ey_generic_leapfrog(ey_plan* pl, void* theta, void* p, double step, const vo
   return EY_TINY_DISPATCH(launch_leapfrog, pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
 }
 
-template <typename T, bool TINY>
+template <typename T, class TINY>
 static int launch_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
                        const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                        uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run) {
@@ -835,7 +883,7 @@ int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const vo
                                                   chain_offset, accepted, log_rate, s, run);
 }
 
-template <typename T, bool TINY>
+template <typename T, class TINY>
 static int launch_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
                      const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
                      void* log_rate, hipStream_t s, const EyRun* run) {

@@ -980,13 +980,17 @@ def test_chain_stats_hip_pass_equals_torch_formulas():
     ([2, 2, 1], [1, 1], [1, 1], 0),            # the reference's XOR net (tests/*mlp221*)
     ([2, 3, 2, 1], [1, 1, 1], [1, 1, 1], 0),   # BASELINE configs[1]
     ([4, 3, 3], [1, 0], [1, 1], 1),            # the Iris net of examples/samplers/mlp/iris
-    ([8, 4, 4, 4], [2, 3, 0], [1, 0, 1], 1),   # the largest shape it takes; tanh, relu, a layer without bias
-    ([3, 2], [1], [1], 0),                     # a single layer, two BCE outputs
+    ([4, 3, 2, 3], [1, 1, 0], [1, 1, 1], 1),   # the reference's second Iris net
+    ([2, 3, 3, 2], [1, 1, 0], [0, 1, 1], 1),   # tests/test_gibbs_blocking.py's net, first layer without bias
+    ([1, 2, 1], [1, 1], [1, 1], 0),            # mlp.Hyperparameters' default
+    ([8, 4, 4, 4], [2, 3, 0], [1, 0, 1], 1),   # run-time extents: the largest shape it takes; tanh, relu, no bias
+    ([3, 2], [1], [1], 0),                     # run-time extents: a single layer, two BCE outputs
 ])
 def test_tiny_models_register_resident_evaluation(dims, acts, bias, lik, tag):
-    """The register-resident evaluation the generic kernels take for tiny models (ey_generic.hip, tiny_rows; by default
-    from 128 rows up) against the C oracle and against the LDS tile loop it stands in for, on every entry point and on
-    row counts either side of a 64-row tile.  ey_debug_set_variant bit 9 selects it for any batch, bit 8 never."""
+    """The register-resident evaluation the generic kernels take for tiny models (ey_generic.hip, tiny_rows: extents at
+    compile time for the reference's own shapes, at run time -- by default from 128 rows up -- for the others) against the
+    C oracle and against the LDS tile loop it stands in for, on every entry point and on row counts either side of a
+    64-row tile.  ey_debug_set_variant bit 9 selects it for any batch, bit 8 never."""
     from eeyore_amd import _lib as L
     from eeyore_amd.plan import Plan
     npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
