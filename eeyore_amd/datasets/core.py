@@ -107,6 +107,13 @@ class XYDataset(Dataset):
     def __getitem__(self, idx):
         return self.x[idx], self.y[idx]
 
+    def __getitems__(self, indices):
+        """The rows of one batch at once (torch's DataLoader fetcher prefers this over one ``__getitem__`` per row): one
+        gather per tensor -- on a device-resident data set the row-by-row fetch of a 150-row batch is 300 indexing
+        launches, most of a single-chain iteration.  Same rows, same order, same values for the collate function."""
+        idx = torch.as_tensor(indices, dtype=torch.long, device=self.x.device)
+        return list(zip(self.x.index_select(0, idx).unbind(0), self.y.index_select(0, idx).unbind(0)))
+
     def __repr__(self):
         return 'XYDataset'
 

@@ -113,6 +113,32 @@ def test_synthetic_iris_shaped_matches_fixture_generator():
     assert x.shape == (150, 4) and y.sum(0).tolist() == [50, 50, 50]
 
 
+def test_xydataset_batched_fetch_yields_the_batches_of_the_row_by_row_fetch():
+    """XYDataset.__getitems__ (one gather per batch) hands the DataLoader the rows, order and values that one
+    __getitem__ per row does (eeyore/datasets/xydataset.py:21-22), for shuffled full batches and for minibatches, and
+    consumes the global generator identically."""
+    from torch.utils.data import DataLoader
+    from eeyore_amd.datasets import XYDataset
+
+    class RowByRow(XYDataset):
+        __getitems__ = None  # the fetcher then falls back to __getitem__
+
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(37, 4, generator=g, dtype=torch.float64), torch.randn(37, 3, generator=g, dtype=torch.float64)
+    for batch_size in (37, 10):
+        for yy in (y, y[:, 0]):
+            torch.manual_seed(11)
+            a = [(bx.clone(), by.clone()) for bx, by in DataLoader(XYDataset(x, yy), batch_size=batch_size, shuffle=True)]
+            after_a = torch.rand(1)
+            torch.manual_seed(11)
+            b = [(bx.clone(), by.clone()) for bx, by in DataLoader(RowByRow(x, yy), batch_size=batch_size, shuffle=True)]
+            after_b = torch.rand(1)
+            assert len(a) == len(b) and torch.equal(after_a, after_b)
+            for (ax, ay), (bx, by) in zip(a, b):
+                assert ax.shape == bx.shape and ay.shape == by.shape
+                assert torch.equal(ax, bx) and torch.equal(ay, by)
+
+
 def test_data_counter():
     c = DataCounter(batch_size=50, sample_size=150)
     assert c.num_batches == 3
