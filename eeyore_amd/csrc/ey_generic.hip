@@ -116,7 +116,7 @@ bool ey_generic_tiny_ok(const EyModel& m) {
 // iteration behind a wave-uniform guard: ~300 scalar branches per tile of MLP(2-3-2-1)); TinyFix<...> states them at
 // compile time, so the guards fold away and only the registers the shape needs remain.  TinyFix exists for the shapes
 // the reference's own tests and examples use (mlp.py's default 1-2-1, XOR 2-2-1 and 2-3-2-1, 2-3-3-2, Iris 4-3-3 and
-// 4-3-2-3).
+// 4-3-2-3, the banknotes logistic regression 4-1).
 struct TinyOff {
   static constexpr bool on = false;
 };
@@ -760,6 +760,7 @@ static int tiny_kind(const ey_plan* pl) {
   if (is(3, 4, 3, 2, 3)) return 5;
   if (is(2, 1, 2, 1, 0)) return 6;
   if (is(3, 2, 3, 3, 2)) return 7;
+  if (is(1, 4, 1, 0, 0)) return 8;
   return (g_ey_force_tiny.load() || m.N >= 128) ? 1 : 0;
 }
 template <typename F>
@@ -772,6 +773,7 @@ static int tiny_dispatch(const ey_plan* pl, F f) {
     case 5: return f(TinyFix<3, 4, 3, 2, 3>{});
     case 6: return f(TinyFix<2, 1, 2, 1, 0>{});
     case 7: return f(TinyFix<3, 2, 3, 3, 2>{});
+    case 8: return f(TinyFix<1, 4, 1, 0, 0>{});
     default: return f(TinyOff{});
   }
 }

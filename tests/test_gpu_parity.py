@@ -983,6 +983,7 @@ def test_chain_stats_hip_pass_equals_torch_formulas():
     ([4, 3, 2, 3], [1, 1, 0], [1, 1, 1], 1),   # the reference's second Iris net
     ([2, 3, 3, 2], [1, 1, 0], [0, 1, 1], 1),   # tests/test_gibbs_blocking.py's net, first layer without bias
     ([1, 2, 1], [1, 1], [1, 1], 0),            # mlp.Hyperparameters' default
+    ([4, 1], [1], [0], 0),                     # the banknotes logistic regression (no bias)
     ([8, 4, 4, 4], [2, 3, 0], [1, 0, 1], 1),   # run-time extents: the largest shape it takes; tanh, relu, no bias
     ([3, 2], [1], [1], 0),                     # run-time extents: a single layer, two BCE outputs
 ])
