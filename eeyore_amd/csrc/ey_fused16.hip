@@ -74,6 +74,13 @@ struct F16Args {
   double da_d, da_logeub;
 };
 
+// F16_ABLATE (diagnostic builds only, tools/ablate_fused16.sh): 1 = no transcendental in the activations, 2 = the
+// skinny products (logits, dH1, dW2, dW0) replaced by one add each, 4 = no global loads of the data tile, 8 = no
+// transpose stores.  Results are wrong in such a build; only its timing is read.
+#ifndef F16_ABLATE
+#define F16_ABLATE 0
+#endif
+
 template <typename T>
 struct V4 {
   typedef T type __attribute__((ext_vector_type(4)));
@@ -81,6 +88,13 @@ struct V4 {
 template <typename T>
 using v4 = typename V4<T>::type;
 
+template <typename T>
+__device__ __forceinline__ v4<T> mfma16(T a, T b, v4<T> c);
+template <typename T>
+__device__ __forceinline__ v4<T> mfma16s(T a, T b, v4<T> c) {  // the skinny products
+  if (F16_ABLATE & 2) { c[0] += a * b; return c; }
+  return mfma16<T>(a, b, c);
+}
 template <typename T>
 __device__ __forceinline__ v4<T> mfma16(T a, T b, v4<T> c) {
   if constexpr (sizeof(T) == 8) return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -115,6 +129,7 @@ struct Nm<double> {
 // MFMA shares the vector ALUs with them); both are accurate to ~1 ulp, far inside the stated 2e-4.
 template <typename T>
 __device__ __forceinline__ T f16_sigmoid(T g) {
+  if (F16_ABLATE & 1) return T(0.25) * g + T(0.5);
   if constexpr (sizeof(T) == 4) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
   else return T(1) / (T(1) + Nm<T>::exp(-g));
 }
@@ -349,8 +364,8 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
     constexpr int KS = (V & 2) ? 4 : 2;
     T xb[KS];
 #pragma unroll
-    for (int s4 = 0; s4 < KS; ++s4) xb[s4] = s4 < a.ks0 ? xt[s4 * 64 + lane] : T(0);
-    const int lab = (int)xt[off_lab + c];  // -1 marks a padding row
+    for (int s4 = 0; s4 < KS; ++s4) xb[s4] = (F16_ABLATE & 4) ? T(0.01 * lane) : (s4 < a.ks0 ? xt[s4 * 64 + lane] : T(0));
+    const int lab = (F16_ABLATE & 4) ? (c % 3) : (int)xt[off_lab + c];  // -1 marks a padding row
     const bool valid = lab >= 0;
     // ---- F0: H0^T = act0(W0 X^T + b0)                                  (mlp.py:45-50)
     v4<T> H0[MT], H1[MT];
@@ -364,7 +379,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
       H0[m] = acc;
     }
     f16_act_tiles<T, MT>(a.act0, H0);
-    if (GRAD) {
+    if (GRAD && !(F16_ABLATE & 8)) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -386,7 +401,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
       }
       f16_act_tiles<T, MT>(a.act1, H1);
     }
-    if (GRAD) {
+    if (GRAD && !(F16_ABLATE & 8)) {
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
@@ -403,7 +418,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lacc = mfma16<T>(lw[K::O_W2A + (m * 4 + r) * 64 + lane], H1[m][r], lacc);
+      for (int r = 0; r < 4; ++r) lacc = mfma16s<T>(lw[K::O_W2A + (m * 4 + r) * 64 + lane], H1[m][r], lacc);
     T lg[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {  // o = fi(go, ro): f32 (0, o), f64 (o, 0)
@@ -459,7 +474,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
     const T d2b = g == 0 ? d2all[0] : (g == 1 ? d2all[1] : (g == 2 ? d2all[2] : d2all[3]));  // delta2[row c][o = g]
     v4<T> D1[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) D1[m] = mfma16<T>(lw[K::O_W2T + m * 64 + lane], d2b, v4<T>{0, 0, 0, 0});
+    for (int m = 0; m < MT; ++m) D1[m] = mfma16s<T>(lw[K::O_W2T + m * 64 + lane], d2b, v4<T>{0, 0, 0, 0});
     f16_dact_tiles<T, MT>(a.act1, D1, H1);
     // ---- dW2[o][f] += sum_n delta2[n][o] H1[n][f]           (contracts over rows: U tiles)
     {
@@ -468,14 +483,15 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
       for (int n = 0; n < MT; ++n) {
         const v4<T> h1u = f16_ld4(lw + K::O_TB0 + (16 * n + c) * F16_TS + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dW2[n] = mfma16<T>(c < 4 ? d2u[r] : T(0), h1u[r], dW2[n]);
+        for (int r = 0; r < 4; ++r) dW2[n] = mfma16s<T>(c < 4 ? d2u[r] : T(0), h1u[r], dW2[n]);
       }
     }
     f16_fence();  // H1^T has been read: its buffer takes delta1^T
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lw[K::O_TB0 + (16 * m + L::fi(g, r)) * F16_TS + pc] = D1[m][r];
+      for (int r = 0; r < 4; ++r)
+        if (!(F16_ABLATE & 8)) lw[K::O_TB0 + (16 * m + L::fi(g, r)) * F16_TS + pc] = D1[m][r];
     f16_fence();
     // ---- dH0 = delta1 W1 untransposed (A = delta1 T tiles with M = rows, B = theta's own W1 registers): U tiles
     v4<T> h0u[MT], d0u[MT];
@@ -510,11 +526,11 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
     {
       T xu[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xu[r] = xt[off_xu + r * 64 + lane];
+      for (int r = 0; r < 4; ++r) xu[r] = (F16_ABLATE & 4) ? T(0.02 * lane) : xt[off_xu + r * 64 + lane];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dW0[m] = mfma16<T>(d0u[m][r], xu[r], dW0[m]);
+        for (int r = 0; r < 4; ++r) dW0[m] = mfma16s<T>(d0u[m][r], xu[r], dW0[m]);
         db0[m] += (d0u[m][0] + d0u[m][1]) + (d0u[m][2] + d0u[m][3]);
       }
     }
