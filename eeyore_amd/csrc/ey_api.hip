@@ -114,6 +114,23 @@ int ey_plan_num_params(const ey_plan* pl, int64_t* P) {
 }
 
 std::atomic<int> g_ey_force_large{0};  // ey_debug_set_variant bit 4: route f32 plans through the batched-GEMM path (tests)
+extern std::atomic<int> g_ey_mf_variant;                  // ey_mfma32.hip: bits 0..3
+extern std::atomic<int> g_ey_no_dma, g_ey_no_tail, g_ey_no_fuse;  // ey_large.hip: bits 5, 6, 7
+extern std::atomic<int> g_ey_no_tiny, g_ey_force_tiny;    // ey_generic.hip: bits 8, 9
+// Diagnostic switches for A/B runs and tests (not part of the reference-facing surface); returns the previous value.
+extern "C" int ey_debug_set_variant(int v) {
+  const int old = g_ey_mf_variant.load() | (g_ey_force_large.load() << 4) | (g_ey_no_dma.load() << 5) |
+                  (g_ey_no_tail.load() << 6) | (g_ey_no_fuse.load() << 7) | (g_ey_no_tiny.load() << 8) |
+                  (g_ey_force_tiny.load() << 9);
+  g_ey_mf_variant.store(v & 15);
+  g_ey_force_large.store((v >> 4) & 1);
+  g_ey_no_dma.store((v >> 5) & 1);
+  g_ey_no_tail.store((v >> 6) & 1);
+  g_ey_no_fuse.store((v >> 7) & 1);
+  g_ey_no_tiny.store((v >> 8) & 1);
+  g_ey_force_tiny.store((v >> 9) & 1);
+  return old;
+}
 // the fused MFMA kernel serves this plan with the batch it currently holds
 static bool use_mfma32(const ey_plan* pl) { return pl->mfma32_ok && (pl->mfma32_data_ok || !pl->has_data); }
 // nvec: state vectors the generic kernel of the calling operation keeps in LDS (2 value/MH, 3 HMC, 4 MALA)

@@ -938,25 +938,8 @@ static size_t mf_lds_bytes(int ntiles, int waves, int park) {
 // path, bit 5 = the layerwise path's register-staged GEMM instead of the LDS-DMA one, bit 6 = the layerwise path's
 // narrow last layer as separate launches instead of the fused tail kernel, bit 7 = the layerwise path's leapfrog update
 // as a separate kernel instead of in the gradient kernels' epilogues
-static std::atomic<int> g_variant{0};
-extern std::atomic<int> g_ey_force_large;
-extern std::atomic<int> g_ey_no_dma;
-extern std::atomic<int> g_ey_no_tail;
-extern std::atomic<int> g_ey_no_fuse;
-extern std::atomic<int> g_ey_no_tiny, g_ey_force_tiny;
-extern "C" int ey_debug_set_variant(int v) {
-  const int old = g_variant.load() | (g_ey_force_large.load() << 4) | (g_ey_no_dma.load() << 5) |
-                  (g_ey_no_tail.load() << 6) | (g_ey_no_fuse.load() << 7) | (g_ey_no_tiny.load() << 8) |
-                  (g_ey_force_tiny.load() << 9);
-  g_variant.store(v & 15);
-  g_ey_force_large.store((v >> 4) & 1);
-  g_ey_no_dma.store((v >> 5) & 1);
-  g_ey_no_tail.store((v >> 6) & 1);
-  g_ey_no_fuse.store((v >> 7) & 1);
-  g_ey_no_tiny.store((v >> 8) & 1);
-  g_ey_force_tiny.store((v >> 9) & 1);
-  return old;
-}
+// ey_debug_set_variant (ey_api.hip) bits 0..3: launch variants of this kernel, for A/B runs and tests
+std::atomic<int> g_ey_mf_variant{0};
 
 // Pack (x, labels) into the per-tile LDS images, on the device and on the caller's stream: one thread per (tile, row).
 // Rows beyond N are zero with label -1 (they contribute nothing).
@@ -1026,14 +1009,14 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
   a.short_last = (m.N - 32 * (a.ntiles - 1)) <= 24 ? 1 : 0;
-  a.balance = (g_variant.load() & 2) ? 0 : 1;
+  a.balance = (g_ey_mf_variant.load() & 2) ? 0 : 1;
   if (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) {
     a.mom_s1 = pl->mom_s1;
     a.mom_s2 = pl->mom_s2;
     a.mom_acc = pl->mom_acc;
   }
   if constexpr (MODE == MODE_HMC) {
-    const int variant = g_variant.load();
+    const int variant = g_ey_mf_variant.load();
     if (variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);
     // the headline shape (few row tiles, one Normal(m, s) prior for all parameters) has its own, leaner instantiation
     if (a.ntiles <= MF_PARK_TILES && a.prior_uniform && !(variant & 4))
