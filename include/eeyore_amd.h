@@ -208,8 +208,10 @@ int ey_plan_attach_moments(ey_plan* plan, void* s1, void* s2, void* acc, int64_t
 int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* table, int64_t n, int64_t C, double d,
                       double log_eub, int final_avg);
 
-/* Tuning knob for the MFMA kernel family (not part of the drop-in surface): selects the workgroup shape /
- * issue-priority variant of the fused trajectory kernel; returns the previous value.  Results do not depend on it. */
+/* Diagnostic switches for A/B runs and tests (not part of the drop-in surface); returns the previous value.  Bits 0..3:
+ * workgroup shape / issue-priority variants of the fused f32 trajectory kernel; 4: f32 plans through the layerwise
+ * path; 5, 6, 7: that path without LDS-DMA staging / fused last layer / fused leapfrog update; 8, 9: tiny models never /
+ * always through the register-resident evaluation of the generic kernels.  Results agree to rounding across them. */
 int ey_debug_set_variant(int variant);
 
 /* Test / measurement entry of the layerwise path's batched f32 product (not part of the drop-in surface):
