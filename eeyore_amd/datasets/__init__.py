@@ -1,2 +1,2 @@
-from .core import DataCounter, EmptyXYDataset, XYDataset, data_paths
+from .core import DataCounter, EmptyXYDataset, XYDataset, batches, data_paths
 from . import synthetic

@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import torch
 from torch.nn.functional import one_hot
-from torch.utils.data import Dataset
+from torch.utils.data import BatchSampler, DataLoader, Dataset, default_collate
 
 from eeyore_amd.constants import torch_to_np_types
 
@@ -141,3 +141,26 @@ class EmptyXYDataset(XYDataset):
 
     def __repr__(self):
         return 'Empty XYDataset'
+
+
+def batches(dataloader):
+    """What ``for x, y in dataloader`` yields, batch for batch.  A plain single-process ``DataLoader`` over an
+    ``XYDataset`` with the default collate function is served without the fetcher: the index batches come from the
+    loader's own ``batch_sampler`` (so shuffling, ``drop_last`` and the sampler's use of the random generators are the
+    loader's), the rows from one gather per tensor, and the one draw an iterator of the loader takes from the global
+    generator for its base seed is taken too -- a script that seeds torch sees the same batches AND the same random
+    stream after them as with the loader itself (tests/test_host_logic.py checks both against this torch).  On a
+    device-resident data set that is two launches instead of a few hundred per batch.  Anything else -- workers, a custom
+    collate function or sampler class, another dataset type -- is iterated as it is."""
+    ds = getattr(dataloader, 'dataset', None)  # any iterable of (x, y) is accepted in a loader's place
+    plain = (type(dataloader) is DataLoader and dataloader.num_workers == 0 and type(ds) is XYDataset
+             and dataloader.collate_fn is default_collate and type(dataloader.batch_sampler) is BatchSampler
+             and not dataloader.pin_memory and torch.is_tensor(ds.x) and torch.is_tensor(ds.y)
+             and ds.x.device == ds.y.device)
+    if not plain:
+        yield from dataloader
+        return
+    torch.empty((), dtype=torch.int64).random_(generator=dataloader.generator)  # _BaseDataLoaderIter's base seed
+    for idx in dataloader.batch_sampler:
+        i = torch.as_tensor(idx, dtype=torch.long, device=ds.x.device)
+        yield ds.x.index_select(0, i), ds.y.index_select(0, i)

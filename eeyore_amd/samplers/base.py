@@ -15,7 +15,7 @@ from timeit import default_timer as timer
 import torch
 
 from eeyore_amd.chains import ChainBuffer, ChainList
-from eeyore_amd.datasets import DataCounter
+from eeyore_amd.datasets import DataCounter, batches
 
 
 class Sampler:
@@ -59,7 +59,7 @@ class SerialSampler(Sampler):
         counter.set_epoch_info(num_epochs, num_burnin_epochs)
         progress = _Progress(verbose, verbose_step, counter)
         for epoch in range(counter.num_epochs):
-            for x, y in self.dataloader:
+            for x, y in batches(self.dataloader):
                 progress.before(counter.idx)
                 self.draw(x, y, savestate=counter.idx >= counter.num_burnin_iters)
                 progress.after(counter.idx, epoch)

@@ -139,6 +139,33 @@ def test_xydataset_batched_fetch_yields_the_batches_of_the_row_by_row_fetch():
                 assert torch.equal(ax, bx) and torch.equal(ay, by)
 
 
+def test_batches_equals_iterating_the_dataloader_including_the_random_stream():
+    """datasets.batches (what SerialSampler.run walks): the batches of the DataLoader itself and the same state of the
+    global generator after every epoch, so a seeded script draws the same momenta / proposals as it would behind the
+    loader (eeyore/samplers/serial_sampler.py:44-45 iterates the loader).  Custom collate functions fall through."""
+    from torch.utils.data import DataLoader
+    from eeyore_amd.datasets import XYDataset, batches
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(23, 4, generator=g, dtype=torch.float64), torch.randn(23, 2, generator=g, dtype=torch.float64)
+    for kw in (dict(batch_size=23, shuffle=True), dict(batch_size=23, shuffle=False), dict(batch_size=5, shuffle=True),
+               dict(batch_size=5, shuffle=True, drop_last=True), dict(batch_size=7, shuffle=False)):
+        for yy in (y, y[:, 0]):
+            got, want, states = [], [], []
+            for walk, store in ((batches, got), (iter, want)):
+                torch.manual_seed(17)
+                loader = DataLoader(XYDataset(x, yy), **kw)
+                for epoch in range(3):
+                    for bx, by in walk(loader):
+                        store.append((bx.clone(), by.clone(), torch.randn(2)))  # a draw between batches, as a sampler makes
+                states.append(torch.get_rng_state())
+            assert len(got) == len(want) and torch.equal(states[0], states[1]), kw
+            for a, b in zip(got, want):
+                assert a[0].shape == b[0].shape and a[1].shape == b[1].shape
+                assert all(torch.equal(u, v) for u, v in zip(a, b)), kw
+    own = DataLoader(XYDataset(x, y), batch_size=4, collate_fn=lambda rows: (len(rows), rows[0][0]))
+    assert [b[0] for b in batches(own)] == [4, 4, 4, 4, 4, 3]
+
+
 def test_data_counter():
     c = DataCounter(batch_size=50, sample_size=150)
     assert c.num_batches == 3
