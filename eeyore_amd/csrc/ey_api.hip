@@ -137,12 +137,14 @@ static bool use_mfma32(const ey_plan* pl) { return pl->mfma32_ok && (pl->mfma32_
 // The layerwise path is NEEDED when the generic kernel's LDS image does not fit, and PREFERRED for models that fit but
 // are wide enough for 32-wide matrix tiles to beat one wave's vector ALUs: measured (tools/route_probe.py, any number
 // of chains, any row count) the crossover is at sum_l d_l d_{l+1} ~ 600 in f32 (MLP(4-70-3) 0.9 x, MLP(12-48-6) 2 x,
-// MLP(10-100-10) 6-7 x the generic kernel) and below 240 in f64 (MLP(6-24-4) 1.3 x, MLP(4-70-3) 2.3 x).
+// MLP(10-100-10) 6-7 x the generic kernel) and below 240 in f64 (MLP(6-24-4) 1.3 x, MLP(4-70-3) 2.3 x).  Re-measured
+// over 64 .. 16384 chains with the blocked generic loop (tools/route_probe_chains.py): MLP(10-30-10), sum 600, is
+// 1.6-2.9 x faster layerwise in f32 at every chain count, MLP(4-70-3), sum 490, 0.7 x from 1024 chains up: 560.
 // EY_FORCE_GENERIC overrides the preference, not the need.
 static bool prefer_large(const ey_plan* pl) {
   long w = 0;
   for (int l = 0; l < pl->m.nl; ++l) w += (long)pl->m.dims[l] * pl->m.dims[l + 1];
-  return w >= (pl->dtype == EY_F32 ? 640 : 200);
+  return w >= (pl->dtype == EY_F32 ? 560 : 200);
 }
 static bool use_large(const ey_plan* pl, int nvec = 3, uint32_t flags = 0) {
   if (ey_large_needed(pl, nvec)) return true;

@@ -373,11 +373,31 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
       const T* W = th + m.woff[k];
       const T* hin = l.act + m.hoff[k] * TS + lane;
       T* hout = l.act + m.hoff[k + 1] * TS + lane;
-      for (int j = 0; j < dout; ++j) {
-        T g = T(0);
-        for (int i = 0; i < din; ++i) g += hin[i * TS] * W[j * din + i];
-        if (m.boff[k] >= 0) g += th[m.boff[k] + j];
-        hout[j * TS] = act_fn<T>(m.act[k], g);
+      // four outputs at a time: one read of the row's input feeds four sums and nothing is stored inside the i loop,
+      // so its loads pipeline (one output at a time every load waited behind the previous output's store); each sum
+      // still adds its terms in the order i = 0, 1, ..., so the results are those of the plain loop, bit for bit
+      for (int j0 = 0; j0 < dout; j0 += 4) {
+        const int nj = min(4, dout - j0);
+        const T* w0 = W + j0 * din;
+        const T* w1 = w0 + (nj > 1 ? din : 0);  // rows beyond dout alias row j0: read, never stored
+        const T* w2 = w0 + (nj > 2 ? 2 * din : 0);
+        const T* w3 = w0 + (nj > 3 ? 3 * din : 0);
+        T g0 = T(0), g1 = T(0), g2 = T(0), g3 = T(0);
+#pragma unroll 4
+        for (int i = 0; i < din; ++i) {
+          const T h = hin[i * TS];
+          g0 += h * w0[i];
+          g1 += h * w1[i];
+          g2 += h * w2[i];
+          g3 += h * w3[i];
+        }
+        auto put = [&](int q, T g) {
+          if (q < nj) {
+            if (m.boff[k] >= 0) g += th[m.boff[k] + j0 + q];
+            hout[(j0 + q) * TS] = act_fn<T>(m.act[k], g);
+          }
+        };
+        put(0, g0); put(1, g1); put(2, g2); put(3, g3);
       }
     }
     // ---- likelihood and output delta
@@ -444,10 +464,23 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
         if (k > 0) {
           // delta_{k-1}[i][n] = (sum_j delta_k[j][n] W_k[j][i]) * act'(h_k[i][n])   (row-parallel)
           const T* W = th + m.woff[k];
-          for (int i = 0; i < din; ++i) {
-            T a = T(0);
-            for (int j = 0; j < dout; ++j) a += dcur[j * TS + lane] * W[j * din + i];
-            dnext[i * TS + lane] = a * dact_fn<T>(m.act[k - 1], hin_t[i * TS + lane]);
+          for (int i0 = 0; i0 < din; i0 += 4) {  // four inputs at a time, each sum in the order j = 0, 1, ...
+            const int ni = min(4, din - i0);
+            const int o1 = ni > 1 ? 1 : 0, o2 = ni > 2 ? 2 : 0, o3 = ni > 3 ? 3 : 0;
+            T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+#pragma unroll 4
+            for (int j = 0; j < dout; ++j) {
+              const T d = dcur[j * TS + lane];
+              const T* w = W + j * din + i0;
+              a0 += d * w[0];
+              a1 += d * w[o1];
+              a2 += d * w[o2];
+              a3 += d * w[o3];
+            }
+            auto put = [&](int q, T a) {
+              if (q < ni) dnext[(i0 + q) * TS + lane] = a * dact_fn<T>(m.act[k - 1], hin_t[(i0 + q) * TS + lane]);
+            };
+            put(0, a0); put(1, a1); put(2, a2); put(3, a3);
           }
           T* t = dcur; dcur = dnext; dnext = t;
         }
