@@ -200,11 +200,35 @@ __device__ __forceinline__ void f16_dact_tiles(int code, typename V4<T>::type (&
   }
 }
 
+// wave total in every lane, without LDS traffic: DPP adds inside each 16-lane row (quad swaps, half-mirror, mirror), then
+// row_bcast:15 / row_bcast:31 carry the row totals to lane 63, whose value v_readlane hands to all (as wsum of
+// ey_mfma32.hip; six __shfl_xor rounds were twelve ds_bpermute in f64)
+template <int CTRL, int ROWMASK, typename T>
+__device__ __forceinline__ T f16_dpp(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+  } else {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROWMASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  }
+}
 template <typename T>
 __device__ __forceinline__ T f16_wsum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += f16_dpp<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += f16_dpp<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += f16_dpp<0x141, 0xF>(v);  // row_half_mirror
+  v += f16_dpp<0x140, 0xF>(v);  // row_mirror
+  v += f16_dpp<0x142, 0xA>(v);  // row_bcast:15
+  v += f16_dpp<0x143, 0xC>(v);  // row_bcast:31
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  } else {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  }
 }
 // sum over the four lane groups g (lanes c, c + 16, c + 32, c + 48): every lane gets the total of its column c
 template <typename T>
