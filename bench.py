@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: leapfrog-steps/sec x chains, HMC on MLP(4-32-32-3), Iris-shaped synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -79,12 +79,20 @@ def cpu_reference_faithful(x, y, sigma, budget_s=8.0):
                                       f"run serially in the reference, so x chains = the same number"}
 
 
-def cpu_baseline(x, y, sigma, budget_s=12.0):
-    """The C oracle (oracle/mlp_oracle.c, a port of the reference's algorithm) timed on this host's cores on a
-    bounded sample of the same workload.  The oracle is the checker, never the product."""
+def usable_cpus():
+    """Hardware threads this process may run on (the scheduler's affinity mask, not the host's total)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(x, y, sigma, cores, budget_s=9.0):
+    """The C oracle (oracle/mlp_oracle.c, a port of the reference's algorithm) timed on `cores` threads of this host
+    (one chain per thread at a time, OpenMP over chains) on a bounded sample of the same workload.  The oracle is the
+    checker, never the product."""
     from oracle.c_oracle import COracle
     host_cpus = os.cpu_count() or 1
-    cores = min(host_cpus, 16)  # a one-GPU box's CPU share is 16 threads; the host count is reported beside it
     co = COracle(DIMS, [1, 1, 0], 1, x, y, 0.0, sigma, dtype=np.float32, nthreads=cores)
     rng = np.random.default_rng(0)
     P = co.P
@@ -103,16 +111,68 @@ def cpu_baseline(x, y, sigma, budget_s=12.0):
 
     t_probe = run(2 * cores, 1)
     # scale the sample to ~budget_s of wall time: more chains first (keeps every core busy), then iterations
-    per_chain_iter = t_probe / 2.0
-    total = max(1.0, budget_s / max(per_chain_iter, 1e-4))
-    iters = int(min(10, max(1, total // 64)))
-    C0 = int(cores * max(2, min(256, total // iters)))
+    per_chain_iter = t_probe / 2.0  # every thread took two chains through one iteration
+    total = max(1.0, budget_s / max(per_chain_iter, 1e-4))  # chain-iterations per thread that fit the budget
+    per_thread = int(max(2, min(16, total // 100)))  # few chains per thread: their start-up evaluations are serial
+    iters = int(max(1, min(100, total // per_thread)))
+    C0 = cores * per_thread
     t = run(C0, iters)
     return {"value": C0 * iters * L_STEPS / t, "unit": "leapfrog-steps/sec x chains", "cores": cores, "kind": "port",
             "host_cpus": host_cpus,
             "sample": f"{C0} chains x {iters} HMC iterations (L={L_STEPS}, L+1 gradient evaluations each as "
                       f"hmc.py:104), f32, C oracle with OpenMP over chains ({cores} of the host's {host_cpus} hardware "
                       f"threads), {t:.1f} s"}
+
+
+def self_launch(n_ranks, argv):
+    """`bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process -- which has not
+    touched the GPU: no HIP call, no torch.cuda call before this point -- starts N fresh rank processes with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as torch.distributed.run would, waits for them, relays rank 0's one
+    JSON line and returns non-zero if any rank failed.  (Children, not exec: a rank must start from a clean process.)"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip()]
+    for ln in lines:  # the one JSON line on stdout; anything else a library printed there (gloo's banner) on stderr
+        print(ln, flush=True, file=sys.stdout if ln.lstrip().startswith("{") else sys.stderr)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def dry_run(args, rank, world):
+    """The multi-rank skeleton of main() without the device: barrier, timed region, MAX over ranks, one line from rank 0."""
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({"metric": "leapfrog-steps/sec x chains, HMC MLP(4-32-32-3)", "value": None, "dry_run": True,
+                          "unit": "leapfrog-steps/sec x chains", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+                          "higher_is_better": True, "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -127,7 +187,12 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed launches before the timed region, on top of --warmup, until the clocks have settled")
     ap.add_argument("--force-generic", action="store_true", help="time the generic VALU kernel instead of the MFMA one")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / collectives only (no GPU needed, prints value null): the CPU-side test of "
+                         "the multi-rank plumbing; never a measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     from eeyore_amd import _lib as L
     from eeyore_amd.datasets import synthetic
@@ -138,7 +203,9 @@ def main():
     local = local % max(1, torch.cuda.device_count())  # only differs in a gloo rehearsal on a smaller box
     gloo = world > 1 and dist.get_backend() == "gloo"
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     C = args.chains_per_gpu
@@ -262,8 +329,8 @@ def main():
                 "kernel": "generic" if args.force_generic else plan.kernel,
                 "gradient_evaluations_per_iteration": L_STEPS, "iterations_per_launch": ipl,
                 "stats_summary_ms": round(summary_ms, 3),
+                "value_including_stats_summary": total_chains * L_STEPS * args.steps / (elapsed + 1e-3 * summary_ms),
                 "acceptance": None if summ is None else round(summ["acceptance"], 4),
-                "max_rhat": None if summ is None else round(float(summ["rhat"].max().item()), 4),
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -286,8 +353,13 @@ def main():
                                                / pm.get("iterations_per_launch", 1))
                 line["roofline"]["traffic_source"] = pm.get("source", "profiles/pmc_latest.json")
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 figure (the other ranks would wait for it)
-            line["cpu_baseline"] = cpu_baseline(xs, ys, sigma)
-            line["cpu_baseline"]["reference_faithful"] = cpu_reference_faithful(xs, ys, sigma)
+            # BASELINE.md section 3 item 3, "generous CPU": one chain per hardware thread on ALL threads this process may
+            # use; beside it the 16 threads that are a one-GPU box's share of the host, and the reference-faithful path
+            ncpu = usable_cpus()
+            line["cpu_baseline"] = cpu_baseline(xs, ys, sigma, ncpu)
+            if ncpu > 16:
+                line["cpu_baseline"]["share_16_threads"] = cpu_baseline(xs, ys, sigma, 16, budget_s=5.0)
+            line["cpu_baseline"]["reference_faithful"] = cpu_reference_faithful(xs, ys, sigma, budget_s=6.0)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -18,6 +18,8 @@ EY_RECOMPUTE_INITIAL_GRAD, EY_FORCE_GENERIC = 1, 2
 
 # every symbol include/eeyore_amd.h declares: (name, restype, argtypes)
 _vp, _i, _i64, _u64, _u32, _d = ct.c_void_p, ct.c_int, ct.c_int64, ct.c_uint64, ct.c_uint32, ct.c_double
+EY_OPT_F32_PRODUCTS, EY_PRODUCTS_BF16X3, EY_PRODUCTS_EXACT = 1, 0, 1
+
 SYMBOLS = {
     "ey_version": (_i, []),
     "ey_last_error": (ct.c_char_p, []),
@@ -50,6 +52,9 @@ SYMBOLS = {
     "ey_plan_attach_da": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _i]),
     "ey_inse_multivariate": (_i, [_vp, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
     "ey_debug_set_variant": (_i, [_i]),
+    "ey_plan_set_variant": (_i, [_vp, _i]),
+    "ey_plan_set_option": (_i, [_vp, _i, _i]),
+    "ey_plan_get_option": (_i, [_vp, _i, ct.POINTER(ct.c_int)]),
     "ey_debug_bgemm": (_i, [_vp, _vp, _vp, _i, _i, _i] + [_i64] * 9 + [_vp, _i64, _i, _i, _vp]),
 }
 

@@ -78,10 +78,23 @@ struct ey_plan {
   void* d_xpack16 = nullptr;
   size_t xpack16_bytes = 0;
   int n_cu;
+  int variant = 0;   // diagnostic switches (ey_plan_set_variant; bits as documented in include/eeyore_amd.h)
+  int products = 0;  // EY_OPT_F32_PRODUCTS: EY_PRODUCTS_BF16X3 (0) or EY_PRODUCTS_EXACT (1)
   // layerwise batched-GEMM path for models whose parameters do not fit LDS (ey_large.hip): workspace it owns
   void* d_work;
   size_t work_bytes;
 };
+
+// The diagnostic switches of the plan a C-ABI call is serving, for the dispatch code below the entry points (thread-local:
+// plans on different threads are independent; an entry point sets it for its own duration).
+extern thread_local int t_ey_variant;
+struct EyVariantScope {
+  int old;
+  explicit EyVariantScope(int v) : old(t_ey_variant) { t_ey_variant = v; }
+  ~EyVariantScope() { t_ey_variant = old; }
+};
+#define EY_VBIT(b) ((t_ey_variant >> (b)) & 1)
+int ey_default_variant();  // what plans created now start with (ey_debug_set_variant, EY_VARIANT)
 
 // what a launch needs of the attached dual averaging: the rows of the table for its iterations
 struct EyDA {

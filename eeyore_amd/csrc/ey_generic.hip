@@ -778,12 +778,11 @@ __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, con
 // in f32 when the chains fill the chip; in f64 (one wave per SIMD) a chip full of chains is 0.75-1.1 x.  The rule looks
 // at the batch only, not at the number of chains: the arithmetic a chain sees must not depend on how many chains (or
 // GPUs) run beside it.  ey_debug_set_variant bit 8: never (A/B, tests), bit 9: whenever the model qualifies.
-std::atomic<int> g_ey_no_tiny{0}, g_ey_force_tiny{0};
 // 0: the LDS tile loop, 1: TinyDyn, 2..: the compile-time shapes (taken for any batch: their fixed cost is a handful of
 // loads and reductions)
 static int tiny_kind(const ey_plan* pl) {
   const EyModel& m = pl->m;
-  if (!ey_generic_tiny_ok(m) || g_ey_no_tiny.load()) return 0;
+  if (!ey_generic_tiny_ok(m) || EY_VBIT(8)) return 0;
   auto is = [&](int nl, int a, int b, int c, int d) {
     return m.nl == nl && m.dims[0] == a && m.dims[1] == b && (nl < 2 || m.dims[2] == c) && (nl < 3 || m.dims[3] == d);
   };
@@ -794,7 +793,7 @@ static int tiny_kind(const ey_plan* pl) {
   if (is(2, 1, 2, 1, 0)) return 6;
   if (is(3, 2, 3, 3, 2)) return 7;
   if (is(1, 4, 1, 0, 0)) return 8;
-  return (g_ey_force_tiny.load() || m.N >= 128) ? 1 : 0;
+  return (EY_VBIT(9) || m.N >= 128) ? 1 : 0;
 }
 template <typename F>
 static int tiny_dispatch(const ey_plan* pl, F f) {

@@ -21,8 +21,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ey_debug_set_variant bit 5 (A/B runs): 0 = LDS-DMA staging where the operands allow it, 1 = the register-staged kernel
-std::atomic<int> g_ey_no_dma{0};
-#define g_bgemm_dma (!g_ey_no_dma.load())
+#define g_bgemm_dma (!EY_VBIT(5))
 
 #define BK 16
 #define LDT(R) ((R) + 4)  // [k][row] image of an R-row operand tile: 16-byte aligned rows, staggered over banks
@@ -1640,7 +1639,7 @@ static void tail_launch(const TailArgsT<T>& a, int C, hipStream_t s) {
   else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_tail<T, 8, 16, GRAD>), dim3(C), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_tail<T, 4, 32, GRAD>), dim3(C), dim3(256), 0, s, a);
 }
-std::atomic<int> g_ey_no_tail{0};  // ey_debug_set_variant bit 6: the last layer as separate launches (A/B, tests)
+// variant bit 6: the last layer as separate launches (A/B, tests)
 
 void ey_large_free(ey_plan* pl) {
   (void)hipFree(pl->d_work);
@@ -1686,7 +1685,7 @@ static int leap_fuse_slots(const EyModel& m, bool tail) {
   }
   return cursor;
 }
-std::atomic<int> g_ey_no_fuse{0};  // ey_debug_set_variant bit 7: HMC with the separate leapfrog kernel (A/B, tests)
+// variant bit 7: HMC with the separate leapfrog kernel (A/B, tests)
 
 // value (+ gradient when grad != null) for chains [0, C) of theta, using `ws` (2 * C * act_floats floats) as scratch;
 // qpart / nblk: partial sums of the prior quadratic form of theta left by the previous leapfrog update (else k_prior)
@@ -1711,7 +1710,7 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
   int rc, cursor = 0;
   // f32 only: in f64 the fused kernel measured SLOWER than the separate launches (every lane of a row repeats the
   // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
-  const bool tail = sizeof(T) == 4 && tail_ok(m) && !g_ey_no_tail.load();
+  const bool tail = sizeof(T) == 4 && tail_ok(m) && !EY_VBIT(6);
   for (int l = 0; l < (tail ? K - 1 : K); ++l) {
     BGT<T> g = {};
     g.A = l == 0 ? (const T*)m.x : H[l];
@@ -1834,8 +1833,8 @@ static int large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const v
   const int nblk = leap_blocks(P);
   // f32 only: in f64 the fused kernel measured SLOWER than the separate launches (every lane of a row repeats the
   // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
-  const bool tail = sizeof(T) == 4 && tail_ok(m) && !g_ey_no_tail.load();
-  const bool fuse = sizeof(T) == 4 && !g_ey_no_fuse.load();
+  const bool tail = sizeof(T) == 4 && tail_ok(m) && !EY_VBIT(6);
+  const bool fuse = sizeof(T) == 4 && !EY_VBIT(7);
   const int nslots = fuse ? leap_fuse_slots(m, tail) : 0;
   const int nq = nblk > nslots ? nblk : nslots;
   const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc + 2 * (size_t)cc * nq;
@@ -2096,6 +2095,7 @@ int ey_large_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int6
 extern "C" int ey_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int K, long sAm, long sAk, long sBk,
                               long sBn, long sCm, long sCn, long bA, long bB, long bC, const float* bias, long bBias,
                               int act, int batch, void* stream) {
+  EyVariantScope vs(ey_default_variant());
   BG g = {};
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
   g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.sCm = sCm; g.sCn = sCn;

@@ -30,26 +30,33 @@
 
 #include "ey_common.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MF_MAX_TILES 24  // 27 KB data image + 8 x 16.3 KB per-wave regions fit the 160 KB of a CU
 // per-wave LDS carve, in floats (all offsets multiples of 4 => 16-byte aligned b128 accesses)
 #define TS36 36
-#define O_W1IMG 0
-#define O_TB0 1152
-#define O_TB1 2304
-#define O_W0IMG 3456   // [32][5]
-#define O_W2IMG 3616   // [4][36]
-#define O_W2TIMG 3760  // [32][4]
-#define O_B0IMG 3888
-#define O_B1IMG 3920
-#define O_D2BUF 3952   // [4][2][16], the four outputs D2S floats apart
+// The carve depends on BF3 (a compile-time constant in scope wherever these are used): the bf16x3 form keeps the three
+// bf16 pieces of W1's rows (the A operand of the F1 product) in 6 private 16-byte slots per lane and needs the f32
+// image of W1 only while those are made (it then lies in the first transpose buffer).
+#define O_W1P 0        // BF3: [piece 0..2][k-step 0..1][lane] x 16 bytes
+#define O_W1IMG (BF3 ? 1536 : 0)
+#define O_TB0 (BF3 ? 1536 : 1152)
+#define O_TB1 (BF3 ? 2688 : 2304)
+#define O_SMALL (BF3 ? 3840 : 3456)
+#define O_W0IMG (O_SMALL + 0)     // [32][5]
+#define O_W2IMG (O_SMALL + 160)   // [4][36]
+#define O_W2TIMG (O_SMALL + 304)  // [32][4]
+#define O_B0IMG (O_SMALL + 432)
+#define O_B1IMG (O_SMALL + 464)
+#define O_D2BUF (O_SMALL + 496)   // [4][2][16], the four outputs D2S floats apart
 // Stride between the four outputs (delta2) / inputs (x) of the regrouped images: the ds_read_b128 of a lane group takes
 // its four 16-byte pieces from jj = 0..3, which 32 floats apart land on the same banks for jj and jj + 2 (a two-way
 // conflict on eight reads per tile: the 10 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 1); 36 apart they do not.
 #define D2S 36
-#define WAVE_FLOATS 4096
+#define WAVE_FLOATS (BF3 ? 4480 : 4096)
+#define WAVE_FLOATS_OF(bf3) ((bf3) ? 4480 : 4096)
 #define XTILE_FLOATS 304  // per row tile: [32][5] (x0..x3, label) + [4][D2S] (x regrouped for the 4x4x1 product)
 
 // canonical offsets of MLP(4-32-32-3) in theta
@@ -90,6 +97,7 @@ struct MfArgs {
   unsigned char* accepted;
   float *rate, *hcur, *hprop;
   int balance;         // 1: the two waves of a SIMD keep in step through s_setprio (see Pace)
+  int stagger;         // row tiles by which the second wave of a SIMD pair is kept AHEAD of the first (see Pace)
   double *mom_s1, *mom_s2, *mom_acc;  // attached running moments (ey_plan_attach_moments) or null
   // ey_hmc_run: n_iters consecutive draws per launch and the per-iteration records (each nullable)
   int n_iters;
@@ -158,12 +166,16 @@ __device__ unsigned long long g_ey_wave_t[3 * 8192];  // per chain: kernel entry
 #define PH(i) do { if (ph_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += n_ - ph_t; ph_t = n_; } } while (0)
 #define KO(i) do { if (kt_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ko_acc[i] += n_ - ko_t; ko_t = n_; } } while (0)
 #else
-#define PH(i) do { } while (0)
+// BF3: a scheduling barrier at the phase boundaries selected by EY_SB keeps the instruction scheduler from overlapping
+// whole phases (it fills the 256 registers two waves per SIMD allow, and the allocator then spills)
+#ifndef EY_SB
+#define EY_SB 0
+#endif
+#define PH(i) do { if (BF3 && ((EY_SB >> (i)) & 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define KO(i) do { } while (0)
 #endif
 // Packed f32 math (two elements per instruction at the rate of one): written on two-element vectors so that the
 // instruction selector sees v2f32 operations (it scalarises the same operations on a whole 16-element tile).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_add1(f32x2 a) { return a + 1.0f; }
 __device__ __forceinline__ f32x2 pk_h_one_minus_h(f32x2 h) { return __builtin_elementwise_fma(-h, h, h); }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
@@ -201,6 +213,56 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   if (EY_ABLATE & 2) { c[0] += a * 1e-9f; return c; }
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
+// ---- bf16x3 form of the three 32x32x32 products (BF3): every f32 operand element is split into three bf16 pieces,
+// x = hi + mid + lo EXACTLY (round-to-nearest pieces of 8 significant bits each: |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|), and
+// a b is summed from the six piece products of relative size >= 2^-18 on v_mfma_f32_32x32x16_bf16 (products of bf16 are
+// exact in f32; accumulation in f32), smallest terms first.  The three dropped products are below 2^-26 |a b|.
+// Measured against f64 (tools/bf16x3_probe.hip, profiles/r03_bf16x3_probe.txt): rms error 0.56 and maximum 6.2 in units of
+// 2^-24 sum_k |a_k b_k| against 0.95 and 10.4 for the exact kernel's k-ordered f32 fma chain (v_mfma_f32_32x32x2_f32).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Pieces { u32x4 hi[2], mid[2], lo[2]; };  // [k-step s]: operand elements 8s .. 8s+7, packed in pairs
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32, round to nearest even
+}
+__device__ __forceinline__ void split16(const f32x16& v, Pieces& P) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float a = v[8 * s + 2 * d], b = v[8 * s + 2 * d + 1];
+      const unsigned hh = pk_bf16(a, b);
+      const float ra = a - __builtin_bit_cast(float, hh << 16), rb = b - __builtin_bit_cast(float, hh & 0xffff0000u);
+      const unsigned mm_ = pk_bf16(ra, rb);
+      const float sa = ra - __builtin_bit_cast(float, mm_ << 16), sb = rb - __builtin_bit_cast(float, mm_ & 0xffff0000u);
+      P.hi[s][d] = hh;
+      P.mid[s][d] = mm_;
+      P.lo[s][d] = pk_bf16(sa, sb);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += A B over the 32 contracted indices both operands hold as elements 8s+j of k-step s
+__device__ __forceinline__ f32x16 product_bf3(const Pieces& A, const Pieces& B, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    acc = mfma_bf16(A.hi[s], B.lo[s], acc);
+    acc = mfma_bf16(A.lo[s], B.hi[s], acc);
+    acc = mfma_bf16(A.mid[s], B.mid[s], acc);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    acc = mfma_bf16(A.hi[s], B.mid[s], acc);
+    acc = mfma_bf16(A.mid[s], B.hi[s], acc);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) acc = mfma_bf16(A.hi[s], B.hi[s], acc);
+  return acc;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in issue order; this only stops the compiler from moving them.
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -263,7 +325,8 @@ __device__ __forceinline__ void for_each2(Vec& a, Vec& b, F f) {
 }
 
 // stage the operand images of theta in this wave's LDS region
-__device__ __forceinline__ void write_images(float* lw, const Vec& th, int c, int h) {
+template <bool BF3>
+__device__ __forceinline__ void write_images(float* lw, const Vec& th, int c, int h, int lane) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = NEG_LOG2E * th.w1[r];
   if (h == 0) {
@@ -280,6 +343,24 @@ __device__ __forceinline__ void write_images(float* lw, const Vec& th, int c, in
     lw[O_B0IMG + c] = NEG_LOG2E * th.b0;
   }
   wave_lds_fence();
+  if constexpr (BF3) {
+    // row c of the scaled W1 in the element order of the F1 product's k-steps (element 4q+j <-> input 8q+4h+j, the order
+    // in which the accumulator tile H0 holds its features), split once per position; the f32 image is dead after this
+    f32x16 wr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + O_W1IMG + c * TS36 + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wr[4 * q + j] = wv[j];
+    }
+    Pieces A;
+    split16(wr, A);
+    u32x4* pv = reinterpret_cast<u32x4*>(lw + O_W1P) + lane;
+    pv[0 * 64] = A.hi[0]; pv[1 * 64] = A.hi[1];
+    pv[2 * 64] = A.mid[0]; pv[3 * 64] = A.mid[1];
+    pv[4 * 64] = A.lo[0]; pv[5 * 64] = A.lo[1];
+    wave_lds_fence();
+  }
 }
 
 __device__ __forceinline__ void store_T(float* tb, const f32x16& v, int c, int h) {
@@ -297,22 +378,23 @@ __device__ __forceinline__ void store_T(float* tb, const f32x16& v, int c, int h
 // numbers of chains.  The partner's counter is read at the top of a tile and consumed in the middle of it, so the
 // LDS latency is never waited for.
 struct Pace {
-  int* prog;    // [waves] tiles left, per wave of this workgroup
+  int* prog;    // [waves] tiles left (+ bias), per wave of this workgroup
   int wave, partner;
   int left;
+  int bias;     // added to what this wave publishes and compares: the wave then runs `bias` tiles ahead of its partner
   bool on;
 };
 __device__ __forceinline__ int pace_post(Pace& pc, int lane) {
   if (!pc.on) return 0;
   pc.left = __builtin_amdgcn_readfirstlane(pc.left - 1);
-  if (lane == 0) __hip_atomic_store(&pc.prog[pc.wave], pc.left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (lane == 0) __hip_atomic_store(&pc.prog[pc.wave], pc.left + pc.bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return __hip_atomic_load(&pc.prog[pc.partner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
   if (!pc.on) return;
   // (scalar comparison: a vector compare would be lowered to EXEC masking, under which both s_setprio would execute)
   const int theirs = __builtin_amdgcn_readfirstlane(theirs_v);
-  if (pc.left < theirs) __builtin_amdgcn_s_setprio(0);
+  if (pc.left + pc.bias < theirs) __builtin_amdgcn_s_setprio(0);
   else __builtin_amdgcn_s_setprio(1);
 }
 
@@ -326,7 +408,7 @@ __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
 // latency the end of every evaluation then waits for (four serial round trips per leapfrog step before this).
 // GRAD = false: the value only (random-walk MH needs no gradient, metropolis_hastings.py:41-73): the forward products
 // and the row log-sum-exp, about a third of the work.
-template <int PARK, bool UPRIOR, bool GRAD = true>
+template <int PARK, bool UPRIOR, bool BF3, bool GRAD = true>
 __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, bool has_temp, float temp, int c,
                       int h, int lane, bool need_value, Pace& pc) {
   const int jj = lane & 3;
@@ -339,6 +421,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
   const float b2_0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[0])));
   const float b2_1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[1])));
   const float b2_2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[2])));
+  static_assert(PARK == 0 || PARK == 12, "all twelve elements or none");
   if (PARK) {
     float* park = lw + WAVE_FLOATS + lane;
 #pragma unroll
@@ -355,6 +438,17 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
   const bool ph_on = (blockIdx.x & 63) == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
   unsigned long long ph_t = ph_on ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
+  // BF3: W1 crosses the tile loop as its three bf16 pieces (the B operand of dH0 = delta1 W1, 24 registers) instead of
+  // as 16 floats; the floats are rebuilt after the loop (hi + mid + lo is exact), so they are not live inside it.
+  Pieces Bw;
+  if constexpr (BF3 && GRAD) {
+    f32x16 w1v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w1v[r] = th.w1[r];
+    split16(w1v, Bw);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(Bw.hi[s]), "+v"(Bw.mid[s]), "+v"(Bw.lo[s]));
+  }
   // One 32-row tile.  SG = the 8-row k-groups of the row-contracting products (dW2, dW1, dW0) that hold rows: 4, or 3
   // in the copy the last tile of a batch takes when its rows 24..31 are all padding (a quarter of its dW1 product).
   auto tile = [&](const int t, auto sg_tag) __attribute__((always_inline)) {
@@ -383,11 +477,23 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
     }
+    if constexpr (BF3) {
+      // A = the pieces of W1's row c (made once per position by write_images), B = the accumulator tile H0 itself:
+      // elements 8s+j of k-step s are features 16s + 8(j>>2) + 4h + (j&3) in both
+      Pieces B1p, A1p;
+      split16(H0, B1p);
+      const u32x4* pv = reinterpret_cast<const u32x4*>(lw + O_W1P) + lane;
+      A1p.hi[0] = pv[0 * 64]; A1p.hi[1] = pv[1 * 64];
+      A1p.mid[0] = pv[2 * 64]; A1p.mid[1] = pv[3 * 64];
+      A1p.lo[0] = pv[4 * 64]; A1p.lo[1] = pv[5 * 64];
+      acc = product_bf3(A1p, B1p, acc);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + O_W1IMG + c * TS36 + 8 * q + 4 * h);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + O_W1IMG + c * TS36 + 8 * q + 4 * h);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], H0[4 * q + j], acc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], H0[4 * q + j], acc, 0, 0, 0);
+      }
     }
     pace_apply(pc, pace_theirs);  // while the F1 products run
     const f32x16 H1 = sigmoid_tile(acc);
@@ -462,8 +568,9 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     PH(6);
     // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
     f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
+    f32x16 D1U;  // BF3: delta1 likewise (lane <-> output feature)
 #pragma unroll
-    for (int r = 4 * SG; r < 16; ++r) H0U[r] = 0.0f;
+    for (int r = 4 * SG; r < 16; ++r) { H0U[r] = 0.0f; D1U[r] = 0.0f; }
 #pragma unroll
     for (int s = 0; s < SG; ++s) {
       const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
@@ -471,10 +578,18 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         H0U[4 * s + i] = hu[i];
-        if (EY_ABLATE & 8) dW1[i] += du[i] * hu[i];
+        if constexpr (BF3) D1U[4 * s + i] = du[i];
+        else if (EY_ABLATE & 8) dW1[i] += du[i] * hu[i];
         else dW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(du[i], hu[i], dW1, 0, 0, 0);
       }
       db1 += (du[0] + du[1]) + (du[2] + du[3]);
+    }
+    if constexpr (BF3) {
+      // both operands hold row 8s+4h+i as element 4s+i: any common order of the contracted index serves
+      Pieces Ad, Bh;
+      split16(D1U, Ad);
+      split16(H0U, Bh);
+      dW1 = product_bf3(Ad, Bh, dW1);
     }
     PH(7);
     // ---- B1(1): dH0 = delta1 W1 computed UNtransposed (A = delta1 tile with M = rows, B = theta's own W1
@@ -482,8 +597,14 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     // comes out in the layout the dW0 product needs, with no LDS round trip (layer 0 is the last consumer).
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    if constexpr (BF3) {
+      Pieces Ad;
+      split16(D1, Ad);
+      acc = product_bf3(Ad, Bw, acc);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
+    }
     const f32x16 D0u = times_dsigmoid(acc, H0U);
     PH(8);
     // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
@@ -505,6 +626,19 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
 #pragma unroll 1
   for (int t = 0; t < nfull; ++t) tile(t, std::integral_constant<int, 4>());
   if (A.short_last) tile(nfull, std::integral_constant<int, 3>());
+  if constexpr (BF3 && GRAD) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(Bw.hi[s]), "+v"(Bw.mid[s]), "+v"(Bw.lo[s]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int s = r >> 3, d = (r & 7) >> 1;
+      const unsigned hh = Bw.hi[s][d], mm_ = Bw.mid[s][d], ll = Bw.lo[s][d];
+      const float fh = __builtin_bit_cast(float, (r & 1) ? (hh & 0xffff0000u) : (hh << 16));
+      const float fm = __builtin_bit_cast(float, (r & 1) ? (mm_ & 0xffff0000u) : (mm_ << 16));
+      const float fl = __builtin_bit_cast(float, (r & 1) ? (ll & 0xffff0000u) : (ll << 16));
+      th.w1[r] = (fh + fm) + fl;
+    }
+  }
   if (PARK) {
     int at = WAVE_FLOATS + lane;
     asm volatile("" : "+v"(at));  // an offset the compiler cannot match with the stores above: no forwarding
@@ -631,6 +765,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
 // l, l + 64, ... (ey_rng_normal4: one Philox call per block) into the two transpose buffers of this wave's LDS region
 // (free between evaluations), from where every lane then picks the 29 elements of its register layout.  One call
 // per element in every lane, as a lane-local draw needs, costs 29 Philox calls per lane instead of at most 6.
+template <bool BF3>
 __device__ __forceinline__ const float* stage_normals(float* lw, const EyRng& rn, int lane) {
   float* st = lw + O_TB0;  // O_TB0 and O_TB1 are adjacent: 2304 floats >= NPAR + 3
   constexpr int NB = (NPAR + 3) / 4;
@@ -644,7 +779,7 @@ __device__ __forceinline__ const float* stage_normals(float* lw, const EyRng& rn
 }
 
 // One chain of one launch: everything between reading theta and writing the accepted state back.
-template <int MODE, int PARK, bool UPRIOR, bool DA>
+template <int MODE, int PARK, bool UPRIOR, bool DA, bool BF3>
 __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int it,
                                           const int c, const int h, const int lane, Pace& pc) {
   // Later iterations of one launch read what this wave's lanes wrote at the end of the previous one.  Workgroup scope
@@ -668,8 +803,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   for_each(th, c, h, lane, [&](float& v, int idx, bool) { v = thg[idx]; });
 
   if (MODE == MODE_GRAD) {
-    write_images(lw, th, c, h);
-    const float t = eval<PARK, UPRIOR>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3>(lw, th, c, h, lane);
+    const float t = eval<PARK, UPRIOR, BF3>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
     for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
     if (lane == 0) A.target[chain] = t;
     return;
@@ -684,7 +819,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     float qf = 0.0f;
     Vec gp;
     if (MODE == MODE_MALA) for_each(g, c, h, lane, [&](float& v, int idx, bool) { v = grg[idx]; });
-    const float* zst = zin ? nullptr : stage_normals(lw, rn, lane);
+    const float* zst = zin ? nullptr : stage_normals<BF3>(lw, rn, lane);
     for_each3(th, g, p, c, h, lane, [&](float& tv, float& gv, float& pv, int idx, bool counts) {
       const float zi = zin ? zin[idx] : zst[idx];
       if (MODE == MODE_MALA) {
@@ -697,8 +832,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
       }
     });
     wave_lds_fence();  // the staged normals have been read; the evaluation reuses that LDS
-    write_images(lw, p, c, h);
-    const float tv = eval<PARK, UPRIOR, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3>(lw, p, c, h, lane);
+    const float tv = eval<PARK, UPRIOR, BF3, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
     const float t_old = A.target[chain];
     float log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
     if (MODE == MODE_MALA) {
@@ -740,7 +875,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   if (MODE == MODE_HMC) {
     const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_NORMAL);
     const float* p0 = A.p0 ? A.p0 + chain * NPAR : nullptr;
-    const float* pst = p0 ? nullptr : stage_normals(lw, rn, lane);
+    const float* pst = p0 ? nullptr : stage_normals<BF3>(lw, rn, lane);
     for_each(p, c, h, lane, [&](float& v, int idx, bool counts) {
       v = p0 ? p0[idx] : pst[idx];   // hmc.py:134
       if (counts) kin += v * v;
@@ -756,8 +891,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   const float h_cur = -t_cur + 0.5f * kin;  // hmc.py:91-98,137
   float t = t_cur;
   if (MODE == MODE_LEAPFROG || A.recompute) {  // hmc.py:104
-    write_images(lw, th, c, h);
-    t = eval<PARK, UPRIOR>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3>(lw, th, c, h, lane);
+    t = eval<PARK, UPRIOR, BF3>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
   }
   // leapfrog, hmc.py:100-124 (grad_potential = -grad)
   for_each2(p, g, [&](float& pv, float& gv) { pv = pv + 0.5f * eps * gv; });
@@ -766,9 +901,9 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   for (int k = 1; k <= A.L; ++k) {
     for_each2(th, p, [&](float& tv, float& pv) { tv = tv + eps * pv; });
     KO(1);
-    write_images(lw, th, c, h);
+    write_images<BF3>(lw, th, c, h, lane);
     KO(2);
-    t = eval<PARK, UPRIOR>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc);
+    t = eval<PARK, UPRIOR, BF3>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc);
     KO(3);
     const float w = (k < A.L) ? eps : 0.5f * eps;
     for_each2(p, g, [&](float& pv, float& gv) { pv = pv + w * gv; });
@@ -846,7 +981,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
 // Two waves share a SIMD because f32 MFMA runs on the vector ALUs: the partner hides latency (LDS round trips, MFMA
 // result latency) rather than adding throughput (tools/coexec_probe*.hip).  WAVES = 4 is the former layout (two
 // 4-wave workgroups per CU, one chain per wave), kept for A/B runs (ey_debug_set_variant bit 0).
-template <int MODE, int WAVES, int PARK, bool UPRIOR, bool DA>
+template <int MODE, int WAVES, int PARK, bool UPRIOR, bool DA, bool BF3>
 __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   constexpr int MF_WAVES = WAVES, MF_THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -876,10 +1011,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   pc.wave = wave;
   pc.partner = wave;
   pc.left = 0;
+  pc.bias = 0;
   int mates = 0;
   for (int w = 0; w < MF_WAVES; ++w)
     if (w != wave && ctl[MF_WAVES + w] == simd) { pc.partner = w; ++mates; }
   pc.on = A.balance != 0 && mates == 1;
+  if (pc.on && wave > pc.partner) pc.bias = A.stagger;
 #if EY_PHASE_TIMING
   if (blockIdx.x == 0 && lane == 0) {
     g_ey_dbg[wave] = simd;
@@ -894,10 +1031,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
     const int evals = (MODE == MODE_HMC) ? A.L + (A.recompute ? 1 : 0) : (MODE == MODE_LEAPFROG ? A.L + 1 : 1);
     const int iters = (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) ? A.n_iters : 1;
     pc.left = (int)std::min<int64_t>(mine * evals * A.ntiles * iters, 0x3fffffff);
-    if (lane == 0) ctl[wave] = pc.left;
+    if (lane == 0) ctl[wave] = pc.left + pc.bias;
   }
   __syncthreads();
-  if (__builtin_amdgcn_readfirstlane(ctl[pc.partner]) == 0) pc.on = false;  // the partner has no chain at all
+  if (__builtin_amdgcn_readfirstlane(ctl[pc.partner]) - (pc.partner > wave ? A.stagger : 0) == 0)
+    pc.on = false;  // the partner has no chain at all
   const int n_iters = (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) ? A.n_iters : 1;
   // Chain-major: a wave takes one of its chains through all iterations of the launch before it starts the next (the
   // chains are independent), so the 21 KB of f64 moment accumulators and the state it reads back stay in this CU's
@@ -911,7 +1049,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
 #if EY_PHASE_TIMING
       if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain] = rt_entry;
 #endif
-      run_chain<MODE, PARK, UPRIOR, DA>(*Ap, xs, lw, chain, it, c, h, lane, pc);
+      run_chain<MODE, PARK, UPRIOR, DA, BF3>(*Ap, xs, lw, chain, it, c, h, lane, pc);
     }
   }
   if (lane == 0) __hip_atomic_store(&ctl[wave], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // nothing left
@@ -926,10 +1064,11 @@ bool ey_mfma32_supports(const ey_plan* pl) {
   return m.act[0] == EY_ACT_SIGMOID && m.act[1] == EY_ACT_SIGMOID && m.act[2] == EY_ACT_NONE;
 }
 
-static size_t mf_lds_bytes(int ntiles, int waves, int park) {
-  return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * (WAVE_FLOATS + 64 * park)) +
+static size_t mf_lds_bytes(int ntiles, int waves, int park, bool bf3) {
+  return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * (WAVE_FLOATS_OF(bf3) + 64 * park)) +
          sizeof(int) * 2 * waves;
 }
+#define MF_BF3_TILES 16   // the bf16x3 form's larger per-wave region leaves room for 16 row tiles (N <= 512)
 #define MF_PARK 12        // position elements parked in LDS during the tile loop ...
 #define MF_PARK_TILES 6   // ... when the data image leaves room for it (N <= 192 rows)
 
@@ -939,7 +1078,6 @@ static size_t mf_lds_bytes(int ntiles, int waves, int park) {
 // narrow last layer as separate launches instead of the fused tail kernel, bit 7 = the layerwise path's leapfrog update
 // as a separate kernel instead of in the gradient kernels' epilogues
 // ey_debug_set_variant (ey_api.hip) bits 0..3: launch variants of this kernel, for A/B runs and tests
-std::atomic<int> g_ey_mf_variant{0};
 
 // Pack (x, labels) into the per-tile LDS images, on the device and on the caller's stream: one thread per (tile, row).
 // Rows beyond N are zero with label -1 (they contribute nothing).
@@ -981,18 +1119,18 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
   return EY_OK;
 }
 
-template <int MODE, int WAVES, int PARK, bool UPRIOR = false, bool DA = true>
+template <int MODE, int WAVES, int PARK, bool UPRIOR = false, bool DA = true, bool BF3 = false>
 static int mf_launch_v(MfArgs& a, int n_cu, hipStream_t s) {
-  const size_t bytes = mf_lds_bytes(a.ntiles, WAVES, PARK);
+  const size_t bytes = mf_lds_bytes(a.ntiles, WAVES, PARK, BF3);
   // per launch: function attributes are per device and plans on different devices / threads share this code
-  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PARK, UPRIOR, DA>),
+  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PARK, UPRIOR, DA, BF3>),
                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)mf_lds_bytes(PARK ? MF_PARK_TILES : MF_MAX_TILES, WAVES, PARK)));
+                             (int)mf_lds_bytes(BF3 ? MF_BF3_TILES : (PARK ? MF_PARK_TILES : MF_MAX_TILES), WAVES, PARK, BF3)));
   // 8 waves: one persistent workgroup per CU, or one per chain when there are fewer chains than CUs (then only wave
   // 0 of a workgroup has work and every chain gets a CU to itself); 4 waves: a workgroup per 4 chains
   const unsigned grid = WAVES == 8 ? (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256)
                                    : (unsigned)((a.C + WAVES - 1) / WAVES);
-  hipLaunchKernelGGL((k_mfma32<MODE, WAVES, PARK, UPRIOR, DA>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+  hipLaunchKernelGGL((k_mfma32<MODE, WAVES, PARK, UPRIOR, DA, BF3>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
@@ -1009,20 +1147,30 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.prior_const = (float)m.prior_const;
   a.ntiles = (m.N + 31) / 32;
   a.short_last = (m.N - 32 * (a.ntiles - 1)) <= 24 ? 1 : 0;
-  a.balance = (g_ey_mf_variant.load() & 2) ? 0 : 1;
+  a.balance = (t_ey_variant & 2) ? 0 : 1;
+  {
+    static const int stagger = [] { const char* e = getenv("EY_MF_STAGGER"); return e ? atoi(e) : 0; }();
+    a.stagger = stagger;
+  }
   if (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) {
     a.mom_s1 = pl->mom_s1;
     a.mom_s2 = pl->mom_s2;
     a.mom_acc = pl->mom_acc;
   }
+  const bool bf3 = pl->products == EY_PRODUCTS_BF16X3 && a.ntiles <= MF_BF3_TILES && !(t_ey_variant & 1);
   if constexpr (MODE == MODE_HMC) {
-    const int variant = g_ey_mf_variant.load();
+    const int variant = t_ey_variant & 15;
     if (variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);
+    if (bf3) {
+      if (a.prior_uniform && !a.da_state) return mf_launch_v<MODE, 8, 0, true, false, true>(a, pl->n_cu, s);
+      return mf_launch_v<MODE, 8, 0, false, true, true>(a, pl->n_cu, s);
+    }
     // the headline shape (few row tiles, one Normal(m, s) prior for all parameters) has its own, leaner instantiation
     if (a.ntiles <= MF_PARK_TILES && a.prior_uniform && !(variant & 4))
       return a.da_state ? mf_launch_v<MODE, 8, MF_PARK, true, true>(a, pl->n_cu, s)
                         : mf_launch_v<MODE, 8, MF_PARK, true, false>(a, pl->n_cu, s);
   }
+  if (bf3) return mf_launch_v<MODE, 8, 0, false, true, true>(a, pl->n_cu, s);
   return mf_launch_v<MODE, 8, 0>(a, pl->n_cu, s);
 }
 

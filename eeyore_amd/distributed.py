@@ -129,27 +129,41 @@ def multi_rhat_sharded(samples_local, layout="ncp", group=None):
     rank reduces its own chains on its device (``ey_inse_multivariate``: per-chain MC covariance and mean), then the
     sum of the MC covariances is all-reduced ([p,p] doubles) and the chain means are all-gathered ([C_local,p] doubles
     per rank; ranks may hold different numbers of chains).  Every rank returns the same
-    (rhat, imag, W, B, is_w_pd, is_b_pd)."""
+    (rhat, imag, W, B, is_w_pd, is_b_pd).  A chain for which the reference's estimator raises 'Not enough samples'
+    (inse_mc_cov.py:45-46) makes every rank raise that error, as the reference's loop over chains would
+    (multi_rhat.py:19): the flag travels with the chain counts, it costs no collective of its own."""
     from .stats import batched
     r = batched.inse_multivariate(samples_local, layout)
-    return multi_rhat_from_local_parts(r["sig"].sum(0), r["mean"], r["n"], group=group)
+    short = torch.isnan(r["sig"]).flatten(1).any(1).sum()
+    return multi_rhat_from_local_parts(torch.nan_to_num(r["sig"], nan=0.0).sum(0), r["mean"], r["n"], group=group,
+                                       not_enough_local=short)
 
 
-def multi_rhat_from_local_parts(w_sum_local, means_local, n, group=None):
-    """The collective half of ``multi_rhat_sharded`` (on whatever device / backend the tensors live on)."""
+def multi_rhat_from_local_parts(w_sum_local, means_local, n, group=None, not_enough_local=None):
+    """The collective half of ``multi_rhat_sharded`` (on whatever device / backend the tensors live on): one all-reduce
+    of the [p,p] sum, one all-gather of (chain count, chains without enough samples) -- read back once, for every rank
+    together -- and one all-gather of the padded chain means."""
     from .stats import batched
     w_sum, means = w_sum_local.clone(), means_local
+    dev = means.device
+    short = torch.zeros((), dtype=torch.int64, device=dev) if not_enough_local is None else not_enough_local.to(torch.int64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         dist.all_reduce(w_sum, op=dist.ReduceOp.SUM, group=group)
-        counts = [torch.zeros(1, dtype=torch.int64, device=means.device) for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([means.shape[0]], dtype=torch.int64, device=means.device), group=group)
-        cmax = int(max(c.item() for c in counts))
-        padded = torch.zeros(cmax, means.shape[1], dtype=means.dtype, device=means.device)
+        mine = torch.stack([torch.tensor(means.shape[0], dtype=torch.int64, device=dev), short.reshape(())])
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        info = torch.stack(parts).tolist()  # the one host read-back of the gather
+        counts, n_short = [c for c, _ in info], sum(s_ for _, s_ in info)
+        padded = torch.zeros(max(counts), means.shape[1], dtype=means.dtype, device=dev)
         padded[:means.shape[0]] = means
         gathered = [torch.empty_like(padded) for _ in range(world)]
         dist.all_gather(gathered, padded, group=group)
-        means = torch.cat([g[:int(c.item())] for g, c in zip(gathered, counts)])
+        means = torch.cat([g[:c] for g, c in zip(gathered, counts)])
+    else:
+        n_short = int(short.item())
+    if n_short:
+        raise RuntimeError(f'Not enough samples ({n_short} of {means.shape[0]} chains)')
     return batched.multi_rhat_from_parts(w_sum, means, n)
 
 

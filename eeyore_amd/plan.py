@@ -40,6 +40,7 @@ class Plan:
         self._data_key, self._data_ref = None, (None, None)
         self._prior_key = None
         self._moments = None
+        self._da_refs = None  # tensors an attached dual averaging points into: alive for as long as it is attached
 
     def __del__(self):
         try:
@@ -52,6 +53,26 @@ class Plan:
     @property
     def kernel(self):
         return L.lib().ey_plan_kernel(self.handle).decode()
+
+    @property
+    def f32_products(self):
+        """'bf16x3' or 'exact': how the fused f32 trajectory kernel forms its 32x32x32 products (EY_OPT_F32_PRODUCTS in
+        include/eeyore_amd.h); only plans that kernel serves are affected."""
+        v = ct.c_int()
+        L.check(L.lib().ey_plan_get_option(self.handle, L.EY_OPT_F32_PRODUCTS, ct.byref(v)), "ey_plan_get_option")
+        return "exact" if v.value == L.EY_PRODUCTS_EXACT else "bf16x3"
+
+    @f32_products.setter
+    def f32_products(self, mode):
+        if mode not in ("bf16x3", "exact"):
+            raise ValueError("f32_products must be 'bf16x3' or 'exact'")
+        L.check(L.lib().ey_plan_set_option(self.handle, L.EY_OPT_F32_PRODUCTS,
+                                           L.EY_PRODUCTS_EXACT if mode == "exact" else L.EY_PRODUCTS_BF16X3),
+                "ey_plan_set_option")
+
+    def set_variant(self, variant):
+        """Diagnostic switches of THIS plan (ey_plan_set_variant); returns the previous value."""
+        return L.lib().ey_plan_set_variant(self.handle, int(variant))
 
     # ------------------------------------------------------------------ data / prior
     def _prep(self, t, shape=None):
@@ -131,6 +152,22 @@ class Plan:
         L.check(L.lib().ey_log_target_grad(self.handle, L.ptr(theta), L.ptr(temp), C, L.ptr(target), L.ptr(grad),
                                            _stream(self.device)), "ey_log_target_grad")
         return target, grad
+
+    # ------------------------------------------------------------------ attached dual averaging
+    def attach_da(self, state, step_vec, table, n, d, log_eub=None, final_avg=True):
+        """ey_plan_attach_da; the plan keeps the three tensors alive until ``detach_da`` (the library holds raw device
+        pointers into them and writes the step and the state after every adapting iteration)."""
+        L.check(L.lib().ey_plan_attach_da(self.handle, L.ptr(state), L.ptr(step_vec), L.ptr(table), int(n),
+                                          int(step_vec.shape[0]), float(d),
+                                          float('nan') if log_eub is None else float(log_eub), int(bool(final_avg))),
+                "ey_plan_attach_da")
+        self._da_refs = (state, step_vec, table)
+
+    def detach_da(self):
+        """Drop whatever dual averaging is attached (a no-op when none is): safe to call before every run."""
+        L.check(L.lib().ey_plan_attach_da(self.handle, None, None, None, 0, 0, 0.5, float('nan'), 0),
+                "ey_plan_attach_da")
+        self._da_refs = None
 
     # ------------------------------------------------------------------ attached running moments
     def attach_moments(self, s1, s2, acc, on_step=None):

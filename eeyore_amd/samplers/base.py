@@ -138,6 +138,9 @@ class SingleChainSerialSampler(SerialSampler):
             return super().run(num_epochs, num_burnin_epochs, verbose=verbose, verbose_step=verbose_step)
         plan = self.model._plan(x, y)
         tuner = getattr(self, 'tuner', None)
+        # Whatever an earlier run left attached goes first: a run that raised or was interrupted during burn-in would
+        # otherwise leave the plan (cached on the model) with device pointers into a tuner that may be gone by now.
+        plan.detach_da()
         # a per-chain dual-averaging tuner can run inside the fused kernels' epilogue (ey_plan_attach_da): burn-in is
         # then blocks of iterations per launch too
         in_kernel_da = (hasattr(tuner, 'attach') and plan.kernel in ('mfma32', 'fused16')
@@ -145,22 +148,24 @@ class SingleChainSerialSampler(SerialSampler):
         if in_kernel_da:
             tuner.attach(plan, counter.num_burnin_iters - counter.idx, idx0=counter.idx)
             self.step = tuner.step
-        while counter.idx < counter.num_iters:
-            burning = counter.idx < counter.num_burnin_iters
-            if in_kernel_da and not burning:
+        try:
+            while counter.idx < counter.num_iters:
+                burning = counter.idx < counter.num_burnin_iters
+                if in_kernel_da and not burning:
+                    tuner.detach()
+                    self.step, in_kernel_da = tuner.step, False
+                if burning and tuner is not None and not in_kernel_da:
+                    self.draw(x, y, savestate=False)  # the tuner looks at every iteration's acceptance rates
+                    counter.increment_idx()
+                    continue
+                k = min(self.fused_block, (counter.num_burnin_iters if burning else counter.num_iters) - counter.idx)
+                self._draw_block(x, y, k, savestate=not burning)
+                for _ in range(k):
+                    counter.increment_idx()
+        finally:
+            if in_kernel_da:  # a run that ends (or fails, or is interrupted) inside burn-in
                 tuner.detach()
-                self.step, in_kernel_da = tuner.step, False
-            if burning and tuner is not None and not in_kernel_da:
-                self.draw(x, y, savestate=False)  # the tuner looks at every iteration's acceptance rates
-                counter.increment_idx()
-                continue
-            k = min(self.fused_block, (counter.num_burnin_iters if burning else counter.num_iters) - counter.idx)
-            self._draw_block(x, y, k, savestate=not burning)
-            for _ in range(k):
-                counter.increment_idx()
-        if in_kernel_da:  # a run that ends inside burn-in
-            tuner.detach()
-            self.step = tuner.step
+                self.step = tuner.step
 
     def _draw_block(self, x, y, k, savestate):
         plan = self.model._plan(x, y)
@@ -212,8 +217,12 @@ class SingleChainSerialSampler(SerialSampler):
         (bayesian_model.py:33-34,48-49 multiply both by the temperature)."""
         old = self._temp()
         self.temperature = temperature
-        if old is not None and getattr(self, '_target', None) is not None:
-            ratio = (temperature / old).to(self._target.dtype)
+        if getattr(self, '_target', None) is not None:
+            kw = dict(device=self._target.device, dtype=self._target.dtype)
+            # no temperature so far = temperature one (bayesian_model.py:33-34: `if self.temperature is not None`)
+            t_old = torch.ones((), **kw) if old is None else torch.as_tensor(old, **kw)
+            t_new = torch.ones((), **kw) if temperature is None else torch.as_tensor(temperature, **kw)
+            ratio = (t_new / t_old).expand(self._target.shape[0]).contiguous()
             self._target *= ratio
             if getattr(self, '_grad', None) is not None:
                 self._grad *= ratio[:, None]

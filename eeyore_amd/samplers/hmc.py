@@ -15,21 +15,31 @@ class HMC(SingleChainSerialSampler):
     ``recompute_initial_grad=True`` re-evaluates the gradient at the start of each trajectory exactly as hmc.py:104
     does (same values, one more evaluation); ``step`` may be a [C] tensor and ``temperature`` a [C] tensor.
     ``chain`` defaults to a fresh chain per sampler (the reference's default argument is one ChainList shared by
-    every sampler, hmc.py:11)."""
+    every sampler, hmc.py:11).  ``init_step_mode``: how a tuner without a starting step gets one -- 'intended'
+    (default: the step-doubling heuristic hmc.py:38-77 set out to write) or 'reference' (what those lines compute,
+    integer powers included; see ``init_step``)."""
 
     keys = ['sample', 'target_val', 'grad_val', 'momentum', 'hamiltonian', 'accepted']
 
     def __init__(self, model, theta0=None, dataloader=None, data0=None, counter=None, step=0.1, num_steps=10,
                  tuner=None, chain=None, rng=None, seed=0, chain_offset=0, recompute_initial_grad=False,
-                 temperature=None):
+                 temperature=None, init_step_mode='intended'):
         super().__init__(default_counter(counter, dataloader))
         self._configure(model, dataloader, theta0, chain, rng, seed, chain_offset, temperature)
+        if init_step_mode not in ('intended', 'reference'):
+            raise ValueError("init_step_mode must be 'intended' or 'reference'")
         self.tuner = tuner
         self.recompute_initial_grad = recompute_initial_grad
         self.step, self.num_steps = step, num_steps
         if isinstance(tuner, HMCDATuner):
             if tuner.e0 is None:  # find a starting step size, then let dual averaging shrink towards it (hmc.py:17-27)
-                self.init_step(theta0.clone().detach())
+                self.init_step(theta0.clone().detach(), intended=init_step_mode == 'intended')
+                if not self.step > 0:
+                    # 'reference' mode, halving direction: the reference's 2**(-1) on an integer tensor is 0 and its
+                    # tuner.num_steps then divides by zero (hmc.py:27,60); the same exception class, with the reason
+                    raise ZeroDivisionError(
+                        "HMC.init_step (init_step_mode='reference') collapsed the step to 0 as eeyore's integer "
+                        "torch.pow(2, -1) does; pass init_step_mode='intended' or give the tuner a starting step e0")
                 if tuner.eub is not None:
                     self.step = min(tuner.eub, self.step)
                 tuner.set_m(self.step)
@@ -80,10 +90,12 @@ class HMC(SingleChainSerialSampler):
 
         The reference's direction a = 2 (r > 1/2) - 1 is an integer tensor, so its ``torch.pow(2, -a)`` / ``torch.pow(2, a)``
         (:60, :67) are integer powers and 2**(-1) is 0: for a = +1 the step doubles until r underflows to 0 (or is NaN),
-        for a = -1 it becomes 0 at once (``tuner.num_steps`` then raises ZeroDivisionError, :27).  That behaviour is kept
-        by default so that a run started here starts where the reference's does (pinned by the G9 fixture);
-        ``intended=True`` gives what :58-77 set out to write (Hoffman & Gelman 2014, algorithm 4: double or halve until r
-        crosses 1/2), which is also what ``init_step_per_chain`` does."""
+        for a = -1 it becomes 0 at once (``tuner.num_steps`` then raises ZeroDivisionError, :27).  ``intended=False``
+        reproduces exactly that (pinned by the G9 fixture; the constructor's ``init_step_mode='reference'``);
+        ``intended=True`` -- what the constructor uses unless told otherwise -- gives what :58-77 set out to write
+        (Hoffman & Gelman 2014, algorithm 4: double or halve until r crosses 1/2), which is also what
+        ``init_step_per_chain`` does.  (x, y) is the first batch of the loader and h_start is computed once, as in the
+        full-batch case of the reference; with minibatches the reference draws a new batch per trial.)"""
         x, y = next(iter(self.dataloader))
         self.step, self.num_steps = 1., 1
         th = (theta if theta.dim() == 1 else theta[0]).to(self.model.device, self.model.dtype)

@@ -107,18 +107,13 @@ class PerChainDATuner(Tuner):
         self._table = torch.tensor([self.coefficients(idx0 + k) for k in range(n)], dtype=torch.float64,
                                    device=dev).contiguous()
         self.step = self.step.contiguous()
-        L.check(L.lib().ey_plan_attach_da(plan.handle, L.ptr(self._state), L.ptr(self.step), L.ptr(self._table), n,
-                                          self.step.shape[0], float(self.d),
-                                          float('nan') if self.logeub is None else self.logeub, int(bool(final_avg))),
-                "ey_plan_attach_da")
+        plan.attach_da(self._state, self.step, self._table, n, self.d, self.logeub, final_avg)
         self._attached = plan
 
     def detach(self):
         """Stop adapting inside the kernels and take their state back (``barh``, ``logbare``; ``step`` was theirs)."""
         if self._attached is None:
             return
-        from eeyore_amd import _lib as L
-        L.check(L.lib().ey_plan_attach_da(self._attached.handle, None, None, None, 0, 0, 0.5, float('nan'), 0),
-                "ey_plan_attach_da")
+        self._attached.detach_da()
         self.barh, self.logbare = self._state[:, 0].clone(), self._state[:, 1].clone()
         self._attached = None

@@ -45,6 +45,20 @@ enum ey_lik {
 
 enum ey_dtype { EY_F32 = 0, EY_F64 = 1 }; /* model.dtype, eeyore/models/model.py:7-10 */
 
+/* Plan options (ey_plan_set_option).
+ * EY_OPT_F32_PRODUCTS: how the fused f32 trajectory kernel ("mfma32": MLP(4-32-32-3), BASELINE configs 3/4) forms its three
+ * 32x32x32 products per row tile.  The reference computes them with torch's f32 matmul (eeyore/models/mlp.py:45-50 ->
+ * nn.Linear); both forms below are f32 in, f32 out, f32 accumulate, and both pass every f32 parity test at the same
+ * tolerances:
+ *   EY_PRODUCTS_BF16X3 (default): each f32 operand is split EXACTLY into three bf16 pieces (hi + mid + lo = x) and the
+ *     product is summed from the six piece products of relative size >= 2^-18 on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 is
+ *     exact in f32, accumulation in f32, smallest terms first); measured error against f64 <= the exact form's
+ *     (profiles/r03_bf3_error_probe.txt, tests/test_bf16x3.py); taken for batches of up to 512 rows;
+ *   EY_PRODUCTS_EXACT: v_mfma_f32_32x32x2_f32, bit for bit a k-ordered f32 fma chain.
+ * The environment variable EY_F32_PRODUCTS=exact|bf16x3 sets what new plans start with. */
+enum ey_option { EY_OPT_F32_PRODUCTS = 1 };
+enum ey_products { EY_PRODUCTS_BF16X3 = 0, EY_PRODUCTS_EXACT = 1 };
+
 enum ey_flags {
   EY_RECOMPUTE_INITIAL_GRAD = 1, /* HMC: re-evaluate the gradient at the start of the trajectory exactly as
                                     hmc.py:104 does (L+1 evaluations) instead of using the cached `grad` (L) */
@@ -65,6 +79,8 @@ int ey_plan_num_params(const ey_plan* plan, int64_t* P);
  * (fused 16x16x4 trajectory, f32 and f64), "bgemm" (layerwise batched GEMMs for models beyond LDS, f32 and f64) or
  * "generic" */
 const char* ey_plan_kernel(const ey_plan* plan);
+int ey_plan_set_option(ey_plan* plan, int option, int value);
+int ey_plan_get_option(const ey_plan* plan, int option, int* value);
 
 /* The (x, y) full batch the samplers receive from their DataLoader (eeyore/samplers/serial_sampler.py:41-46).
  * x [N, d_0]; y [N, d_K] (one-hot for CE as XYDataset(yonehot=True) yields, {0,1} for BCE).  Copied into the plan. */
@@ -208,10 +224,13 @@ int ey_plan_attach_moments(ey_plan* plan, void* s1, void* s2, void* acc, int64_t
 int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* table, int64_t n, int64_t C, double d,
                       double log_eub, int final_avg);
 
-/* Diagnostic switches for A/B runs and tests (not part of the drop-in surface); returns the previous value.  Bits 0..3:
- * workgroup shape / issue-priority variants of the fused f32 trajectory kernel; 4: f32 plans through the layerwise
- * path; 5, 6, 7: that path without LDS-DMA staging / fused last layer / fused leapfrog update; 8, 9: tiny models never /
- * always through the register-resident evaluation of the generic kernels.  Results agree to rounding across them. */
+/* Diagnostic switches for A/B runs and tests (not part of the drop-in surface).  They are state of the PLAN:
+ * ey_plan_set_variant changes one plan and returns its previous value; ey_debug_set_variant sets what plans created
+ * afterwards start with (also EY_VARIANT in the environment) and returns the previous default.  Bits 0..2: workgroup
+ * shape / issue-priority / parking variants of the fused f32 trajectory kernel; 4: f32 plans through the layerwise path;
+ * 5, 6, 7: that path without LDS-DMA staging / fused last layer / fused leapfrog update; 8, 9: tiny models never / always
+ * through the register-resident evaluation of the generic kernels.  Results agree to rounding across them. */
+int ey_plan_set_variant(ey_plan* plan, int variant);
 int ey_debug_set_variant(int variant);
 
 /* Test / measurement entry of the layerwise path's batched f32 product (not part of the drop-in surface):

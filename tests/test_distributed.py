@@ -207,3 +207,71 @@ def test_sharded_multi_rhat_equals_the_reference_value():
         np.testing.assert_allclose(rhat, float(z["multi_rhat"]), rtol=1e-10)
         np.testing.assert_allclose(W, z["W"], rtol=1e-10, atol=1e-14)
         np.testing.assert_allclose(B, z["B"], rtol=1e-10)
+
+
+def _rhat_short_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from eeyore_amd.distributed import multi_rhat_from_local_parts
+    p = 3
+    w = torch.eye(p, dtype=torch.float64)
+    means = torch.zeros(2 if rank == 0 else 1, p, dtype=torch.float64)
+    short = torch.tensor(1 if rank == 1 else 0)       # one chain of rank 1 had 'Not enough samples'
+    try:
+        multi_rhat_from_local_parts(w, means, 100, not_enough_local=short)
+        q.put((rank, "returned"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_multi_rhat_raises_on_every_rank_when_one_chain_is_too_short():
+    """The reference raises 'Not enough samples' from inside its loop over chains (inse_mc_cov.py:45-46 via
+    multi_rhat.py:19); sharded, the chain may live on another rank: every rank must raise, none may return NaN."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rhat_short_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all("Not enough samples (1 of 3 chains)" in got[r] for r in range(world)), got
+
+
+# ------------------------------------------------------------------------------------------- bench.py's own launcher
+def _run_bench(extra, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr.decode()
+
+
+def test_bench_launches_its_own_ranks_on_cpu():
+    """`python bench.py --gpus 2` with no launcher around it starts two rank processes itself (gloo here), takes the
+    MAX of their timed regions and prints exactly ONE JSON line with n_gpus = 2; --gpus 1 stays a single process.
+    (--dry-run: the plumbing without the device; the measuring form of the same command runs in the -m gpu suite.)"""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
+                                {"EEYORE_DIST_BACKEND": "gloo"})
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 20 and lines[0]["warmup"] == 5
+    assert lines[0]["dry_run"] is True and lines[0]["value"] is None  # never mistaken for a measurement
+    assert lines[0]["ms_per_step"] * 20 >= 20.0 - 1e-6  # the slower rank (sleeps 20 ms) sets the time: MAX over ranks
+    rc, lines, err = _run_bench(["--gpus", "1", "--dry-run"])
+    assert rc == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1, err
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies makes the launcher exit non-zero (here: a world size the children refuse)."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--chains-per-gpu", "not-a-number"])
+    assert rc != 0

@@ -135,6 +135,9 @@ def test_g5_mala_mh_traces_accept_bit_exact():
 F32_DECISION_TOL = 2e-3  # a decision is compared when |u - rate| (|log u - log_rate|) exceeds tol*max(1, |.|)
 
 
+F32_TRACE_COUNTS = {"g4_hmc_traces.npz": (188, 1, 3), "g5_mala_mh_traces.npz": None}  # recorded on the box, see the test's last lines
+
+
 @pytest.mark.parametrize("fixture,kind", [("g4_hmc_traces.npz", "hmc"), ("g5_mala_mh_traces.npz", "mala_mh")])
 def test_f32_draws_against_the_reference_traces(fixture, kind):
     """The f32 kernels on the reference's own traces (recorded in f64), one draw at a time from the reference's
@@ -184,7 +187,10 @@ def test_f32_draws_against_the_reference_traces(fixture, kind):
             scale = max(1.0, float(np.abs(rec["sample"][it]).max()))
             np.testing.assert_allclose(th32[0].cpu().numpy(), rec["sample"][it], rtol=5e-4, atol=5e-4 * scale)
             np.testing.assert_allclose(tv32.item(), rec["target_val"][it], rtol=5e-4, atol=5e-3)
-    assert total >= 150 and in_margin <= 0.03 * total and saturated <= 0.05 * total, (total, in_margin, saturated)
+    print(f"f32 draws on {fixture}: (total, in_margin, saturated) = {(total, in_margin, saturated)}")
+    # the committed traces give these counts exactly (in_margin and saturated are properties of the traces and of f32,
+    # not of the kernel: the margin comes from the f64 evaluation, a saturated sigmoid from the reference's naive BCE)
+    assert (total, in_margin, saturated) == F32_TRACE_COUNTS[fixture], (total, in_margin, saturated)
 
 
 def test_g6_pt_swap_decide():
@@ -516,7 +522,8 @@ def test_g9_init_step_matches_reference(monkeypatch):
         real_randn = torch.randn
         monkeypatch.setattr(torch, "randn", lambda *a, **k: _t(rec["momentum"]))
         try:
-            s = HMC(model, theta0=_t(rec["theta0"]), dataloader=_loader_for(rec), tuner=HMCDATuner(1.0), chain=ChainList())
+            s = HMC(model, theta0=_t(rec["theta0"]), dataloader=_loader_for(rec), tuner=HMCDATuner(1.0), chain=ChainList(),
+                    init_step_mode='reference')
         finally:
             monkeypatch.setattr(torch, "randn", real_randn)
         assert s.step == float(rec["step"]) and s.num_steps == int(rec["num_steps"]), (name, s.step)
@@ -524,9 +531,14 @@ def test_g9_init_step_matches_reference(monkeypatch):
     # the halving direction: the reference's integer power sends the step to 0 and tuner.num_steps divides by zero
     rec = dict(groups(load("g4_hmc_traces.npz"))["mlp433"])
     model = _model_for(rec)
-    with pytest.raises(ZeroDivisionError):
+    with pytest.raises(ZeroDivisionError, match="init_step_mode"):
         torch.manual_seed(0)
-        HMC(model, theta0=_t(rec["theta0"]), dataloader=_loader_for(rec), tuner=HMCDATuner(1.0), chain=ChainList())
+        HMC(model, theta0=_t(rec["theta0"]), dataloader=_loader_for(rec), tuner=HMCDATuner(1.0), chain=ChainList(),
+            init_step_mode='reference')
+    # the default is the heuristic as intended: a usable sampler
+    torch.manual_seed(0)
+    s = HMC(model, theta0=_t(rec["theta0"]), dataloader=_loader_for(rec), tuner=HMCDATuner(1.0), chain=ChainList())
+    assert 0 < s.step < 1 and s.num_steps == max(1, round(1.0 / s.step))
     # ... while the heuristic it set out to write brackets the ratio 1/2, per chain as well
     s = HMC(model, theta0=_t(rec["theta0"]), dataloader=_loader_for(rec), step=0.1, num_steps=3, chain=ChainList())
     torch.manual_seed(0)
@@ -672,6 +684,83 @@ def test_run_with_attached_moments_and_in_kernel_tuner_off_the_mfma32_kernel():
         assert ch.get_samples().shape == (16, C, P) and torch.isfinite(ch.get_target_vals()).all()
         summ = st.summary()
         assert torch.isfinite(summ["mean"]).all() and 0 < summ["acceptance"] <= 1
+
+
+def test_a_run_that_fails_inside_burn_in_leaves_no_dual_averaging_attached():
+    """HMC.run attaches the per-chain dual averaging to the plan cached on the model (raw device pointers into the
+    tuner's tensors).  A run that raises inside a burn-in block must detach it, and a later run on the same model with
+    another tuner, or none, must neither adapt nor touch the first tuner's memory."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    from eeyore_amd.tuners import PerChainDATuner
+    data = synthetic.iris_shaped(dtype=torch.float32, device=DEV)
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'],
+                    hparams=mlp.Hyperparameters(dims=[4, 32, 32, 3], activations=[torch.sigmoid, torch.sigmoid, None]),
+                    dtype=torch.float32, device=DEV)
+    P, C = model.num_params(), 64
+    model.prior = Normal(torch.zeros(P, device=DEV), torch.full((P,), 3.0 ** 0.5, device=DEV))
+    th0 = 0.1 * torch.randn(C, P, device=DEV)
+    s = HMC(model, theta0=th0.clone(), dataloader=loader, step=0.01, num_steps=5, seed=3)
+    s.tuner = PerChainDATuner(torch.full((C,), 0.01, dtype=torch.float64, device=DEV), num_steps=5)
+    s.fused_block = 4
+    calls = {"n": 0}
+    real = s._draw_block
+
+    def failing(x, y, k, savestate):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise RuntimeError("injected failure inside burn-in")
+        return real(x, y, k, savestate)
+
+    s._draw_block = failing
+    with pytest.raises(RuntimeError, match="injected"):
+        s.run(num_epochs=24, num_burnin_epochs=16)
+    plan = model._plan(*next(iter(loader)))
+    assert s.tuner._attached is None and plan._da_refs is None
+    state_after, step_after = s.tuner.barh.clone(), s.tuner.step.clone()
+    # the same model and plan, no tuner: fixed step, and the first tuner's tensors stay as the failed run left them
+    s2 = HMC(model, theta0=th0.clone(), dataloader=loader, step=0.01, num_steps=5, seed=4)
+    s2.run(num_epochs=12, num_burnin_epochs=4)
+    torch.cuda.synchronize()
+    assert torch.equal(s.tuner.step, step_after) and torch.equal(s.tuner.barh, state_after)
+    assert s2.get_chain().get_samples().shape == (8, C, P)
+    # and with a tuner of another chain count (a stale attachment would fail da_check with a size mismatch)
+    s3 = HMC(model, theta0=th0[:32].clone(), dataloader=loader, step=0.01, num_steps=5, seed=5)
+    s3.tuner = PerChainDATuner(torch.full((32,), 0.01, dtype=torch.float64, device=DEV), num_steps=5)
+    s3.run(num_epochs=12, num_burnin_epochs=8)
+    assert s3.tuner._attached is None and torch.isfinite(s3.tuner.step).all()
+
+
+def test_set_temperature_from_none_and_from_a_float():
+    """SerialSampler.set_temperature rescales the cached tempered log-target and gradient by t_new / t_old, with no
+    temperature so far counting as one (bayesian_model.py:33-34) and python floats accepted: equal to re-evaluating."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import synthetic
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    data = synthetic.iris_shaped(dtype=torch.float64, device=DEV)
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'],
+                    hparams=mlp.Hyperparameters(dims=[4, 3, 3], activations=[torch.sigmoid, None]), dtype=torch.float64,
+                    device=DEV)
+    P, C = model.num_params(), 8
+    model.prior = Normal(torch.zeros(P, device=DEV, dtype=torch.float64), torch.ones(P, device=DEV, dtype=torch.float64))
+    s = HMC(model, theta0=0.3 * torch.randn(C, P, device=DEV, dtype=torch.float64), dataloader=loader, step=0.01,
+            num_steps=3, seed=1)
+    s.run(num_epochs=2, num_burnin_epochs=0)  # the cached target / gradient exist now, at temperature None
+    plan = model._plan(*next(iter(loader)))
+    for t_new in (torch.linspace(0.2, 0.9, C, device=DEV, dtype=torch.float64), 0.5):
+        s.set_temperature(t_new)
+        t, g = plan.log_target_grad(s._theta, temp=t_new)
+        np.testing.assert_allclose(s._target.cpu().numpy(), t.cpu().numpy(), rtol=1e-12)
+        np.testing.assert_allclose(s._grad.cpu().numpy(), g.cpu().numpy(), rtol=1e-12, atol=1e-13)
 
 
 def test_hmc_fused_run_loop_gives_the_same_chains():
@@ -1014,7 +1103,7 @@ def test_tiny_models_register_resident_evaluation(dims, acts, bias, lik, tag):
             p0 = rng.standard_normal((C, P)).astype(npdt); u = rng.random(C).astype(npdt)
             res = {}
             for variant in (512, 256):
-                L.lib().ey_debug_set_variant(variant)
+                pl.set_variant(variant)  # a switch of THIS plan
                 r = {}
                 r["t"], r["g"] = pl.log_target_grad(_t(th0, dt))
                 r["tt"], r["gt"] = pl.log_target_grad(_t(th0, dt), temp=_t(temps, dt))
@@ -2249,6 +2338,24 @@ def test_chain_buffer_offloads_asynchronously_and_writes_reference_files(tmp_pat
     cl = ChainLists.from_file([tmp_path / 'run01', tmp_path / 'run06'], dtype=torch.float32)
     assert tuple(cl.get_samples().shape) == (2, 4, pl.P)
     assert torch.equal(cl.get_samples()[1], buf.get_samples()[:, 5].cpu())
+    # ... and byte for byte what the reference's ChainFile writes ('%.18e', chain_file.py:21-45): the states of the G9
+    # fixture, held in a device chain buffer as chain 1 of 2, come out as the bytes the reference wrote for them
+    z = subgroups(load("g9_host_side.npz"), "chainfile")
+    z = {**{k: v for k, v in load("g9_host_side.npz").items() if k.startswith("chainfile/")}}
+    z = {k[len("chainfile/"):]: v for k, v in z.items()}
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        smp = torch.tensor(z["sample"], dtype=dt, device=DEV)
+        tvs = torch.tensor(z["target_val"], dtype=dt, device=DEV)
+        acs = torch.tensor(z["accepted"], dtype=torch.uint8, device=DEV)
+        n9 = smp.shape[0]
+        b9 = ChainBuffer()
+        v9 = b9.block(n9, dict(sample=smp[0][None].repeat(2, 1), target_val=tvs[:1].repeat(2), accepted=acs[:1].repeat(2)))
+        v9['sample'][:, 1], v9['target_val'][:, 1], v9['accepted'][:, 1] = smp, tvs, acs
+        v9['sample'][:, 0], v9['target_val'][:, 0], v9['accepted'][:, 0] = 0, 0, 0
+        b9.commit(n9)
+        b9.to_chainfiles(tmp_path / f"g9_{tag}", chains=[1])
+        for k in ("sample", "target_val", "accepted"):
+            assert (tmp_path / f"g9_{tag}" / "run2" / f"{k}.csv").read_bytes() == z[f"{tag}/{k}.csv"].tobytes(), (tag, k)
 
 
 @pytest.mark.gpu

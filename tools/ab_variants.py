@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B the MFMA kernel variants in ONE process, interleaved rounds (cdna_hip_programming.md rule 24).
-usage: python tools/ab_variants.py [variants...]   e.g. 0 1 3 5"""
+usage: python tools/ab_variants.py [variants...]   e.g. 0 1 3 5     (+1024: the exact f32 products instead of bf16x3)"""
 import os
 import sys
 
@@ -45,7 +45,8 @@ torch.cuda.synchronize()
 times = {v: [] for v in variants}
 for rnd in range(8):
     for v in variants:
-        L.lib().ey_debug_set_variant(v)
+        plan.set_variant(v & 1023)
+        plan.f32_products = 'exact' if v & 1024 else 'bf16x3'
         draw()  # warm the variant
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 5 if IPL == 1 else 2
@@ -54,11 +55,11 @@ for rnd in range(8):
         b.record()
         torch.cuda.synchronize()
         times[v].append(a.elapsed_time(b) / (n * IPL))
-L.lib().ey_debug_set_variant(0)
+plan.set_variant(0)
 F = 1092690 * 20 * C
 print(f"chains {C} step {step} acceptance {out['accepted'].float().mean().item():.3f} "
       f"checksum {theta.double().sum().item():.10e} {target.double().sum().item():.10e}")
 for v in variants:
     t = np.array(times[v])
-    print(f"variant {v}: median {np.median(t):.4f} ms  min {t.min():.4f} ms  -> {F / np.median(t) / 1e9:.1f} TFLOP/s "
+    print(f"variant {v} ({'exact' if v & 1024 else 'bf16x3'} products): median {np.median(t):.4f} ms  min {t.min():.4f} ms  -> {F / np.median(t) / 1e9:.1f} TFLOP/s "
           f"({100 * F / np.median(t) / 1e9 / 157.3:.1f}% of f32 MFMA peak)")

@@ -23,7 +23,7 @@ for dt in (torch.float32, torch.float64):
                 th = 0.5 * plan.philox_normal(C, seed=1, it=0)
                 res = []
                 for variant in (512, 256):  # bit 9: the register-resident evaluation whenever the model qualifies, bit 8: never
-                    L.lib().ey_debug_set_variant(variant)
+                    plan.set_variant(variant)
                     for _ in range(3): plan.log_target_grad(th)
                     torch.cuda.synchronize()
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,6 +31,6 @@ for dt in (torch.float32, torch.float64):
                     for _ in range(20): plan.log_target_grad(th)
                     b.record(); torch.cuda.synchronize()
                     res.append(a.elapsed_time(b) / 20 * 1e3)
-                L.lib().ey_debug_set_variant(0)
+                plan.set_variant(0)
                 line += f" | C={C}: tiny {res[0]:8.1f} us  lds-loop {res[1]:8.1f} us  x{res[1] / res[0]:.2f}"
             print(line, flush=True)

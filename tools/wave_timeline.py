@@ -19,7 +19,7 @@ plan = Plan([4, 32, 32, 3], [1, 1, 1], [1, 1, 0], 1, torch.float32, dev)
 plan.set_data(torch.tensor(xs, dtype=torch.float32, device=dev), torch.tensor(ys, dtype=torch.float32, device=dev))
 plan.set_prior(torch.zeros(plan.P), torch.full((plan.P,), float(np.sqrt(3.0))))
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-L.lib().ey_debug_set_variant(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+plan.set_variant(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 theta = 0.1 * plan.philox_normal(C, seed=0, it=0)
 target, grad = plan.log_target_grad(theta)
 for it in range(5):
