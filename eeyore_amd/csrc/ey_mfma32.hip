@@ -1162,7 +1162,9 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
     const int variant = t_ey_variant & 15;
     if (variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);
     if (bf3) {
-      if (a.prior_uniform && !a.da_state) return mf_launch_v<MODE, 8, 0, true, false, true>(a, pl->n_cu, s);
+      if (a.prior_uniform)
+        return a.da_state ? mf_launch_v<MODE, 8, 0, true, true, true>(a, pl->n_cu, s)
+                          : mf_launch_v<MODE, 8, 0, true, false, true>(a, pl->n_cu, s);
       return mf_launch_v<MODE, 8, 0, false, true, true>(a, pl->n_cu, s);
     }
     // the headline shape (few row tiles, one Normal(m, s) prior for all parameters) has its own, leaner instantiation
