@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed launches before the timed region, on top of --warmup, until the clocks have settled")
     ap.add_argument("--force-generic", action="store_true", help="time the generic VALU kernel instead of the MFMA one")
+    ap.add_argument("--no-compare", action="store_true",
+                    help="do not also time the other form of the kernel's products (profiling runs: one kernel only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / collectives only (no GPU needed, prints value null): the CPU-side test of "
                          "the multi-rank plumbing; never a measurement")
@@ -296,12 +298,23 @@ def main():
         elapsed = t.item()
 
     # dominant kernel, timed per launch with HIP events on the launch stream (torch's current stream)
-    n_ev = 10
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    for a, b in evs:
-        a.record(); steps(it, ipl); b.record(); it += ipl
-    torch.cuda.synchronize()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # one launch of ipl iterations
+    def launch_ms(n_ev=10):
+        nonlocal it
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for a, b in evs:
+            a.record(); steps(it, ipl); b.record(); it += ipl
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # one launch of ipl iterations
+
+    kern_ms = launch_ms()
+    # the same launches with the other form of the kernel's 32x32x32 products (EY_OPT_F32_PRODUCTS), for the record
+    products = plan.f32_products if plan.kernel == "mfma32" else None
+    other = None
+    if products is not None and not args.force_generic and not args.no_compare:
+        plan.f32_products = "exact" if products == "bf16x3" else "bf16x3"
+        steps(it, ipl); it += ipl
+        other = (plan.f32_products, launch_ms())
+        plan.f32_products = products
 
     if rank == 0:
         f_step = flops_per_leapfrog_step(DIMS, N_ROWS)
@@ -319,7 +332,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (bf16x3 products, f32 accumulate)" if products == "bf16x3" and not args.force_generic else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"HMC L={L_STEPS}, {C} chains/GPU ({total_chains} total), MLP(4-32-32-3) sigmoid-sigmoid-"
@@ -327,6 +340,7 @@ def main():
                             f"{'; configs[3] sharding' if world > 1 else ''})",
                 "chains_per_gpu": C, "num_steps": L_STEPS, "step_size": STEP_SIZE, "rng": "in-kernel Philox4x32-10",
                 "kernel": "generic" if args.force_generic else plan.kernel,
+                "f32_products": None if args.force_generic else products,
                 "gradient_evaluations_per_iteration": L_STEPS, "iterations_per_launch": ipl,
                 "stats_summary_ms": round(summary_ms, 3),
                 "value_including_stats_summary": total_chains * L_STEPS * args.steps / (elapsed + 1e-3 * summary_ms),
@@ -340,6 +354,25 @@ def main():
                 "peak_measured": MEASURED_F32_MFMA_TFLOPS, "frac_of_measured": achieved_tflops / MEASURED_F32_MFMA_TFLOPS,
             },
         }
+        if other is not None:
+            o_tflops = f_step * L_STEPS * C * ipl / (other[1] * 1e-3) / 1e12
+            line["config"]["kernels"] = {
+                products: {"kernel_ms": kern_ms, "tflops": achieved_tflops, "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                           "leapfrog_steps_per_sec_x_chains": C * L_STEPS * ipl / (kern_ms * 1e-3)},
+                other[0]: {"kernel_ms": other[1], "tflops": o_tflops, "frac": o_tflops / PEAK_F32_MFMA_TFLOPS,
+                           "leapfrog_steps_per_sec_x_chains": C * L_STEPS * ipl / (other[1] * 1e-3)},
+            }
+        if products == "bf16x3" and not args.force_generic:
+            # The f32-equivalent fraction above prices the ALGORITHMIC f32 flops against the f32 matrix peak.  Beside it, how
+            # much of the kernel's time each matrix pipe is issuing (per SIMD, at the nominal 2.4 GHz): per 32-row tile 36
+            # v_mfma_f32_32x32x16_bf16 (32 cycles each), 2 v_mfma_f32_32x32x2_f32 (64) and 60 v_mfma_f32_4x4x1_16b_f32 (8.4)
+            tiles = (N_ROWS + 31) // 32
+            simd_cycles = 1024 * 2.4e9 * kern_ms * 1e-3
+            per = C * L_STEPS * ipl * tiles
+            line["roofline"]["f32_equivalent"] = True
+            line["roofline"]["bf16_mfma_issue_frac"] = per * 36 * 32 / simd_cycles
+            line["roofline"]["f32_mfma_issue_frac"] = per * (2 * 64 + 60 * 8.4) / simd_cycles
+
         # HBM traffic of the dominant kernel from the committed PMC passes (tools/pmc_passes.sh; separate --pmc runs,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes for gfx950); bench.py cannot profile itself
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")

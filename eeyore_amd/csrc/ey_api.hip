@@ -25,14 +25,15 @@ __global__ void k_labels(const T* __restrict__ y, int* __restrict__ labels, int6
   labels[n] = best;
 }
 
-thread_local int t_ey_variant = 0;
+thread_local int t_ey_variant = 0, t_ey_products = EY_PRODUCTS_BF16X3;
 // what a new plan starts with: EY_VARIANT / EY_F32_PRODUCTS in the environment, or ey_debug_set_variant
 static std::atomic<int> g_ey_default_variant{[] { const char* e = getenv("EY_VARIANT"); return e ? atoi(e) & 1023 : 0; }()};
-static int default_products() {
+int ey_default_variant() { return g_ey_default_variant.load() & 1023; }
+int ey_default_products() {
+  if (g_ey_default_variant.load() & 1024) return EY_PRODUCTS_EXACT;
   const char* e = getenv("EY_F32_PRODUCTS");
   return (e && (!strcmp(e, "exact") || !strcmp(e, "1"))) ? EY_PRODUCTS_EXACT : EY_PRODUCTS_BF16X3;
 }
-int ey_default_variant() { return g_ey_default_variant.load(); }
 
 extern "C" {
 
@@ -94,8 +95,8 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
   hipDeviceProp_t prop;
   EY_HIP(hipGetDeviceProperties(&prop, device_id));
   pl->n_cu = prop.multiProcessorCount;
-  pl->variant = g_ey_default_variant.load();
-  pl->products = default_products();
+  pl->variant = g_ey_default_variant.load() & 1023;
+  pl->products = (g_ey_default_variant.load() & 1024) ? EY_PRODUCTS_EXACT : ey_default_products();
   pl->mfma32_ok = ey_mfma32_supports(pl);
   pl->fused16_ok = ey_fused16_supports(pl);  // also the headline model's second choice (batches beyond mfma32's row limit)
   *out = pl;
@@ -127,7 +128,7 @@ int ey_plan_num_params(const ey_plan* pl, int64_t* P) {
 // Diagnostic switches for A/B runs and tests (not part of the reference-facing surface).  They belong to the plan:
 // ey_plan_set_variant changes one plan, ey_debug_set_variant the value plans created afterwards start with (and what
 // ey_debug_bgemm, which has no plan, runs under).  Both return the previous value.
-extern "C" int ey_debug_set_variant(int v) { return g_ey_default_variant.exchange(v & 1023); }
+extern "C" int ey_debug_set_variant(int v) { return g_ey_default_variant.exchange(v & 2047); }
 extern "C" int ey_plan_set_variant(ey_plan* pl, int v) {
   if (!pl) return -1;
   const int old = pl->variant;
@@ -174,7 +175,7 @@ static bool use_large(const ey_plan* pl, int nvec = 3, uint32_t flags = 0) {
 static bool use_fused16(const ey_plan* pl) { return pl->fused16_ok && !use_mfma32(pl) && !EY_VBIT(4); }
 const char* ey_plan_kernel(const ey_plan* pl) {
   if (!pl) return "generic";
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   if (use_mfma32(pl)) return "mfma32";
   if (use_fused16(pl)) return "fused16";
   return use_large(pl) ? "bgemm" : "generic";
@@ -318,7 +319,7 @@ static int check_ready(const ey_plan* pl, int64_t C, const char* who) {
 int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* log_lik, void* log_prior,
                   void* stream) {
   if (!pl) EY_FAIL(EY_ERR_INVALID, "ey_log_target: null plan");
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   // log_prior alone (bayesian_model.py:46-50) needs no data: with no rows attached the likelihood sum is empty
   if (!log_lik && !pl->has_data && pl->has_prior) {
     if (!theta) EY_FAIL(EY_ERR_INVALID, "ey_log_target: null theta");
@@ -339,7 +340,7 @@ int ey_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, v
 int ey_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* rows, void* stream) {
   int rc = check_ready(pl, C, "ey_log_lik_rows");
   if (rc) return rc < 0 ? rc : EY_OK;
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   if (!theta || !rows) EY_FAIL(EY_ERR_INVALID, "ey_log_lik_rows: null argument");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
@@ -351,7 +352,7 @@ int ey_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t
                        void* stream) {
   int rc = check_ready(pl, C, "ey_log_target_grad");
   if (rc) return rc < 0 ? rc : EY_OK;
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   if (!theta || !target || !grad) EY_FAIL(EY_ERR_INVALID, "ey_log_target_grad: null argument");
   if (C == 0) return EY_OK;
   EY_HIP(hipSetDevice(pl->device));
@@ -367,7 +368,7 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
                 void* stream) {
   int rc = check_ready(pl, C, "ey_hmc_step");
   if (rc) return rc < 0 ? rc : EY_OK;
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: null argument");
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_step: num_steps must be >= 1");
   if (C == 0) return EY_OK;
@@ -403,7 +404,7 @@ int ey_hmc_run(ey_plan* pl, void* theta, void* target, void* grad, double step, 
                void* stream) {
   int rc = check_ready(pl, C, "ey_hmc_run");
   if (rc) return rc < 0 ? rc : EY_OK;
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, "ey_hmc_run: null argument");
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_run: num_steps must be >= 1");
   if (n_iters < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_run: n_iters must be >= 1");
@@ -468,7 +469,7 @@ int ey_hmc_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* 
                     int64_t C, void* target, void* grad, void* stream) {
   int rc = check_ready(pl, C, "ey_hmc_leapfrog");
   if (rc) return rc < 0 ? rc : EY_OK;
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   if (!theta || !p || !target || !grad) EY_FAIL(EY_ERR_INVALID, "ey_hmc_leapfrog: null argument");
   if (L < 1) EY_FAIL(EY_ERR_INVALID, "ey_hmc_leapfrog: num_steps must be >= 1");
   if (C == 0) return EY_OK;
@@ -526,7 +527,7 @@ static int mala_impl(ey_plan* pl, void* theta, void* target, void* grad, const v
                      const EyRun* run, const char* who) {
   int rc = check_ready(pl, C, who);
   if (rc) return rc < 0 ? rc : EY_OK;
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   if (!theta || !target || !grad || !accepted) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": null argument");
   if (!(step > 0.0) && !step_vec) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": step must be positive");
   if (run && run->n_iters < 1) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": n_iters must be >= 1");
@@ -563,7 +564,7 @@ static int mh_impl(ey_plan* pl, void* theta, void* target, const void* z, const 
                    void* accepted, void* log_rate, void* stream, const EyRun* run, const char* who) {
   int rc = check_ready(pl, C, who);
   if (rc) return rc < 0 ? rc : EY_OK;
-  EyVariantScope vs(pl->variant);
+  EyVariantScope vs(pl);
   if (!theta || !target || !scale || !accepted) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": null argument");
   if (run && run->n_iters < 1) EY_FAIL(EY_ERR_INVALID, std::string(who) + ": n_iters must be >= 1");
   if (C == 0) return EY_OK;

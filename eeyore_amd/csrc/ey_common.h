@@ -87,14 +87,21 @@ struct ey_plan {
 
 // The diagnostic switches of the plan a C-ABI call is serving, for the dispatch code below the entry points (thread-local:
 // plans on different threads are independent; an entry point sets it for its own duration).
-extern thread_local int t_ey_variant;
+extern thread_local int t_ey_variant, t_ey_products;
 struct EyVariantScope {
-  int old;
-  explicit EyVariantScope(int v) : old(t_ey_variant) { t_ey_variant = v; }
-  ~EyVariantScope() { t_ey_variant = old; }
+  int old, oldp;
+  explicit EyVariantScope(int v, int products = -1) : old(t_ey_variant), oldp(t_ey_products) {
+    t_ey_variant = v;
+    if (products >= 0) t_ey_products = products;
+  }
+  explicit EyVariantScope(const struct ey_plan* pl);
+  ~EyVariantScope() { t_ey_variant = old; t_ey_products = oldp; }
 };
 #define EY_VBIT(b) ((t_ey_variant >> (b)) & 1)
-int ey_default_variant();  // what plans created now start with (ey_debug_set_variant, EY_VARIANT)
+int ey_default_variant();   // what plans created now start with (ey_debug_set_variant, EY_VARIANT)
+int ey_default_products();  // ... and their EY_OPT_F32_PRODUCTS (EY_F32_PRODUCTS; bit 10 of ey_debug_set_variant: exact)
+
+inline EyVariantScope::EyVariantScope(const ey_plan* pl) : EyVariantScope(pl->variant, pl->products) {}
 
 // what a launch needs of the attached dual averaging: the rows of the table for its iterations
 struct EyDA {

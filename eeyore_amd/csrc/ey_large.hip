@@ -641,6 +641,147 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_dma(BG g) {
   bg_epilogue<2, 2, 2, 2>(g, acc, m0, n0, wm, wn, c, h, b, rsum, do_rowsum, tid);
 }
 
+// ---- the 128 x 128 product in the bf16x3 form (EY_OPT_F32_PRODUCTS = EY_PRODUCTS_BF16X3, the default): every f32
+// operand element is split EXACTLY into three bf16 pieces while it is staged (x = hi + mid + lo, round-to-nearest pieces
+// of 8 significant bits) and a b is summed from the six piece products of relative size >= 2^-18 on
+// v_mfma_f32_32x32x16_bf16, f32 accumulation, smallest terms first -- as the fused trajectory kernel does
+// (ey_mfma32.hip, where the error against f64 is measured: no larger than the f32 fma chain's).  Per 16-deep k-chunk and
+// wave that is 24 MFMAs of 32 cycles where the f32 form issues 32 of 64; the split costs each thread 16 elements per
+// chunk (both operands), amortised over the 128-wide tile.
+// Staging is through registers, either operand in either direction (AK / BK_: k contiguous, else rows contiguous): a
+// thread takes one (row, 8 consecutive k) task per operand and chunk -- two 16-byte loads when k is contiguous, eight
+// dword loads (lanes <-> consecutive rows) when the rows are -- and writes its three 16-byte granules into the image
+// [piece][row][2 granules], granule position g ^ ((row >> 3) & 1): lane (c, h) of an MFMA reads granule h of its row with
+// one conflict-free ds_read_b128 per piece.  Two LDS stages of 24 KB, one barrier per chunk.
+#define BK3 16
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned l_pk_bf16(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void l_split8(const float (&v)[8], u32x4_t& hi, u32x4_t& mid, u32x4_t& lo) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float a = v[2 * d], b = v[2 * d + 1];
+    const unsigned hh = l_pk_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, hh << 16), rb = b - __builtin_bit_cast(float, hh & 0xffff0000u);
+    const unsigned mm = l_pk_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, mm << 16), sb = rb - __builtin_bit_cast(float, mm & 0xffff0000u);
+    hi[d] = hh;
+    mid[d] = mm;
+    lo[d] = l_pk_bf16(sa, sb);
+  }
+}
+__device__ __forceinline__ f32x16 l_mfma_bf16(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// this thread's eight elements of k-chunk kt: row `row` (global), k = 16 kt + 8 tg + j; zero outside the matrix
+template <bool KF>
+__device__ __forceinline__ void bf3_fetch(const float* P, long sRow, long sK, int row, int rows, int K, int kt, int tg,
+                                          float (&v)[8]) {
+  const int k0 = kt * BK3 + 8 * tg;
+  const bool rok = row < rows;
+  const float* src = P + (long)(rok ? row : 0) * sRow + (long)k0 * sK;
+  if (KF) {
+    if (rok && k0 + 8 <= K) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (rok && k0 + j < K) ? src[j] : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (rok && k0 + j < K) ? src[(long)j * sK] : 0.0f;
+  }
+}
+template <bool AK, bool BK_>
+__global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
+  __shared__ __attribute__((aligned(16))) u32x4_t As[2][3 * 128 * 2];
+  __shared__ __attribute__((aligned(16))) u32x4_t Bs[2][3 * 128 * 2];
+  __shared__ float rs_red[2][128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const BlockId bid = xcd_block();
+  const int m0 = bid.y * 128, n0 = bid.x * 128;
+  const long b = bid.z;
+  const float* A = g.A + b * g.bA;
+  const float* B = g.B + b * g.bB;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int ktiles = (g.K + BK3 - 1) / BK3;
+  const bool want_rowsum = g.rowsum != nullptr && bid.x == 0;
+  float rsum = 0.0f;
+  // staging tasks: k contiguous -> consecutive lanes take the two granules of a row; rows contiguous -> consecutive lanes
+  // take consecutive rows
+  const int ar = AK ? (tid >> 1) : (tid & 127), ag = AK ? (tid & 1) : (tid >> 7);
+  const int br = BK_ ? (tid >> 1) : (tid & 127), bg = BK_ ? (tid & 1) : (tid >> 7);
+  const int a_slot = ar * 2 + (ag ^ ((ar >> 3) & 1)), b_slot = br * 2 + (bg ^ ((br >> 3) & 1));
+  // fragment slots of this lane: rows wm * 64 + 32 i + c (A) and wn * 64 + 32 j + c (B); 32 rows further = 64 slots
+  const int ra = wm * 64 + c, rb = wn * 64 + c;
+  const int fa = ra * 2 + (h ^ ((ra >> 3) & 1)), fb = rb * 2 + (h ^ ((rb >> 3) & 1));
+  float va[8], vb[8];
+  auto stage = [&](int st) {
+    u32x4_t hi, mid, lo;
+    l_split8(va, hi, mid, lo);
+    As[st][0 * 256 + a_slot] = hi; As[st][1 * 256 + a_slot] = mid; As[st][2 * 256 + a_slot] = lo;
+    l_split8(vb, hi, mid, lo);
+    Bs[st][0 * 256 + b_slot] = hi; Bs[st][1 * 256 + b_slot] = mid; Bs[st][2 * 256 + b_slot] = lo;
+  };
+  bf3_fetch<AK>(A, g.sAm, g.sAk, m0 + ar, g.M, g.K, 0, ag, va);
+  bf3_fetch<BK_>(B, g.sBn, g.sBk, n0 + br, g.N, g.K, 0, bg, vb);
+  if (want_rowsum) rsum += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
+  stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < ktiles;
+    if (more) {
+      bf3_fetch<AK>(A, g.sAm, g.sAk, m0 + ar, g.M, g.K, kt + 1, ag, va);
+      bf3_fetch<BK_>(B, g.sBn, g.sBk, n0 + br, g.N, g.K, kt + 1, bg, vb);
+    }
+    u32x4_t pa[2][3], pb[2][3];  // [tile][piece: hi, mid, lo]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        pa[i][p] = As[cur][p * 256 + fa + 64 * i];
+        pb[i][p] = Bs[cur][p * 256 + fb + 64 * i];
+      }
+    // (hi, lo), (lo, hi), (mid, mid), (hi, mid), (mid, hi), (hi, hi): smallest terms first
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = l_mfma_bf16(pa[i][TA[t]], pb[j][TB[t]], acc[i][j]);
+    if (more) {
+      if (want_rowsum) rsum += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
+      stage(cur ^ 1);
+    }
+    __syncthreads();
+  }
+  bool do_rowsum = false;
+  if (want_rowsum) {  // the two granule columns of a row, in a fixed order
+    rs_red[ag][ar] = rsum;
+    __syncthreads();
+    do_rowsum = tid < 128;
+    if (do_rowsum) rsum = rs_red[0][tid] + rs_red[1][tid];
+  }
+  bg_epilogue<2, 2, 2, 2>(g, acc, m0, n0, wm, wn, c, h, b, rsum, do_rowsum, tid);
+}
+
 static bool dma_ok(const BG& g, bool& kfast) {
   if (g.K % BK != 0 || g.M <= 32 || g.N <= 32) return false;
   const bool a_k = g.sAk == 1, b_k = g.sBk == 1, a_m = g.sAm == 1, b_n = g.sBn == 1;
@@ -922,7 +1063,13 @@ static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry) {
   } else {
     dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
     bool kfast = false;
-    if (g_bgemm_dma && dma_ok(g, kfast)) {
+    const bool a_k = g.sAk == 1, b_k = g.sBk == 1;
+    if (t_ey_products == EY_PRODUCTS_BF16X3 && (a_k || g.sAm == 1) && (b_k || g.sBn == 1)) {
+      if (a_k && b_k) hipLaunchKernelGGL((k_bgemm_bf3<true, true>), grid, dim3(256), 0, s, g);
+      else if (a_k) hipLaunchKernelGGL((k_bgemm_bf3<true, false>), grid, dim3(256), 0, s, g);
+      else if (b_k) hipLaunchKernelGGL((k_bgemm_bf3<false, true>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((k_bgemm_bf3<false, false>), grid, dim3(256), 0, s, g);
+    } else if (g_bgemm_dma && dma_ok(g, kfast)) {
       if (kfast) hipLaunchKernelGGL(k_bgemm_dma<true>, grid, dim3(256), 0, s, g);
       else hipLaunchKernelGGL(k_bgemm_dma<false>, grid, dim3(256), 0, s, g);
     } else {
@@ -2095,7 +2242,7 @@ int ey_large_log_lik_rows(ey_plan* pl, const void* theta, const void* temp, int6
 extern "C" int ey_debug_bgemm(const float* A, const float* B, float* C, int M, int N, int K, long sAm, long sAk, long sBk,
                               long sBn, long sCm, long sCn, long bA, long bB, long bC, const float* bias, long bBias,
                               int act, int batch, void* stream) {
-  EyVariantScope vs(ey_default_variant());
+  EyVariantScope vs(ey_default_variant(), ey_default_products());
   BG g = {};
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
   g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.sCm = sCm; g.sCn = sCn;

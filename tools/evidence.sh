@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r2}
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-compare > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/bench_kernel_stats.csv
 echo "trace done"
 python3 bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err

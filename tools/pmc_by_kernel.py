@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc CSV output summarised per kernel name: dispatches and the SUM of every counter over them, plus the
-matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs) where both were collected.
+"""rocprofv3 --pmc CSV output summarised per kernel name.
+
+Every counter is reported PER DISPATCH: its sum over all rows divided by the number of dispatches IT was collected on (a
+counter that two passes both collected -- GRBM_GUI_ACTIVE usually -- has twice the dispatches of one that a single pass
+collected; dividing both by one common count was the bug of round 2's summary, which read the matrix pipe half as busy
+as the counters said).  Derived: the matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over
+GRBM_GUI_ACTIVE / 8 XCDs, both per dispatch) and, where FETCH_SIZE / WRITE_SIZE were collected, the fabric bytes per
+dispatch 2 x FETCH_SIZE + WRITE_SIZE (KiB; the factor two is the gfx950 correction of MI355X_MICROARCH.md's HBM section).
 usage: pmc_by_kernel.py <dir>"""
 import csv
 import glob
@@ -10,19 +16,36 @@ from collections import defaultdict
 
 root = sys.argv[1]
 tot = defaultdict(lambda: defaultdict(float))
-cnt = defaultdict(lambda: defaultdict(int))
+disp = defaultdict(lambda: defaultdict(set))
 for f in glob.glob(f"{root}/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         name = re.sub(r"\(.*", "", row["Kernel_Name"])
         name = re.sub(r"^void ", "", name)
         tot[name][row["Counter_Name"]] += float(row["Counter_Value"])
-        cnt[name][row["Counter_Name"]] += 1
-for name in sorted(tot, key=lambda k: -tot[k].get("SQ_BUSY_CYCLES", tot[k].get("GRBM_GUI_ACTIVE", 0.0))):
+        disp[name][row["Counter_Name"]].add((f, row.get("Dispatch_Id", row.get("Correlation_Id", ""))))
+
+
+def per_dispatch(name, counter):
+    n = len(disp[name][counter])
+    return tot[name][counter] / n if n else float("nan")
+
+
+def busy_key(name):
+    for k in ("SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+        if k in tot[name]:
+            return -tot[name][k]
+    return 0.0
+
+
+for name in sorted(tot, key=busy_key):
     c = tot[name]
-    n = max(cnt[name].values())
-    line = f"{name[:70]:70s} dispatches {n:5d}"
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
-        line += f"  mfma_busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (c['GRBM_GUI_ACTIVE'] / 8):.3f}"
+    n = max(len(v) for v in disp[name].values())
+    line = f"{name[:70]:70s} dispatches (most-collected counter) {n:5d}"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+        line += f"  mfma_busy {per_dispatch(name, 'SQ_VALU_MFMA_BUSY_CYCLES') / 1024 / (per_dispatch(name, 'GRBM_GUI_ACTIVE') / 8):.3f}"
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        kib = 2.0 * per_dispatch(name, "FETCH_SIZE") + per_dispatch(name, "WRITE_SIZE")
+        line += f"  fabric bytes per dispatch {kib * 1024 / 1e6:.2f} MB"
     print(line)
     for k in sorted(c):
-        print(f"    {k:28s} {c[k]:20.1f}")
+        print(f"    {k:28s} per dispatch {per_dispatch(name, k):20.1f}   (over {len(disp[name][k])} dispatches)")

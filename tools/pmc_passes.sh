@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_${1:-r1}
 # every dispatch of the dominant kernel is one launch of 25 HMC iterations, the bench default (warm-up 25 = one launch,
 # 50 steps = two, the event-timed section ten more)
-CMD="python3 bench.py --steps 50 --warmup 25 --iters-per-launch 25 --no-cpu-baseline"
+CMD="python3 bench.py --steps 50 --warmup 25 --iters-per-launch 25 --no-cpu-baseline --no-compare"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/a -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $OUT/b -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c -- $CMD > /dev/null 2>&1

@@ -10,12 +10,14 @@ from collections import defaultdict
 root = sys.argv[1]
 kern = sys.argv[2] if len(sys.argv) > 2 else "k_mfma32<0"
 acc = defaultdict(list)
+names = set()
 for f in glob.glob(f"{root}/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         if kern in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            names.add(row["Kernel_Name"].split("(")[0].replace("void ", ""))
 n = max((len(v) for v in acc.values()), default=0)
-print(f"kernel {kern}: mean per dispatch over {n} dispatches")
+print(f"kernel {kern} ({', '.join(sorted(names))}): mean per dispatch over {n} dispatches")
 mean = {k: sum(v) / len(v) for k, v in acc.items()}
 for k in sorted(mean):
     print(f"{k:28s} {mean[k]:18.1f}")
@@ -30,7 +32,7 @@ if len(sys.argv) > 3 and "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     h = hashlib.sha256()
     for name in ("ey_mfma32.hip", "ey_common.h"):  # as bench.py's kernel_source_hash()
         h.update(open(os.path.join(root, "eeyore_amd", "csrc", name), "rb").read())
-    json.dump({"kernel": "k_mfma32<0,8,12,true> (HMC trajectory)", "kernel_source_sha256": h.hexdigest(),
+    json.dump({"kernel": (sorted(names)[0] if names else kern) + " (HMC trajectory)", "kernel_source_sha256": h.hexdigest(),
                "FETCH_SIZE_KB": mean["FETCH_SIZE"],
                "WRITE_SIZE_KB": mean["WRITE_SIZE"], "dispatches": n, "iterations_per_launch": ipl,
                "source": f"tools/pmc_passes.sh (rocprofv3 --pmc, separate passes), 4096 chains x L=20 x {ipl} "
