@@ -286,9 +286,10 @@ static int moments_trailing(ey_plan* pl, int rc, const void* theta, const void* 
 // used up); `advance` moves the plan's position in the table past it.
 static EyDA da_window(ey_plan* pl, int n_iters) {
   EyDA w;
-  if (!pl->da_state || pl->da_done >= pl->da_n) return w;
+  if (!pl->da_state) return w;
+  w.step = pl->da_step;  // the attached step vector stays the step of every launch until it is detached
+  if (pl->da_done >= pl->da_n) return w;  // the table is used up: nothing adapts any more
   w.state = pl->da_state;
-  w.step = pl->da_step;
   w.table = pl->da_table + 3 * pl->da_done;
   w.n = (int)std::min<int64_t>(n_iters, pl->da_n - pl->da_done);
   w.final_it = (pl->da_final_avg && pl->da_done + n_iters >= pl->da_n) ? (int)(pl->da_n - 1 - pl->da_done) : -1;
@@ -377,13 +378,18 @@ int ey_hmc_step(ey_plan* pl, void* theta, void* target, void* grad, const void* 
   if ((rc = da_check(pl, C, fused, "ey_hmc_step"))) return rc;
   EY_HIP(hipSetDevice(pl->device));
   const EyDA da = da_window(pl, 1);
-  if (fused && da.state) pl->da_done += 1;
-  if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC))  // accumulates attached moments itself
-    return ey_mfma32_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
-                         accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream, nullptr, &da);
-  if (use_fused16(pl) && !(flags & EY_FORCE_GENERIC))
+  if (da.step) step_vec = da.step;  // every kernel family: the attached step vector is the step
+  if (use_mfma32(pl) && !(flags & EY_FORCE_GENERIC)) {  // accumulates attached moments itself
+    rc = ey_mfma32_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
+                       accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream, nullptr, &da);
+    if (rc == EY_OK && da.state) pl->da_done += 1;  // the table advances only past iterations that were launched
+    return rc;
+  }
+  if (use_fused16(pl) && !(flags & EY_FORCE_GENERIC)) {
     rc = ey_fused16_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                         accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream, nullptr, &da);
+    if (rc == EY_OK && da.state) pl->da_done += 1;
+  }
   else if (use_large(pl, 3, flags))
     rc = ey_large_hmc(pl, theta, target, grad, p0, u, step, step_vec, L, temp, C, seed, iter, chain_offset, flags,
                       accepted, accept_rate, H_cur, H_prop, (hipStream_t)stream);
@@ -417,20 +423,24 @@ int ey_hmc_run(ey_plan* pl, void* theta, void* target, void* grad, double step, 
   hipStream_t s = (hipStream_t)stream;
   EyRun run = {n_iters, samples, targets, accepted_rec, (int*)accept_count};
   const EyDA da = da_window(pl, n_iters);
-  if ((f16 || m32) && da.state) pl->da_done += da.n;
-  if (m32)
-    return ey_mfma32_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
-                         flags, accepted, nullptr, nullptr, nullptr, s, &run, &da);
+  if (da.step) step_vec = da.step;
+  if (m32) {
+    rc = ey_mfma32_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
+                       flags, accepted, nullptr, nullptr, nullptr, s, &run, &da);
+    if (rc == EY_OK && da.state) pl->da_done += da.n;
+    return rc;
+  }
   if (f16 || !use_large(pl, 3, flags)) {
     // the generic kernels do not fuse the moments: they are replayed from the recorded samples, which must then exist
     // (checked BEFORE the launch: a failure must leave the chains where they were)
     if (pl->mom_s1 && n_iters > 1 && (!samples || !accepted_rec))
       EY_FAIL(EY_ERR_UNSUPPORTED, "ey_hmc_run: attached moments with n_iters > 1 need the samples and accepted records "
                                   "on this kernel family");
-    if (f16)
+    if (f16) {
       rc = ey_fused16_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter, chain_offset,
                           flags, accepted, nullptr, nullptr, nullptr, s, &run, &da);
-    else
+      if (rc == EY_OK && da.state) pl->da_done += da.n;
+    } else
       rc = ey_generic_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter,
                           chain_offset, flags, accepted, nullptr, nullptr, nullptr, s, &run);
     if (rc != EY_OK || !pl->mom_s1) return rc;

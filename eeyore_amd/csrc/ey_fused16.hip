@@ -1028,8 +1028,9 @@ static int f16_hmc_t(ey_plan* pl, void* theta, void* target, void* grad, const v
   if (da && da->state) {
     a.da_state = da->state; a.da_tab = da->table; a.da_step = (T*)da->step; a.da_n = da->n;
     a.da_final_it = da->final_it; a.da_has_eub = da->has_eub; a.da_d = da->d; a.da_logeub = da->logeub;
-    step_vec = da->step;
   }
+  // while a dual averaging is attached its step vector is THE step, also once its table is used up (include/eeyore_amd.h)
+  if (da && da->step) step_vec = da->step;
   a.C = C; a.theta = (T*)theta; a.target = (T*)target; a.grad = (T*)grad; a.p0 = (const T*)p0; a.u = (const T*)u;
   a.step = (T)step; a.step_vec = (const T*)step_vec; a.L = L; a.temp = (const T*)temp; a.seed = seed; a.iter = iter;
   a.chain_offset = chain_offset; a.recompute = (flags & EY_RECOMPUTE_INITIAL_GRAD) ? 1 : 0;

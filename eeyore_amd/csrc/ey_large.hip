@@ -678,24 +678,33 @@ __device__ __forceinline__ void l_split8(const float (&v)[8], u32x4_t& hi, u32x4
 __device__ __forceinline__ f32x16 l_mfma_bf16(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
-// this thread's eight elements of k-chunk kt: row `row` (global), k = 16 kt + 8 tg + j; zero outside the matrix
+// this thread's eight elements of k-chunk kt: k = 16 kt + 8 tg + j of the row `rowp` points at.  No branch depends on the
+// lane: a chunk that lies inside K (wave-uniform test) is loaded straight -- two 16-byte loads when k is contiguous, eight
+// dword loads otherwise --, only the last chunk of a K that is not a multiple of 16 clamps its addresses and zeroes what
+// lies beyond K.  (With per-lane bounds branches the compiler waited for every load where the branches merge, which
+// serialised the fetch of chunk kt + 1 with the products of chunk kt.)  Rows beyond the matrix are clamped by the
+// caller: their products land in outputs the epilogue drops.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 template <bool KF>
-__device__ __forceinline__ void bf3_fetch(const float* P, long sRow, long sK, int row, int rows, int K, int kt, int tg,
-                                          float (&v)[8]) {
+__device__ __forceinline__ void bf3_fetch(const float* rowp, long sK, int K, int kt, int tg, float (&v)[8]) {
   const int k0 = kt * BK3 + 8 * tg;
-  const bool rok = row < rows;
-  const float* src = P + (long)(rok ? row : 0) * sRow + (long)k0 * sK;
-  if (KF) {
-    if (rok && k0 + 8 <= K) {
+  if ((kt + 1) * BK3 <= K) {
+    const float* src = rowp + (long)k0 * sK;
+    if (KF) {
+      const f32x4_u lo = *reinterpret_cast<const f32x4_u*>(src), hi = *reinterpret_cast<const f32x4_u*>(src + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = src[j];
+      for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (rok && k0 + j < K) ? src[j] : 0.0f;
+      for (int j = 0; j < 8; ++j) v[j] = src[(long)j * sK];
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (rok && k0 + j < K) ? src[(long)j * sK] : 0.0f;
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      const float x = rowp[(long)(k < K ? k : K - 1) * sK];
+      v[j] = k < K ? x : 0.0f;
+    }
   }
 }
 template <bool AK, bool BK_>
@@ -730,6 +739,8 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
   // fragment slots of this lane: rows wm * 64 + 32 i + c (A) and wn * 64 + 32 j + c (B); 32 rows further = 64 slots
   const int ra = wm * 64 + c, rb = wn * 64 + c;
   const int fa = ra * 2 + (h ^ ((ra >> 3) & 1)), fb = rb * 2 + (h ^ ((rb >> 3) & 1));
+  const float* arow = A + (long)min(m0 + ar, g.M - 1) * g.sAm;
+  const float* brow = B + (long)min(n0 + br, g.N - 1) * g.sBn;
   float va[8], vb[8];
   auto stage = [&](int st) {
     u32x4_t hi, mid, lo;
@@ -738,8 +749,8 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
     l_split8(vb, hi, mid, lo);
     Bs[st][0 * 256 + b_slot] = hi; Bs[st][1 * 256 + b_slot] = mid; Bs[st][2 * 256 + b_slot] = lo;
   };
-  bf3_fetch<AK>(A, g.sAm, g.sAk, m0 + ar, g.M, g.K, 0, ag, va);
-  bf3_fetch<BK_>(B, g.sBn, g.sBk, n0 + br, g.N, g.K, 0, bg, vb);
+  bf3_fetch<AK>(arow, g.sAk, g.K, 0, ag, va);
+  bf3_fetch<BK_>(brow, g.sBk, g.K, 0, bg, vb);
   if (want_rowsum) rsum += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
   stage(0);
   __syncthreads();
@@ -747,8 +758,8 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
     const int cur = kt & 1;
     const bool more = kt + 1 < ktiles;
     if (more) {
-      bf3_fetch<AK>(A, g.sAm, g.sAk, m0 + ar, g.M, g.K, kt + 1, ag, va);
-      bf3_fetch<BK_>(B, g.sBn, g.sBk, n0 + br, g.N, g.K, kt + 1, bg, vb);
+      bf3_fetch<AK>(arow, g.sAk, g.K, kt + 1, ag, va);
+      bf3_fetch<BK_>(brow, g.sBk, g.K, kt + 1, bg, vb);
     }
     u32x4_t pa[2][3], pb[2][3];  // [tile][piece: hi, mid, lo]
 #pragma unroll

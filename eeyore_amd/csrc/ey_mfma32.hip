@@ -1195,8 +1195,9 @@ int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void
   if (da && da->state) {
     a.da_state = da->state; a.da_tab = da->table; a.da_step = (float*)da->step; a.da_n = da->n;
     a.da_final_it = da->final_it; a.da_has_eub = da->has_eub; a.da_d = da->d; a.da_logeub = da->logeub;
-    step_vec = da->step;  // the kernel reads each iteration's step where the previous one's update left it
   }
+  // while a dual averaging is attached its step vector is THE step, also once its table is used up (include/eeyore_amd.h)
+  if (da && da->step) step_vec = da->step;  // the kernel reads each iteration's step where the previous one's update left it
   a.C = C; a.theta = (float*)theta; a.target = (float*)target; a.grad = (float*)grad;
   a.p0 = (const float*)p0; a.u = (const float*)u; a.step = (float)step; a.step_vec = (const float*)step_vec;
   a.L = L; a.temp = (const float*)temp; a.seed = seed; a.iter = iter; a.chain_offset = chain_offset;

@@ -220,7 +220,10 @@ int ey_plan_attach_moments(ey_plan* plan, void* s1, void* s2, void* acc, int64_t
  * so that host and device agree to the last bit; the plan counts the iterations it has adapted and stops after n.
  * d: target acceptance; log_eub: log of the upper bound on the step or NaN; final_avg != 0: the n-th iteration leaves
  * the AVERAGED step exp(logbare) (hmcda_tuner.py's return_e=False).  The number of leapfrog steps stays what the calls
- * pass.  state = NULL detaches.  Served by the fused kernel families (mfma32, fused16); EY_ERR_UNSUPPORTED otherwise. */
+ * pass.  For as long as a state is attached, step_vec is the step of every HMC launch on the plan -- also after the n
+ * adapting iterations are used up (the launches then read it and adapt nothing) -- and the step / step_vec arguments of
+ * the calls are ignored; the plan's position in the table advances only past iterations whose launch succeeded.
+ * state = NULL detaches.  Served by the fused kernel families (mfma32, fused16); EY_ERR_UNSUPPORTED otherwise. */
 int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* table, int64_t n, int64_t C, double d,
                       double log_eub, int final_avg);
 

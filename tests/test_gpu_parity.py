@@ -1606,7 +1606,7 @@ def test_bgemm_hmc_fused_leapfrog_equals_separate_kernel(dims, acts, bias, N):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("forced", [True, False])
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EY_FUZZ_SEEDS", "16"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EY_FUZZ_SEEDS", "64"))))
 def test_random_architectures_vs_oracle(seed, forced):
     """Seeded random MLPs (1-4 layers, widths 1-140, odd row counts, with and without bias, every activation, both
     likelihoods, both dtypes), once forced onto the layerwise path -- whatever mix of kernels its dispatcher picks for the
@@ -2361,7 +2361,8 @@ def test_chain_buffer_offloads_asynchronously_and_writes_reference_files(tmp_pat
 @pytest.mark.parametrize("M,N,K,kfast", [(256, 128, 64, True), (200, 130, 48, True), (128, 784, 96, False),
                                          (128, 272, 32, False), (64, 20, 40, True), (10, 128, 64, False)])
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
-def test_batched_gemm_vs_torch_bmm(M, N, K, kfast, act):
+@pytest.mark.parametrize("products", ["bf16x3", "exact"])
+def test_batched_gemm_vs_torch_bmm(M, N, K, kfast, act, products):
     """The batched f32 product of the config-5 path (ey_large.hip: DMA-staged 128 x 128 kernel, the narrow kernels and the
     N-remainder split) against torch.bmm in f64 plus the activation, both operand orders, ragged M / N."""
     import ctypes as ct
@@ -2386,8 +2387,12 @@ def test_batched_gemm_vs_torch_bmm(M, N, K, kfast, act):
     ref = [ref, torch.sigmoid(ref), torch.tanh(ref), torch.relu(ref)][act]
     C = torch.full((batch, M, N), float("nan"), device=dev)
     st = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
-    L.check(L.lib().ey_debug_bgemm(L.ptr(a), L.ptr(b), L.ptr(C), M, N, K, sA[0], sA[1], sB[0], sB[1], N, 1, bA, bB, M * N,
-                                   L.ptr(bias), N, act, batch, st), "ey_debug_bgemm")
+    old = L.lib().ey_debug_set_variant(1024 if products == "exact" else 0)  # bit 10: the f32 form of the 128-wide product
+    try:
+        L.check(L.lib().ey_debug_bgemm(L.ptr(a), L.ptr(b), L.ptr(C), M, N, K, sA[0], sA[1], sB[0], sB[1], N, 1, bA, bB,
+                                       M * N, L.ptr(bias), N, act, batch, st), "ey_debug_bgemm")
+    finally:
+        L.lib().ey_debug_set_variant(old)
     # f32 accumulation over K <= 96 terms of O(1) products (sigmoid / tanh / relu do not expand that error); the
     # hardware exp2 / reciprocal add ~1e-7 relative
     tol = 2e-5 * (K ** 0.5)
