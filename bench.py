@@ -80,11 +80,26 @@ def cpu_reference_faithful(x, y, sigma, budget_s=8.0):
 
 
 def usable_cpus():
-    """Hardware threads this process may run on (the scheduler's affinity mask, not the host's total)."""
+    """Hardware threads this process may run on: the scheduler's affinity mask, cut down by a cgroup CPU quota where one
+    is set (a container may see every thread of the host and still be throttled to a share of them)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), None))):
+        try:
+            with open(path) as f:
+                quota, period = parse(f.read())
+            if period is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = f.read().strip()
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
 
 
 def cpu_baseline(x, y, sigma, cores, budget_s=9.0):
@@ -388,10 +403,16 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 figure (the other ranks would wait for it)
             # BASELINE.md section 3 item 3, "generous CPU": one chain per hardware thread on ALL threads this process may
             # use; beside it the 16 threads that are a one-GPU box's share of the host, and the reference-faithful path
+            # (a box may show all 256 threads of its host and schedule this job on a share of them -- measured on the pool:
+            # 256 threads 2.3e4, 16 threads 7.4e4 -- so both are timed and the FASTER one is the baseline, the other kept)
             ncpu = usable_cpus()
-            line["cpu_baseline"] = cpu_baseline(xs, ys, sigma, ncpu)
+            base = cpu_baseline(xs, ys, sigma, ncpu)
             if ncpu > 16:
-                line["cpu_baseline"]["share_16_threads"] = cpu_baseline(xs, ys, sigma, 16, budget_s=5.0)
+                share = cpu_baseline(xs, ys, sigma, 16, budget_s=5.0)
+                if share["value"] > base["value"]:
+                    base, share = share, base
+                base["other_thread_count"] = {k: share[k] for k in ("value", "cores", "sample")}
+            line["cpu_baseline"] = base
             line["cpu_baseline"]["reference_faithful"] = cpu_reference_faithful(xs, ys, sigma, budget_s=6.0)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1149,7 +1149,8 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   a.short_last = (m.N - 32 * (a.ntiles - 1)) <= 24 ? 1 : 0;
   a.balance = (t_ey_variant & 2) ? 0 : 1;
   {
-    static const int stagger = [] { const char* e = getenv("EY_MF_STAGGER"); return e ? atoi(e) : 0; }();
+    // two row tiles: +0.5-0.9 % over none in three interleaved A/B rounds (profiles/r03_ab_stagger.txt); EY_MF_STAGGER overrides
+    static const int stagger = [] { const char* e = getenv("EY_MF_STAGGER"); return e ? atoi(e) : 2; }();
     a.stagger = stagger;
   }
   if (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) {
