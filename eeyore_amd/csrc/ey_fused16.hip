@@ -416,15 +416,17 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo) H1[mo] = H0[mo];
     } else {
+      // the MT output blocks are independent accumulation chains: stepped together (block innermost), so that at one wave
+      // per SIMD an MFMA does not wait for the result of the one before it
 #pragma unroll
-      for (int mo = 0; mo < MT; ++mo) {
-        v4<T> acc = f16_ld4(lw + K::O_B1 + 16 * mo + 4 * g);
+      for (int mo = 0; mo < MT; ++mo) H1[mo] = f16_ld4(lw + K::O_B1 + 16 * mo + 4 * g);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma16<T>(lw[K::O_W1A + ((mo * MT + m) * 4 + r) * 64 + lane], H0[m][r], acc);
-        H1[mo] = acc;
-      }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mo = 0; mo < MT; ++mo)
+            H1[mo] = mfma16<T>(lw[K::O_W1A + ((mo * MT + m) * 4 + r) * 64 + lane], H0[m][r], H1[mo]);
       f16_act_tiles<T, MT>(a.act1, H1);
     }
     if (GRAD && !(F16_ABLATE & 8)) {
@@ -529,22 +531,23 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
       for (int n = 0; n < MT; ++n) {
         h0u[n] = f16_ld4(lw + K::O_TB1 + (16 * n + c) * F16_TS + 4 * g);
-        v4<T> acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma16<T>(D1[m][r], th[(m * MT + n) * 4 + r], acc);
-        d0u[n] = acc;
+        d0u[n] = v4<T>{0, 0, 0, 0};
       }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int n = 0; n < MT; ++n) d0u[n] = mfma16<T>(D1[m][r], th[(m * MT + n) * 4 + r], d0u[n]);
       f16_dact_tiles<T, MT>(a.act0, d0u, h0u);
       // ---- dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo) {
         const v4<T> d1u = f16_ld4(lw + K::O_TB0 + (16 * mo + c) * F16_TS + 4 * g);
 #pragma unroll
-        for (int n = 0; n < MT; ++n)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dW1[mo * MT + n] = mfma16<T>(d1u[r], h0u[n][r], dW1[mo * MT + n]);
+          for (int n = 0; n < MT; ++n) dW1[mo * MT + n] = mfma16<T>(d1u[r], h0u[n][r], dW1[mo * MT + n]);
         db1[mo] += (d1u[0] + d1u[1]) + (d1u[2] + d1u[3]);
       }
     }
