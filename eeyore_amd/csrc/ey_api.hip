@@ -97,7 +97,8 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
   pl->n_cu = prop.multiProcessorCount;
   pl->variant = g_ey_default_variant.load() & 1023;
   pl->products = (g_ey_default_variant.load() & 1024) ? EY_PRODUCTS_EXACT : ey_default_products();
-  pl->mfma32_ok = ey_mfma32_supports(pl);
+  pl->mfma32_kind = ey_mfma32_kind(pl);
+  pl->mfma32_ok = pl->mfma32_kind != 0;
   pl->fused16_ok = ey_fused16_supports(pl);  // also the headline model's second choice (batches beyond mfma32's row limit)
   *out = pl;
   return EY_OK;
@@ -151,7 +152,12 @@ extern "C" int ey_plan_get_option(const ey_plan* pl, int option, int* value) {
   EY_FAIL(EY_ERR_INVALID, "ey_plan_get_option: unknown option");
 }
 // the fused MFMA kernel serves this plan with the batch it currently holds
-static bool use_mfma32(const ey_plan* pl) { return pl->mfma32_ok && (pl->mfma32_data_ok || !pl->has_data); }
+static bool use_mfma32(const ey_plan* pl) {
+  if (!pl->mfma32_ok || !(pl->mfma32_data_ok || !pl->has_data)) return false;
+  if (pl->mfma32_kind == 2)  // the other 4-32-32 models: the bf16x3 form only, whose LDS image holds 16 row tiles
+    return pl->products == EY_PRODUCTS_BF16X3 && !(t_ey_variant & 1) && (!pl->has_data || pl->m.N <= 512);
+  return true;
+}
 // nvec: state vectors the generic kernel of the calling operation keeps in LDS (2 value/MH, 3 HMC, 4 MALA)
 // The layerwise path is NEEDED when the generic kernel's LDS image does not fit, and PREFERRED for models that fit but
 // are wide enough for 32-wide matrix tiles to beat one wave's vector ALUs: measured (tools/route_probe.py, any number
@@ -219,7 +225,7 @@ int ey_plan_set_data(ey_plan* pl, const void* x, const void* y, int64_t N, void*
     int rc = ey_mfma32_set_data(pl, s);
     if (rc) return rc;
   }
-  if (pl->fused16_ok && !(pl->mfma32_ok && pl->mfma32_data_ok)) {
+  if (pl->fused16_ok && (pl->mfma32_kind == 2 || !(pl->mfma32_ok && pl->mfma32_data_ok))) {  // kind 2: either may serve
     int rc = ey_fused16_set_data(pl, s);
     if (rc) return rc;
   }

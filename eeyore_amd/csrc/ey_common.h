@@ -70,6 +70,7 @@ struct ey_plan {
   int* d_labels;
   // mfma32 path (4-32-32-3-like models, f32): padded/packed data image
   bool mfma32_ok;        // the model is one the fused kernel serves
+  int mfma32_kind = 0;   // 1: the headline model; 2: served in the bf16x3 form only (ey_mfma32_kind)
   bool mfma32_data_ok;   // ... and the current batch fits its LDS image (recomputed by every ey_plan_set_data)
   void* d_xpack;
   int64_t cap_N;         // rows the data buffers below were allocated for (they only grow)
@@ -175,6 +176,7 @@ void ey_large_free(ey_plan* pl);
 
 // mfma32 kernels (ey_mfma32.hip)
 bool ey_mfma32_supports(const ey_plan* pl);
+int ey_mfma32_kind(const ey_plan* pl);  // 1 the headline model, 2 served in the bf16x3 form only, 0 not served
 int ey_mfma32_set_data(ey_plan* pl, hipStream_t s);
 int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
                   const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,

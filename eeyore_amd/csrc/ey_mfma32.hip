@@ -65,8 +65,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define I_W1 160
 #define I_B1 1184
 #define I_W2 1216
-#define I_B2 1312
-#define NPAR 1315
+#define I_B2 (1216 + 32 * DKV)   // DKV = outputs of the model: a compile-time constant in scope wherever these are used
+#define NPAR (1216 + 33 * DKV)
+
+// What varies between the models this kernel serves: MLP(4-32-32-DK), both hidden layers with activation ACT, head LIK.
+//   CE-sum on DK = 3 logits (the headline model; eeyore/constants/constants.py:17) or BCE-sum on one sigmoid output
+//   (eeyore/stats/loss.py:1-11, naive logs: NaN once the output saturates, which rejects).
+template <int DK_, int ACT_, int LIK_>
+struct MfShape {
+  static constexpr int DK = DK_, ACT = ACT_, LIK = LIK_;
+};
+typedef MfShape<3, EY_ACT_SIGMOID, EY_LIK_CE_SUM> MfHeadline;
 
 enum { MODE_HMC = 0, MODE_GRAD = 1, MODE_LEAPFROG = 2, MODE_MALA = 3, MODE_MH = 4 };
 
@@ -116,12 +125,13 @@ struct MfArgs {
 // The arguments as the kernels read them: in place in the kernarg segment (constant address space, scalar loads).
 typedef const __attribute__((address_space(4))) MfArgs KArgs;
 
+template <int DKV>
 struct Vec {
   float w1[16];
   float w0[4];
-  float w2[3];
+  float w2[DKV];
   float b1, b0;
-  float b2[3];
+  float b2[DKV];
 };
 
 // Wave reductions without LDS traffic.  wsum: DPP adds inside each 16-lane row (quad swaps, half-mirror, mirror), then
@@ -179,9 +189,20 @@ __device__ unsigned long long g_ey_wave_t[3 * 8192];  // per chain: kernel entry
 __device__ __forceinline__ f32x2 pk_add1(f32x2 a) { return a + 1.0f; }
 __device__ __forceinline__ f32x2 pk_h_one_minus_h(f32x2 h) { return __builtin_elementwise_fma(-h, h, h); }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
-// sigmoid of a whole accumulator tile: exp2, packed "+1", rcp
-__device__ __forceinline__ f32x16 sigmoid_tile(const f32x16& a) {
+// The staged images of W0, b0, W1, b1 carry the activation's factor, so the accumulator holds s * g:
+//   sigmoid(g) = 1 / (1 + 2^(-log2e g))            s = -log2(e):   v_exp_f32, packed "+1", v_rcp_f32
+//   tanh(g)    = 2 / (1 + 2^(-2 log2e g)) - 1      s = -2 log2(e): the same and one fma
+//   relu(g)    = max(g, 0)                          s = 1
+template <int ACT>
+struct ActScale { static constexpr float value = ACT == EY_ACT_SIGMOID ? NEG_LOG2E : (ACT == EY_ACT_TANH ? 2.0f * NEG_LOG2E : 1.0f); };
+template <int ACT>
+__device__ __forceinline__ f32x16 act_tile(const f32x16& a) {
   f32x16 h;
+  if (ACT == EY_ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[r] = fmaxf(a[r], 0.0f);
+    return h;
+  }
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
     f32x2 e;
@@ -190,16 +211,27 @@ __device__ __forceinline__ f32x16 sigmoid_tile(const f32x16& a) {
     e = pk_add1(e);
     h[r] = (EY_ABLATE & 4) ? e[0] : __builtin_amdgcn_rcpf(e[0]);
     h[r + 1] = (EY_ABLATE & 4) ? e[1] : __builtin_amdgcn_rcpf(e[1]);
+    if (ACT == EY_ACT_TANH) {
+      h[r] = __builtin_fmaf(2.0f, h[r], -1.0f);
+      h[r + 1] = __builtin_fmaf(2.0f, h[r + 1], -1.0f);
+    }
   }
   return h;
 }
-// d * h (1 - h) for a tile
-__device__ __forceinline__ f32x16 times_dsigmoid(const f32x16& d, const f32x16& h) {
+// d * act'(g) from the activation value h:  sigmoid h (1 - h),  tanh 1 - h^2,  relu [h > 0]
+template <int ACT>
+__device__ __forceinline__ f32x16 times_dact(const f32x16& d, const f32x16& h) {
   f32x16 o;
+  if (ACT == EY_ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = h[r] > 0.0f ? d[r] : 0.0f;
+    return o;
+  }
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
     const f32x2 h2 = {h[r], h[r + 1]}, d2 = {d[r], d[r + 1]};
-    const f32x2 v = pk_mul(d2, pk_h_one_minus_h(h2));
+    const f32x2 dh = ACT == EY_ACT_TANH ? __builtin_elementwise_fma(-h2, h2, f32x2{1.0f, 1.0f}) : pk_h_one_minus_h(h2);
+    const f32x2 v = pk_mul(d2, dh);
     o[r] = v[0];
     o[r + 1] = v[1];
   }
@@ -271,76 +303,76 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // visit every canonical element a lane holds: f(value&, canonical index, counts) where `counts` says whether this
 // lane's copy is the one that enters sums over parameters (replicas in the other half / other lanes do not)
-template <typename F>
-__device__ __forceinline__ void for_each(Vec& v, int c, int h, int lane, F f) {
+template <int DKV, typename F>
+__device__ __forceinline__ void for_each(Vec<DKV>& v, int c, int h, int lane, F f) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) f(v.w1[r], I_W1 + (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + c, true);
 #pragma unroll
   for (int i = 0; i < 4; ++i) f(v.w0[i], I_W0 + (4 * (c >> 2) + i) * 4 + (c & 3), h == 0);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) f(v.w2[o], I_W2 + o * 32 + c, h == 0);
+  for (int o = 0; o < DKV; ++o) f(v.w2[o], I_W2 + o * 32 + c, h == 0);
   f(v.b1, I_B1 + c, h == 0);
   f(v.b0, I_B0 + c, h == 0);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) f(v.b2[o], I_B2 + o, lane == 0);
+  for (int o = 0; o < DKV; ++o) f(v.b2[o], I_B2 + o, lane == 0);
 }
-template <typename F>
-__device__ __forceinline__ void for_each_pair(Vec& a, Vec& b, int c, int h, int lane, F f) {
+template <int DKV, typename F>
+__device__ __forceinline__ void for_each_pair(Vec<DKV>& a, Vec<DKV>& b, int c, int h, int lane, F f) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) f(a.w1[r], b.w1[r], I_W1 + (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + c, true);
 #pragma unroll
   for (int i = 0; i < 4; ++i) f(a.w0[i], b.w0[i], I_W0 + (4 * (c >> 2) + i) * 4 + (c & 3), h == 0);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) f(a.w2[o], b.w2[o], I_W2 + o * 32 + c, h == 0);
+  for (int o = 0; o < DKV; ++o) f(a.w2[o], b.w2[o], I_W2 + o * 32 + c, h == 0);
   f(a.b1, b.b1, I_B1 + c, h == 0);
   f(a.b0, b.b0, I_B0 + c, h == 0);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) f(a.b2[o], b.b2[o], I_B2 + o, lane == 0);
+  for (int o = 0; o < DKV; ++o) f(a.b2[o], b.b2[o], I_B2 + o, lane == 0);
 }
-template <typename F>
-__device__ __forceinline__ void for_each3(Vec& a, Vec& b, Vec& d, int c, int h, int lane, F f) {
+template <int DKV, typename F>
+__device__ __forceinline__ void for_each3(Vec<DKV>& a, Vec<DKV>& b, Vec<DKV>& d, int c, int h, int lane, F f) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) f(a.w1[r], b.w1[r], d.w1[r], I_W1 + (8 * (r >> 2) + 4 * h + (r & 3)) * 32 + c, true);
 #pragma unroll
   for (int i = 0; i < 4; ++i) f(a.w0[i], b.w0[i], d.w0[i], I_W0 + (4 * (c >> 2) + i) * 4 + (c & 3), h == 0);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) f(a.w2[o], b.w2[o], d.w2[o], I_W2 + o * 32 + c, h == 0);
+  for (int o = 0; o < DKV; ++o) f(a.w2[o], b.w2[o], d.w2[o], I_W2 + o * 32 + c, h == 0);
   f(a.b1, b.b1, d.b1, I_B1 + c, h == 0);
   f(a.b0, b.b0, d.b0, I_B0 + c, h == 0);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) f(a.b2[o], b.b2[o], d.b2[o], I_B2 + o, lane == 0);
+  for (int o = 0; o < DKV; ++o) f(a.b2[o], b.b2[o], d.b2[o], I_B2 + o, lane == 0);
 }
-template <typename F>
-__device__ __forceinline__ void for_each2(Vec& a, Vec& b, F f) {
+template <int DKV, typename F>
+__device__ __forceinline__ void for_each2(Vec<DKV>& a, Vec<DKV>& b, F f) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) f(a.w1[r], b.w1[r]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) f(a.w0[i], b.w0[i]);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) f(a.w2[o], b.w2[o]);
+  for (int o = 0; o < DKV; ++o) f(a.w2[o], b.w2[o]);
   f(a.b1, b.b1);
   f(a.b0, b.b0);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) f(a.b2[o], b.b2[o]);
+  for (int o = 0; o < DKV; ++o) f(a.b2[o], b.b2[o]);
 }
 
 // stage the operand images of theta in this wave's LDS region
-template <bool BF3>
-__device__ __forceinline__ void write_images(float* lw, const Vec& th, int c, int h, int lane) {
+template <bool BF3, typename SH>
+__device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, int c, int h, int lane) {
+  constexpr float SC = ActScale<SH::ACT>::value;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = NEG_LOG2E * th.w1[r];
+  for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = SC * th.w1[r];
   if (h == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lw[O_W0IMG + (4 * (c >> 2) + i) * 5 + (c & 3)] = NEG_LOG2E * th.w0[i];
+    for (int i = 0; i < 4; ++i) lw[O_W0IMG + (4 * (c >> 2) + i) * 5 + (c & 3)] = SC * th.w0[i];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-      lw[O_W2IMG + o * TS36 + c] = th.w2[o];
-      lw[O_W2TIMG + c * 4 + o] = th.w2[o];
+    for (int o = 0; o < 4; ++o) {  // outputs beyond DK are zero rows / columns of the two images
+      const float w = o < SH::DK ? th.w2[o < SH::DK ? o : 0] : 0.0f;
+      lw[O_W2IMG + o * TS36 + c] = w;
+      lw[O_W2TIMG + c * 4 + o] = w;
     }
-    lw[O_W2IMG + 3 * TS36 + c] = 0.0f;
-    lw[O_W2TIMG + c * 4 + 3] = 0.0f;
-    lw[O_B1IMG + c] = NEG_LOG2E * th.b1;
-    lw[O_B0IMG + c] = NEG_LOG2E * th.b0;
+    lw[O_B1IMG + c] = SC * th.b1;
+    lw[O_B0IMG + c] = SC * th.b0;
   }
   wave_lds_fence();
   if constexpr (BF3) {
@@ -408,21 +440,23 @@ __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
 // latency the end of every evaluation then waits for (four serial round trips per leapfrog step before this).
 // GRAD = false: the value only (random-walk MH needs no gradient, metropolis_hastings.py:41-73): the forward products
 // and the row log-sum-exp, about a third of the work.
-template <int PARK, bool UPRIOR, bool BF3, bool GRAD = true>
-__device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, bool has_temp, float temp, int c,
-                      int h, int lane, bool need_value, Pace& pc) {
+template <int PARK, bool UPRIOR, bool BF3, typename SH, bool GRAD = true>
+__device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec<SH::DK>& g, bool has_temp, float temp,
+                      int c, int h, int lane, bool need_value, Pace& pc) {
+  constexpr int DKV = SH::DK;
   const int jj = lane & 3;
   f32x16 dW1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dW1[r] = 0.0f;
   f32x4 dW0a = {0, 0, 0, 0}, dW0b = {0, 0, 0, 0}, dW2a = {0, 0, 0, 0}, dW2b = {0, 0, 0, 0};
-  float db1 = 0.0f, db0 = 0.0f, db2[3] = {0.0f, 0.0f, 0.0f}, lik = 0.0f;
-
-  const float b2_0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[0])));
-  const float b2_1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[1])));
-  const float b2_2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[2])));
-  static_assert(PARK == 0 || PARK == 12, "all twelve elements or none");
-  if (PARK) {
+  float db1 = 0.0f, db0 = 0.0f, db2[DKV], b2s[DKV], lik = 0.0f;
+#pragma unroll
+  for (int o = 0; o < DKV; ++o) {
+    db2[o] = 0.0f;
+    b2s[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[o])));
+  }
+  static_assert(PARK == 0 || (PARK == 12 && DKV == 3), "all twelve elements of the three-output model or none");
+  if constexpr (PARK != 0) {
     float* park = lw + WAVE_FLOATS + lane;
 #pragma unroll
     for (int i = 0; i < 4; ++i) park[i * 64] = th.w0[i];
@@ -467,7 +501,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     for (int s = 0; s < 2; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw[O_W0IMG + c * 5 + 2 * s + h], xt[c * 5 + 2 * s + h], acc, 0, 0, 0);
     const int lab = __float_as_int(xt[c * 5 + 4]);
-    const f32x16 H0 = sigmoid_tile(acc);
+    const f32x16 H0 = act_tile<SH::ACT>(acc);
     if (GRAD) store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
     PH(0);
     // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
@@ -496,7 +530,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
       }
     }
     pace_apply(pc, pace_theirs);  // while the F1 products run
-    const f32x16 H1 = sigmoid_tile(acc);
+    const f32x16 H1 = act_tile<SH::ACT>(acc);
     if (GRAD) store_T(lw + O_TB0, H1, c, h);  // transposed copy for dW2; the logits and the softmax run while it lands
     PH(1);
     // ---- F2: logits = W2 H1^T + b2 with the 16-block 4x4x1 product; each half sums its 16 features
@@ -509,31 +543,48 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
       lg0 = mfma4(wv[2], H1[4 * q + 2], lg0);
       lg1 = mfma4(wv[3], H1[4 * q + 3], lg1);
     }
-    float l0 = lg0[0] + lg1[0], l1 = lg0[1] + lg1[1], l2 = lg0[2] + lg1[2];
-    l0 = hsum(l0); l1 = hsum(l1); l2 = hsum(l2);
-    l0 += b2_0; l1 += b2_1; l2 += b2_2;
+    float lg[DKV];
+#pragma unroll
+    for (int o = 0; o < DKV; ++o) lg[o] = hsum(lg0[o] + lg1[o]) + b2s[o];
     PH(2);
-    // ---- CE-sum log-likelihood and output delta = onehot - softmax           (constants.py:17)
-    const bool valid = lab >= 0;
-    const float mx = fmaxf(l0, fmaxf(l1, l2));
-    const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx), e2 = __expf(l2 - mx);
-    const float ssum = e0 + e1 + e2;
-    const float llab = lab == 0 ? l0 : (lab == 1 ? l1 : l2);
-    if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
-    if (!GRAD) return;  // nothing was written to LDS in this tile
-    const float rs = __builtin_amdgcn_rcpf(ssum);
-    float d2[3];
-    d2[0] = valid ? ((lab == 0 ? 1.0f : 0.0f) - e0 * rs) : 0.0f;
-    d2[1] = valid ? ((lab == 1 ? 1.0f : 0.0f) - e1 * rs) : 0.0f;
-    d2[2] = valid ? ((lab == 2 ? 1.0f : 0.0f) - e2 * rs) : 0.0f;
+    float d2[DKV];
+    if constexpr (SH::LIK == EY_LIK_CE_SUM) {
+      // ---- CE-sum log-likelihood and output delta = onehot - softmax           (constants.py:17)
+      const bool valid = lab >= 0;
+      float mx = lg[0];
+#pragma unroll
+      for (int o = 1; o < DKV; ++o) mx = fmaxf(mx, lg[o]);
+      float e[DKV], ssum = 0.0f, llab = lg[0];
+#pragma unroll
+      for (int o = 0; o < DKV; ++o) {
+        e[o] = __expf(lg[o] - mx);
+        ssum += e[o];
+        if (o > 0) llab = lab == o ? lg[o] : llab;
+      }
+      if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
+      if (!GRAD) return;  // nothing was written to LDS in this tile
+      const float rs = __builtin_amdgcn_rcpf(ssum);
+#pragma unroll
+      for (int o = 0; o < DKV; ++o) d2[o] = valid ? ((lab == o ? 1.0f : 0.0f) - e[o] * rs) : 0.0f;
+    } else {
+      // ---- BCE-sum on the sigmoid output, with the naive logs of eeyore/stats/loss.py:2 (an output that rounds to 0 or
+      // 1 makes the term NaN, which rejects: the reference's own f32 behaviour); the slot that holds the label of a CE
+      // model holds y here, -1 marking a padding row
+      const float yy = __int_as_float(lab);
+      const bool valid = yy >= 0.0f;
+      const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(NEG_LOG2E * lg[0]));
+      if (need_value && valid && h == 0) lik += __logf(pr) * yy + __logf(1.0f - pr) * (1.0f - yy);
+      if (!GRAD) return;
+      d2[0] = valid ? (yy / pr - (1.0f - yy) / (1.0f - pr)) * (pr * (1.0f - pr)) : 0.0f;
+    }
     if (h == 0) {
-      db2[0] += d2[0]; db2[1] += d2[1]; db2[2] += d2[2];
       // delta2 regrouped [o][half][s'][i] with row = 8s'+4*half+i, the k order of the transposed reads below
       const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
-      lw[O_D2BUF + 0 * D2S + a2] = d2[0];
-      lw[O_D2BUF + 1 * D2S + a2] = d2[1];
-      lw[O_D2BUF + 2 * D2S + a2] = d2[2];
-      lw[O_D2BUF + 3 * D2S + a2] = 0.0f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        if (o < DKV) db2[o < DKV ? o : 0] += d2[o < DKV ? o : 0];
+        lw[O_D2BUF + o * D2S + a2] = o < DKV ? d2[o < DKV ? o : 0] : 0.0f;
+      }
     }
     wave_lds_fence();
     PH(3);
@@ -554,14 +605,13 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
     for (int q = 0; q < 4; ++q) {
       const f32x4 wt = *reinterpret_cast<const f32x4*>(lw + O_W2TIMG + (8 * q + 4 * h + jj) * 4);
       f32x4 d = {0, 0, 0, 0};
-      d = mfma4(wt[0], d2[0], d);
-      d = mfma4(wt[1], d2[1], d);
-      d = mfma4(wt[2], d2[2], d);
+#pragma unroll
+      for (int o = 0; o < DKV; ++o) d = mfma4(wt[o], d2[o], d);
 #pragma unroll
       for (int i = 0; i < 4; ++i) D1[4 * q + i] = d[i];
     }
     PH(5);
-    D1 = times_dsigmoid(D1, H1);
+    D1 = times_dact<SH::ACT>(D1, H1);
     wave_lds_fence();
     store_T(lw + O_TB0, D1, c, h);
     wave_lds_fence();
@@ -605,7 +655,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
     }
-    const f32x16 D0u = times_dsigmoid(acc, H0U);
+    const f32x16 D0u = times_dact<SH::ACT>(acc, H0U);
     PH(8);
     // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
     const float* x2 = xt + 160 + jj * D2S + h * 16;
@@ -639,7 +689,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
       th.w1[r] = (fh + fm) + fl;
     }
   }
-  if (PARK) {
+  if constexpr (PARK != 0) {
     int at = WAVE_FLOATS + lane;
     asm volatile("" : "+v"(at));  // an offset the compiler cannot match with the stores above: no forwarding
 #pragma unroll
@@ -660,7 +710,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
       g.w0[i] = hsum(dW0a[i] + dW0b[i]);
     }
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
+    for (int o = 0; o < DKV; ++o) {
       g.w2[o] = hsum(dW2a[o] + dW2b[o]);
       g.b2[o] = wsum(db2[o]);
     }
@@ -715,7 +765,8 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec& th, Vec& g, boo
 // Attached running moments: s1 += theta, s2 += theta^2, acc += accepted for the state this chain is left in, with the
 // arithmetic of ey_stats_update (the product of two floats is exact in double).  `now` holds the state where the lane
 // has it in registers; `from_memory` says to take it from theta in HBM instead (a rejected HMC proposal).
-__device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, const float* thg, bool from_memory,
+template <int DKV>
+__device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec<DKV>& now, const float* thg, bool from_memory,
                                             bool accepted, int c, int h, int lane) {
   double* m1 = A.mom_s1 + chain * NPAR;
   double* m2 = A.mom_s2 + chain * NPAR;
@@ -726,7 +777,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
   // before the first use (sched_barrier), so the wave waits for two memory round trips per draw, not for one per group
   // of loads -- and not for one only, which would take 145 registers at once and push the values that live across the
   // whole iteration (addresses, lane constants) into scratch, from where every leapfrog step then reloads them.
-  float x[29];
+  float x[26 + DKV];
   {
     int k = 0;
     for_each(now, c, h, lane, [&](float& v, int idx, bool counts) {
@@ -736,7 +787,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    const int k0 = half == 0 ? 0 : 16, k1 = half == 0 ? 16 : 29;
+    const int k0 = half == 0 ? 0 : 16, k1 = half == 0 ? 16 : 26 + DKV;
     double a1[16], a2[16];
     int k = 0;
     for_each(now, c, h, lane, [&](float&, int idx, bool counts) {
@@ -765,7 +816,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec& now, c
 // l, l + 64, ... (ey_rng_normal4: one Philox call per block) into the two transpose buffers of this wave's LDS region
 // (free between evaluations), from where every lane then picks the 29 elements of its register layout.  One call
 // per element in every lane, as a lane-local draw needs, costs 29 Philox calls per lane instead of at most 6.
-template <bool BF3>
+template <bool BF3, int DKV>
 __device__ __forceinline__ const float* stage_normals(float* lw, const EyRng& rn, int lane) {
   float* st = lw + O_TB0;  // O_TB0 and O_TB1 are adjacent: 2304 floats >= NPAR + 3
   constexpr int NB = (NPAR + 3) / 4;
@@ -779,9 +830,11 @@ __device__ __forceinline__ const float* stage_normals(float* lw, const EyRng& rn
 }
 
 // One chain of one launch: everything between reading theta and writing the accepted state back.
-template <int MODE, int PARK, bool UPRIOR, bool DA, bool BF3>
+template <int MODE, int PARK, bool UPRIOR, bool DA, bool BF3, typename SH>
 __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int it,
                                           const int c, const int h, const int lane, Pace& pc) {
+  constexpr int DKV = SH::DK;
+  typedef Vec<DKV> Vec;
   // Later iterations of one launch read what this wave's lanes wrote at the end of the previous one.  Workgroup scope
   // is enough (and only costs a wait for the outstanding stores): all accesses go through this CU's vector cache in
   // order; an agent-scope release would write the whole L2 of the XCD back every iteration.
@@ -803,8 +856,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   for_each(th, c, h, lane, [&](float& v, int idx, bool) { v = thg[idx]; });
 
   if (MODE == MODE_GRAD) {
-    write_images<BF3>(lw, th, c, h, lane);
-    const float t = eval<PARK, UPRIOR, BF3>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3, SH>(lw, th, c, h, lane);
+    const float t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
     for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
     if (lane == 0) A.target[chain] = t;
     return;
@@ -819,7 +872,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     float qf = 0.0f;
     Vec gp;
     if (MODE == MODE_MALA) for_each(g, c, h, lane, [&](float& v, int idx, bool) { v = grg[idx]; });
-    const float* zst = zin ? nullptr : stage_normals<BF3>(lw, rn, lane);
+    const float* zst = zin ? nullptr : stage_normals<BF3, DKV>(lw, rn, lane);
     for_each3(th, g, p, c, h, lane, [&](float& tv, float& gv, float& pv, int idx, bool counts) {
       const float zi = zin ? zin[idx] : zst[idx];
       if (MODE == MODE_MALA) {
@@ -832,8 +885,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
       }
     });
     wave_lds_fence();  // the staged normals have been read; the evaluation reuses that LDS
-    write_images<BF3>(lw, p, c, h, lane);
-    const float tv = eval<PARK, UPRIOR, BF3, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3, SH>(lw, p, c, h, lane);
+    const float tv = eval<PARK, UPRIOR, BF3, SH, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
     const float t_old = A.target[chain];
     float log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
     if (MODE == MODE_MALA) {
@@ -875,7 +928,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   if (MODE == MODE_HMC) {
     const EyRng rn = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_NORMAL);
     const float* p0 = A.p0 ? A.p0 + chain * NPAR : nullptr;
-    const float* pst = p0 ? nullptr : stage_normals<BF3>(lw, rn, lane);
+    const float* pst = p0 ? nullptr : stage_normals<BF3, DKV>(lw, rn, lane);
     for_each(p, c, h, lane, [&](float& v, int idx, bool counts) {
       v = p0 ? p0[idx] : pst[idx];   // hmc.py:134
       if (counts) kin += v * v;
@@ -891,8 +944,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   const float h_cur = -t_cur + 0.5f * kin;  // hmc.py:91-98,137
   float t = t_cur;
   if (MODE == MODE_LEAPFROG || A.recompute) {  // hmc.py:104
-    write_images<BF3>(lw, th, c, h, lane);
-    t = eval<PARK, UPRIOR, BF3>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3, SH>(lw, th, c, h, lane);
+    t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
   }
   // leapfrog, hmc.py:100-124 (grad_potential = -grad)
   for_each2(p, g, [&](float& pv, float& gv) { pv = pv + 0.5f * eps * gv; });
@@ -901,9 +954,9 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   for (int k = 1; k <= A.L; ++k) {
     for_each2(th, p, [&](float& tv, float& pv) { tv = tv + eps * pv; });
     KO(1);
-    write_images<BF3>(lw, th, c, h, lane);
+    write_images<BF3, SH>(lw, th, c, h, lane);
     KO(2);
-    t = eval<PARK, UPRIOR, BF3>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc);
+    t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc);
     KO(3);
     const float w = (k < A.L) ? eps : 0.5f * eps;
     for_each2(p, g, [&](float& pv, float& gv) { pv = pv + w * gv; });
@@ -981,7 +1034,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
 // Two waves share a SIMD because f32 MFMA runs on the vector ALUs: the partner hides latency (LDS round trips, MFMA
 // result latency) rather than adding throughput (tools/coexec_probe*.hip).  WAVES = 4 is the former layout (two
 // 4-wave workgroups per CU, one chain per wave), kept for A/B runs (ey_debug_set_variant bit 0).
-template <int MODE, int WAVES, int PARK, bool UPRIOR, bool DA, bool BF3>
+template <int MODE, int WAVES, int PARK, bool UPRIOR, bool DA, bool BF3, typename SH>
 __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   constexpr int MF_WAVES = WAVES, MF_THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1049,20 +1102,26 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
 #if EY_PHASE_TIMING
       if (lane == 0 && chain < 8192) g_ey_wave_t[3 * chain] = rt_entry;
 #endif
-      run_chain<MODE, PARK, UPRIOR, DA, BF3>(*Ap, xs, lw, chain, it, c, h, lane, pc);
+      run_chain<MODE, PARK, UPRIOR, DA, BF3, SH>(*Ap, xs, lw, chain, it, c, h, lane, pc);
     }
   }
   if (lane == 0) __hip_atomic_store(&ctl[wave], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // nothing left
 }
 
 // ----------------------------------------------------------------------------------------------- host side
-bool ey_mfma32_supports(const ey_plan* pl) {
+// 1: the headline model (both product forms); 2: a 4-32-32 model with another hidden activation or the BCE head, served
+// in the bf16x3 form only (the exact form of those is fused16's); 0: not this kernel's
+int ey_mfma32_kind(const ey_plan* pl) {
   const EyModel& m = pl->m;
-  if (pl->dtype != EY_F32 || m.nl != 3 || m.lik != EY_LIK_CE_SUM) return false;
-  if (m.dims[0] != 4 || m.dims[1] != 32 || m.dims[2] != 32 || m.dims[3] != 3) return false;
-  if (!m.bias[0] || !m.bias[1] || !m.bias[2]) return false;
-  return m.act[0] == EY_ACT_SIGMOID && m.act[1] == EY_ACT_SIGMOID && m.act[2] == EY_ACT_NONE;
+  if (pl->dtype != EY_F32 || m.nl != 3) return 0;
+  if (m.dims[0] != 4 || m.dims[1] != 32 || m.dims[2] != 32) return 0;
+  if (!m.bias[0] || !m.bias[1] || !m.bias[2]) return 0;
+  if (m.act[0] != m.act[1] || m.act[0] < EY_ACT_SIGMOID || m.act[0] > EY_ACT_RELU) return 0;
+  if (m.lik == EY_LIK_CE_SUM && m.dims[3] == 3 && m.act[2] == EY_ACT_NONE) return m.act[0] == EY_ACT_SIGMOID ? 1 : 2;
+  if (m.lik == EY_LIK_BCE_SUM && m.dims[3] == 1 && m.act[2] == EY_ACT_SIGMOID) return 2;
+  return 0;
 }
+bool ey_mfma32_supports(const ey_plan* pl) { return ey_mfma32_kind(pl) != 0; }
 
 static size_t mf_lds_bytes(int ntiles, int waves, int park, bool bf3) {
   return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * (WAVE_FLOATS_OF(bf3) + 64 * park)) +
@@ -1081,8 +1140,8 @@ static size_t mf_lds_bytes(int ntiles, int waves, int park, bool bf3) {
 
 // Pack (x, labels) into the per-tile LDS images, on the device and on the caller's stream: one thread per (tile, row).
 // Rows beyond N are zero with label -1 (they contribute nothing).
-__global__ void k_mf_pack(const float* __restrict__ x, const int* __restrict__ labels, int N, int ntiles,
-                          float* __restrict__ img) {
+__global__ void k_mf_pack(const float* __restrict__ x, const int* __restrict__ labels, const float* __restrict__ y1,
+                          int N, int ntiles, float* __restrict__ img) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ntiles * 32) return;
   const int t = i >> 5, cc = i & 31, n = i;
@@ -1096,7 +1155,8 @@ __global__ void k_mf_pack(const float* __restrict__ x, const int* __restrict__ l
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) xt[cc * 5 + k] = xv[k];
-  xt[cc * 5 + 4] = __int_as_float(lab);
+  // the label of a CE model; for the BCE head (y1 given: one output) the target y itself, -1 marking a padding row
+  xt[cc * 5 + 4] = y1 ? (n < N ? y1[n] : -1.0f) : __int_as_float(lab);
   // regrouped copy for the 4x4x1 weight-gradient product: [in][half][s'][i], row = 8s' + 4 half + i
   const int sp = cc >> 3, hh = (cc >> 2) & 1, ii = cc & 3;
 #pragma unroll
@@ -1114,27 +1174,29 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
   if (!pl->mfma32_data_ok) return EY_OK;
   if (!pl->d_xpack) EY_HIP(hipMalloc(&pl->d_xpack, sizeof(float) * (size_t)MF_MAX_TILES * XTILE_FLOATS));
   hipLaunchKernelGGL(k_mf_pack, dim3((ntiles * 32 + 255) / 256), dim3(256), 0, s, (const float*)pl->d_x,
-                     (const int*)pl->d_labels, m.N, ntiles, (float*)pl->d_xpack);
+                     (const int*)pl->d_labels, m.lik == EY_LIK_BCE_SUM ? (const float*)pl->d_y : nullptr, m.N, ntiles,
+                     (float*)pl->d_xpack);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
 
-template <int MODE, int WAVES, int PARK, bool UPRIOR = false, bool DA = true, bool BF3 = false>
+template <int MODE, int WAVES, int PARK, bool UPRIOR = false, bool DA = true, bool BF3 = false, typename SH = MfHeadline>
 static int mf_launch_v(MfArgs& a, int n_cu, hipStream_t s) {
   const size_t bytes = mf_lds_bytes(a.ntiles, WAVES, PARK, BF3);
   // per launch: function attributes are per device and plans on different devices / threads share this code
-  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PARK, UPRIOR, DA, BF3>),
+  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PARK, UPRIOR, DA, BF3, SH>),
                              hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)mf_lds_bytes(BF3 ? MF_BF3_TILES : (PARK ? MF_PARK_TILES : MF_MAX_TILES), WAVES, PARK, BF3)));
   // 8 waves: one persistent workgroup per CU, or one per chain when there are fewer chains than CUs (then only wave
   // 0 of a workgroup has work and every chain gets a CU to itself); 4 waves: a workgroup per 4 chains
   const unsigned grid = WAVES == 8 ? (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256)
                                    : (unsigned)((a.C + WAVES - 1) / WAVES);
-  hipLaunchKernelGGL((k_mfma32<MODE, WAVES, PARK, UPRIOR, DA, BF3>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+  hipLaunchKernelGGL((k_mfma32<MODE, WAVES, PARK, UPRIOR, DA, BF3, SH>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
 
+#define MF_COMMA ,
 template <int MODE>
 static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
   const EyModel& m = pl->m;
@@ -1159,6 +1221,20 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
     a.mom_acc = pl->mom_acc;
   }
   const bool bf3 = pl->products == EY_PRODUCTS_BF16X3 && a.ntiles <= MF_BF3_TILES && !(t_ey_variant & 1);
+  if (ey_mfma32_kind(pl) == 2) {
+    // the other 4-32-32 models: one instantiation per mode (bf16x3 form, any prior, in-kernel tuner compiled in)
+    if (!bf3) EY_FAIL(EY_ERR_UNSUPPORTED, "mfma32: this model is served in the bf16x3 form only");
+    const int act = m.act[0];
+#define MF_SHAPE_LAUNCH(SHAPE) return mf_launch_v<MODE, 8, 0, false, true, true, SHAPE>(a, pl->n_cu, s)
+    if (m.lik == EY_LIK_CE_SUM) {
+      if (act == EY_ACT_TANH) MF_SHAPE_LAUNCH(MfShape<3 MF_COMMA EY_ACT_TANH MF_COMMA EY_LIK_CE_SUM>);
+      MF_SHAPE_LAUNCH(MfShape<3 MF_COMMA EY_ACT_RELU MF_COMMA EY_LIK_CE_SUM>);
+    }
+    if (act == EY_ACT_SIGMOID) MF_SHAPE_LAUNCH(MfShape<1 MF_COMMA EY_ACT_SIGMOID MF_COMMA EY_LIK_BCE_SUM>);
+    if (act == EY_ACT_TANH) MF_SHAPE_LAUNCH(MfShape<1 MF_COMMA EY_ACT_TANH MF_COMMA EY_LIK_BCE_SUM>);
+    MF_SHAPE_LAUNCH(MfShape<1 MF_COMMA EY_ACT_RELU MF_COMMA EY_LIK_BCE_SUM>);
+#undef MF_SHAPE_LAUNCH
+  }
   if constexpr (MODE == MODE_HMC) {
     const int variant = t_ey_variant & 15;
     if (variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);

@@ -47,14 +47,16 @@ enum ey_dtype { EY_F32 = 0, EY_F64 = 1 }; /* model.dtype, eeyore/models/model.py
 
 /* Plan options (ey_plan_set_option).
  * EY_OPT_F32_PRODUCTS: how the fused f32 trajectory kernel ("mfma32": MLP(4-32-32-3), BASELINE configs 3/4) forms its three
- * 32x32x32 products per row tile.  The reference computes them with torch's f32 matmul (eeyore/models/mlp.py:45-50 ->
+ * 32x32x32 products per row tile, and the layerwise path ("bgemm") its 128-wide batched products.  The reference computes them with torch's f32 matmul (eeyore/models/mlp.py:45-50 ->
  * nn.Linear); both forms below are f32 in, f32 out, f32 accumulate, and both pass every f32 parity test at the same
  * tolerances:
  *   EY_PRODUCTS_BF16X3 (default): each f32 operand is split EXACTLY into three bf16 pieces (hi + mid + lo = x) and the
  *     product is summed from the six piece products of relative size >= 2^-18 on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 is
  *     exact in f32, accumulation in f32, smallest terms first); measured error against f64 <= the exact form's
- *     (profiles/r03_bf3_error_probe.txt, tests/test_bf16x3.py); taken for batches of up to 512 rows;
- *   EY_PRODUCTS_EXACT: v_mfma_f32_32x32x2_f32, bit for bit a k-ordered f32 fma chain.
+ *     (profiles/r03_bf3_error_probe.txt, tests/test_bf16x3.py); the fused kernel takes it for batches of up to 512
+ *     rows, and in this form it also serves the other MLP(4-32-32-dK) models with one hidden activation (sigmoid / tanh /
+ *     relu; CE-sum on 3 logits or BCE-sum on one sigmoid output), which otherwise run on "fused16";
+ *   EY_PRODUCTS_EXACT: v_mfma_f32_32x32x2_f32 (16x16x4 on "fused16"), bit for bit a k-ordered f32 fma chain.
  * The environment variable EY_F32_PRODUCTS=exact|bf16x3 sets what new plans start with. */
 enum ey_option { EY_OPT_F32_PRODUCTS = 1 };
 enum ey_products { EY_PRODUCTS_BF16X3 = 0, EY_PRODUCTS_EXACT = 1 };
@@ -75,7 +77,7 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
 int ey_plan_destroy(ey_plan* plan);
 /* Model.num_params (eeyore/models/model.py:34-36) */
 int ey_plan_num_params(const ey_plan* plan, int64_t* P);
-/* name of the kernel family that serves ey_hmc_step for this plan: "mfma32" (fused f32 trajectory, 4-32-32-3), "fused16"
+/* name of the kernel family that serves ey_hmc_step for this plan: "mfma32" (fused f32 trajectory, 4-32-32-dK), "fused16"
  * (fused 16x16x4 trajectory, f32 and f64), "bgemm" (layerwise batched GEMMs for models beyond LDS, f32 and f64) or
  * "generic" */
 const char* ey_plan_kernel(const ey_plan* plan);

@@ -18,7 +18,11 @@ CASES = [
     ([4, 16, 16, 3], [1, 1, 0], 1, "f32", 150),
     ([4, 16, 16, 3], [1, 1, 0], 1, "f64", 77),
     ([4, 32, 32, 3], [1, 1, 0], 1, "f64", 150),   # the headline model in the reference's default dtype
-    ([4, 32, 32, 3], [2, 2, 0], 1, "f32", 150),   # tanh: not the shape ey_mfma32.hip serves
+    ([4, 32, 32, 3], [2, 2, 0], 1, "f32", 150),   # tanh: served by ey_mfma32.hip too (bf16x3 form), see _expand
+    ([4, 32, 32, 3], [3, 3, 0], 1, "f32", 77),    # relu, likewise
+    ([4, 32, 32, 1], [1, 1, 1], 0, "f32", 150),   # the BCE head on 4-32-32, likewise
+    ([4, 32, 32, 1], [2, 2, 1], 0, "f32", 45),
+    ([4, 32, 32, 1], [3, 3, 1], 0, "f32", 90),
     ([8, 64, 64, 4], [2, 1, 0], 1, "f32", 33),    # widest: d0 = 8 (two k-steps), dK = 4, three waves per CU
     ([2, 16, 16, 1], [1, 1, 1], 0, "f64", 4),     # BCE-sum on a sigmoid output, as the reference's own tests
     ([5, 32, 32, 2], [3, 2, 1], 0, "f64", 49),    # relu, tanh, two BCE outputs
@@ -67,11 +71,29 @@ def _random_cases(n, seed=2024):
 CASES += _random_cases(int(os.environ.get("EY_FUZZ_SEEDS", "10")))
 
 
+def _mfma32_too(dims, acts, lik, tag):
+    """The 4-32-32 models with one hidden activation that the fused f32 trajectory kernel also serves, in its bf16x3 form
+    (ey_mfma32_kind == 2): such a plan runs on it by default and on these kernels with EY_PRODUCTS_EXACT."""
+    if tag != "f32" or dims[:3] != [4, 32, 32] or len(dims) != 4 or acts[0] != acts[1]:
+        return False
+    return (lik == 1 and dims[3] == 3 and acts[2] == 0 and acts[0] in (2, 3)) or (lik == 0 and dims[3] == 1 and acts[2] == 1)
+
+
+def _expand(cases):
+    out = []
+    for case in cases:
+        if _mfma32_too(*case[:4]):
+            out += [case + ("exact", "fused16"), case + ("bf16x3", "mfma32")]
+        else:
+            out.append(case + (None, "fused16"))
+    return out
+
+
 def _t(a, dt):
     return torch.tensor(np.asarray(a), dtype=dt, device=DEV).contiguous()
 
 
-def _setup(dims, acts, lik, tag, N, seed=0):
+def _setup(dims, acts, lik, tag, N, seed=0, products=None):
     from eeyore_amd.plan import Plan
     npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
     rng = np.random.default_rng(sum(dims) + N + seed)
@@ -80,17 +102,19 @@ def _setup(dims, acts, lik, tag, N, seed=0):
     P = sum((dims[l] + 1) * dims[l + 1] for l in range(len(dims) - 1))
     mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
     pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV)
+    if products is not None:
+        pl.f32_products = products
     pl.set_data(_t(x, dt), _t(y, dt))
     pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
     co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, nthreads=4)
     return pl, co, rng, npdt, dt, P
 
 
-@pytest.mark.parametrize("dims,acts,lik,tag,N", CASES)
-def test_fused16_value_gradient_and_draws_vs_oracle(dims, acts, lik, tag, N):
+@pytest.mark.parametrize("dims,acts,lik,tag,N,products,kernel", _expand(CASES))
+def test_fused16_value_gradient_and_draws_vs_oracle(dims, acts, lik, tag, N, products, kernel):
     from eeyore_amd import _lib as L
-    pl, co, rng, npdt, dt, P = _setup(dims, acts, lik, tag, N)
-    assert pl.kernel == "fused16" and pl.P == P
+    pl, co, rng, npdt, dt, P = _setup(dims, acts, lik, tag, N, products=products)
+    assert pl.kernel == kernel and pl.P == P
     C = 11
     scale = 0.3 if lik == 1 else 0.15
     th0 = (scale * rng.standard_normal((C, P))).astype(npdt)
