@@ -19,6 +19,7 @@ EY_RECOMPUTE_INITIAL_GRAD, EY_FORCE_GENERIC = 1, 2
 # every symbol include/eeyore_amd.h declares: (name, restype, argtypes)
 _vp, _i, _i64, _u64, _u32, _d = ct.c_void_p, ct.c_int, ct.c_int64, ct.c_uint64, ct.c_uint32, ct.c_double
 EY_OPT_F32_PRODUCTS, EY_PRODUCTS_BF16X3, EY_PRODUCTS_EXACT = 1, 0, 1
+EY_OPT_ROW_WAVES, EY_ROW_WAVES_OFF, EY_ROW_WAVES_ON, EY_ROW_WAVES_AUTO = 2, 0, 1, 2
 
 SYMBOLS = {
     "ey_version": (_i, []),

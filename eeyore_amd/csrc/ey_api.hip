@@ -97,6 +97,10 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
   pl->n_cu = prop.multiProcessorCount;
   pl->variant = g_ey_default_variant.load() & 1023;
   pl->products = (g_ey_default_variant.load() & 1024) ? EY_PRODUCTS_EXACT : ey_default_products();
+  {
+    const char* e = getenv("EY_ROW_WAVES");
+    pl->row_waves = (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ? e[0] - '0' : EY_ROW_WAVES_AUTO;
+  }
   pl->mfma32_kind = ey_mfma32_kind(pl);
   pl->mfma32_ok = pl->mfma32_kind != 0;
   pl->fused16_ok = ey_fused16_supports(pl);  // also the headline model's second choice (batches beyond mfma32's row limit)
@@ -144,11 +148,18 @@ extern "C" int ey_plan_set_option(ey_plan* pl, int option, int value) {
     pl->products = value;
     return EY_OK;
   }
+  if (option == EY_OPT_ROW_WAVES) {
+    if (value < EY_ROW_WAVES_OFF || value > EY_ROW_WAVES_AUTO)
+      EY_FAIL(EY_ERR_INVALID, "ey_plan_set_option: EY_OPT_ROW_WAVES takes EY_ROW_WAVES_OFF, _ON or _AUTO");
+    pl->row_waves = value;
+    return EY_OK;
+  }
   EY_FAIL(EY_ERR_INVALID, "ey_plan_set_option: unknown option");
 }
 extern "C" int ey_plan_get_option(const ey_plan* pl, int option, int* value) {
   if (!pl || !value) EY_FAIL(EY_ERR_INVALID, "ey_plan_get_option: null argument");
   if (option == EY_OPT_F32_PRODUCTS) { *value = pl->products; return EY_OK; }
+  if (option == EY_OPT_ROW_WAVES) { *value = pl->row_waves; return EY_OK; }
   EY_FAIL(EY_ERR_INVALID, "ey_plan_get_option: unknown option");
 }
 // the fused MFMA kernel serves this plan with the batch it currently holds

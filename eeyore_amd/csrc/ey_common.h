@@ -81,6 +81,7 @@ struct ey_plan {
   int n_cu;
   int variant = 0;   // diagnostic switches (ey_plan_set_variant; bits as documented in include/eeyore_amd.h)
   int products = 0;  // EY_OPT_F32_PRODUCTS: EY_PRODUCTS_BF16X3 (0) or EY_PRODUCTS_EXACT (1)
+  int row_waves = 2; // EY_OPT_ROW_WAVES: EY_ROW_WAVES_OFF (0), _ON (1), _AUTO (2)
   // layerwise batched-GEMM path for models whose parameters do not fit LDS (ey_large.hip): workspace it owns
   void* d_work;
   size_t work_bytes;

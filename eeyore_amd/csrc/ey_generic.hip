@@ -89,9 +89,49 @@ __device__ inline Lds<T> carve(const EyModel& m, unsigned char* smem, int nvec) 
   return l;
 }
 
-static size_t lds_bytes(const EyModel& m, int nvec, size_t esz) {
+__host__ __device__ static size_t lds_bytes(const EyModel& m, int nvec, size_t esz) {
   const size_t Ppad = (m.P + 3) & ~3;
   return esz * (nvec * Ppad + (size_t)m.hrows * TS + 2 * (size_t)m.dmax * TS);
+}
+
+// ROW WAVES.  A workgroup is one chain.  With the register-resident evaluation (tiny models) and a batch of several 64-row
+// tiles, the tiles of one evaluation are independent until the gradient is summed: the workgroup then has up to four
+// waves, every wave runs the WHOLE kernel on its own LDS copy of the chain's state (same inputs, same instructions: the
+// same bits in every wave -- random draws, proposals, accept decisions), but takes only every NW-th row tile inside an
+// evaluation; the waves' partial gradients and log-likelihoods meet in LDS and every wave adds them in the order wave 0,
+// 1, 2, 3, so all waves continue with identical totals.  Only wave 0 writes to global memory; the workgroup barriers the
+// kernels already have order those writes before the other waves' next reads (one CU, one vector cache).  The number of
+// waves is a plan option (EY_OPT_ROW_WAVES): the order in which a gradient is summed differs between one wave and several, so
+// a caller who needs a chain's bits to be independent of how many chains share its launch pins it on or off.
+#define RW_MAX 4
+struct RowWaves {
+  int wave, nw;
+  void* part;  // exchange buffer [P + 1][nw][64 lanes] of per-lane partial sums, then [P + 4] totals
+};
+template <typename T>
+__device__ inline RowWaves row_waves(const EyModel& m, unsigned char* smem, int nvec) {
+  RowWaves rw;
+  rw.wave = threadIdx.x >> 6;
+  rw.nw = blockDim.x >> 6;
+  rw.part = smem + (size_t)rw.nw * lds_bytes(m, nvec, sizeof(T));
+  return rw;
+}
+static size_t row_waves_exchange(const EyModel& m, size_t esz, int nw) {
+  return nw > 1 ? esz * ((size_t)(m.P + 1) * nw * WAVE + m.P + 4) : 0;
+}
+// EY_OPT_ROW_WAVES: off, on (whenever the batch has two row tiles or more), or auto = on while one wave per chain would
+// leave SIMDs idle (C <= 4 x CUs: at 256 chains MALA on MLP(2-3-2-1), N = 256, takes 5.4 us per draw instead of 7.7; with
+// the chip full of chains the waves' repeated scalar work costs 3 x in throughput, so there it stays off).
+static int row_waves_for(const ey_plan* pl, bool tiny, int64_t C) {
+  if (!tiny || pl->m.N < 2 * WAVE || pl->row_waves == EY_ROW_WAVES_OFF) return 1;
+  if (pl->row_waves == EY_ROW_WAVES_AUTO && C > 4 * (int64_t)(pl->n_cu > 0 ? pl->n_cu : 256)) return 1;
+  int nw = std::min(RW_MAX, (pl->m.N + WAVE - 1) / WAVE);
+  const size_t esz = pl->dtype == EY_F32 ? 4 : 8;
+  while (nw > 1 && row_waves_exchange(pl->m, esz, nw) > 32768) --nw;  // several chains per CU must still fit
+  return nw;
+}
+static size_t lds_total(const EyModel& m, int nvec, size_t esz, int nw) {
+  return nw * lds_bytes(m, nvec, esz) + row_waves_exchange(m, esz, nw);
 }
 
 // ------------------------------------------------------------------ register-resident evaluation of tiny models
@@ -173,8 +213,9 @@ __device__ __forceinline__ void tiny_act(int code, T (&h)[TINY_DH], int n) {
 // The row loop of eval_target for a tiny model: the sum of the rows' log-likelihood terms (per lane: the caller adds
 // the lanes) and, when GRAD, the gradient of the log-likelihood in gr (LDS, canonical layout).
 template <typename T, bool GRAD, class S>
-__device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, bool has_temp, T temp, T* row_out) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, bool has_temp, T temp, T* row_out,
+                                       const RowWaves& rw) {
+  const int lane = threadIdx.x & (WAVE - 1);
   const T* x = static_cast<const T*>(m.x);
   const T* y = static_cast<const T*>(m.y);
   const int nl = S::nl(m), dK = S::dim(m, nl), d0 = S::dim(m, 0);
@@ -197,7 +238,7 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
     }
   }
   T lik = T(0);
-  for (int n0 = 0; n0 < m.N; n0 += WAVE) {
+  for (int n0 = rw.wave * WAVE; n0 < m.N; n0 += rw.nw * WAVE) {
     const int n = n0 + lane;
     const bool valid = n < m.N;
     T h0[TINY_D0], h[3][TINY_DH];  // h[k] = output of layer k
@@ -304,6 +345,43 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
       }
     }
   }
+  if (rw.nw > 1) {
+    // ---- ROW WAVES: every wave leaves its per-lane partial sums in the exchange buffer; the parameters (and the
+    // log-likelihood, as entry P) are then shared out over the waves, each adding the waves' partials lane by lane in the
+    // order wave 0, 1, ... and reducing over the lanes as below; every wave copies the totals into its own gradient.
+    T* ex = static_cast<T*>(rw.part);
+    T* totals = ex + (size_t)(m.P + 1) * rw.nw * WAVE;
+    auto slot = [&](int idx) { return ex + ((size_t)idx * rw.nw + rw.wave) * WAVE + lane; };
+    if (GRAD) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k < nl) {
+          const int din = S::dim(m, k), dout = S::dim(m, k + 1);
+#pragma unroll
+          for (int j = 0; j < TINY_DH; ++j)
+            if (j < dout) {
+#pragma unroll
+              for (int i = 0; i < (k == 0 ? TINY_D0 : TINY_DH); ++i)
+                if (i < din) *slot(m.woff[k] + j * din + i) = G[k][j][i];
+              if (m.boff[k] >= 0) *slot(m.boff[k] + j) = GB[k][j];
+            }
+        }
+      }
+    }
+    *slot(m.P) = lik;
+    __syncthreads();
+    for (int idx = (GRAD ? rw.wave : m.P + rw.wave); idx <= m.P; idx += rw.nw) {
+      const T* src = ex + (size_t)idx * rw.nw * WAVE + lane;
+      T v = src[0];
+      for (int w = 1; w < rw.nw; ++w) v += src[w * WAVE];
+      const T tot = tiny_wsum<T>(v);
+      if (lane == 0) totals[idx] = tot;
+    }
+    __syncthreads();
+    if (GRAD)
+      for (int i = lane; i < m.P; i += WAVE) gr[i] = totals[i];
+    return lane == 0 ? totals[m.P] : T(0);  // the caller's wave_sum hands it to every lane
+  }
   if (GRAD) {
     // ---- the lanes' partial gradients, summed in a fixed order, into the canonical layout
 #pragma unroll
@@ -335,7 +413,7 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
 // the chain's N(0,1) stream for elements 0..P-1 into an LDS array, one block of four per lane and round
 template <typename T>
 __device__ inline void fill_normals(T* dst, const EyRng& rn, int P) {
-  for (int b = threadIdx.x; 4 * b < P; b += WAVE) {
+  for (int b = threadIdx.x & (WAVE - 1); 4 * b < P; b += WAVE) {
     T o[4];
     ey_rng_normal4<T>(rn, (uint32_t)b, o);
 #pragma unroll
@@ -347,8 +425,8 @@ __device__ inline void fill_normals(T* dst, const EyRng& rn, int P) {
 
 template <typename T, bool GRAD, class TINY = TinyOff>
 __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, bool has_temp, T temp, T* lik_out,
-                         T* prior_out, T* row_out = nullptr) {
-  const int lane = threadIdx.x;
+                         T* prior_out, T* row_out = nullptr, const RowWaves rw = RowWaves{0, 1, nullptr}) {
+  const int lane = threadIdx.x & (WAVE - 1);
   const T* x = static_cast<const T*>(m.x);
   const T* y = static_cast<const T*>(m.y);
   const int nl = m.nl;
@@ -356,7 +434,7 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
   T lik = T(0);
   if constexpr (TINY::on) {
     __syncthreads();  // the position written by the caller is visible
-    lik = tiny_rows<T, GRAD, TINY>(m, th, gr, has_temp, temp, row_out);
+    lik = tiny_rows<T, GRAD, TINY>(m, th, gr, has_temp, temp, row_out, rw);
   } else {
   if (GRAD) {
     for (int i = lane; i < m.P; i += WAVE) gr[i] = T(0);
@@ -513,39 +591,43 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
 }
 
 // ----------------------------------------------------------------------------------------------- kernels
-template <typename T, bool GRAD, class TINY>
-__global__ void __launch_bounds__(WAVE) k_log_target(EyModel m, const T* theta, const T* temp, T* lik_o, T* prior_o,
+template <typename T, bool GRAD, class TINY, bool RW = false>
+__global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_log_target(EyModel m, const T* theta, const T* temp, T* lik_o, T* prior_o,
                                                      T* target_o, T* grad_o, T* rows_o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds<T> l = carve<T>(m, smem, 2);
+  const RowWaves rw = RW ? row_waves<T>(m, smem, 2) : RowWaves{0, 1, nullptr};  // RW false: one wave, all of this folds away
+  const Lds<T> l = carve<T>(m, smem + (RW ? (size_t)rw.wave * lds_bytes(m, 2, sizeof(T)) : 0), 2);
+  const bool w0 = rw.wave == 0;  // the wave that writes to global memory (ROW WAVES)
   const int64_t c = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
   for (int i = lane; i < m.P; i += WAVE) l.th[i] = theta[c * m.P + i];
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
   T lik, prior;
-  const T t = eval_target<T, GRAD, TINY>(m, l, l.th, l.gr, ht, tc, &lik, &prior, rows_o ? rows_o + c * m.N : nullptr);
-  if (lane == 0) {
+  const T t = eval_target<T, GRAD, TINY>(m, l, l.th, l.gr, ht, tc, &lik, &prior, rows_o ? rows_o + c * m.N : nullptr, rw);
+  if (lane == 0 && w0) {
     if (lik_o) lik_o[c] = lik;
     if (prior_o) prior_o[c] = prior;
     if (target_o) target_o[c] = t;
   }
-  if (GRAD) {
+  if (GRAD && w0) {
     for (int i = lane; i < m.P; i += WAVE) grad_o[c * m.P + i] = l.gr[i];
   }
 }
 
-template <typename T, class TINY>
-__global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T* grad, const T* p0, const T* u_in,
+template <typename T, class TINY, bool RW = false>
+__global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_hmc(EyModel m, T* theta, T* target, T* grad, const T* p0, const T* u_in,
                                               T step, const T* step_vec, int L, const T* temp, uint64_t seed,
                                               uint64_t iter0, uint64_t chain_offset, int recompute,
                                               unsigned char* accepted, T* rate_o, T* hcur_o, T* hprop_o, int n_iters,
                                               T* rec_samples, T* rec_targets, unsigned char* rec_accepted,
                                               int* accept_count, int64_t C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds<T> l = carve<T>(m, smem, 3);
+  const RowWaves rw = RW ? row_waves<T>(m, smem, 3) : RowWaves{0, 1, nullptr};  // RW false: one wave, all of this folds away
+  const Lds<T> l = carve<T>(m, smem + (RW ? (size_t)rw.wave * lds_bytes(m, 3, sizeof(T)) : 0), 3);
+  const bool w0 = rw.wave == 0;  // the wave that writes to global memory (ROW WAVES)
   const int64_t c = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = RW ? (threadIdx.x & (WAVE - 1)) : threadIdx.x;
   const int P = m.P;
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
@@ -572,12 +654,12 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
   const T h_cur = -t_cur + T(0.5) * kin;  // hmc.py:91-98,137
   __syncthreads();
   T t = t_cur;
-  if (recompute) t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);  // hmc.py:104
+  if (recompute) t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr, nullptr, rw);  // hmc.py:104
   // leapfrog (hmc.py:100-124); grad_potential = -grad
   for (int i = lane; i < P; i += WAVE) p[i] = p[i] + T(0.5) * eps * l.gr[i];
   for (int k = 1; k <= L; ++k) {
     for (int i = lane; i < P; i += WAVE) l.th[i] = l.th[i] + eps * p[i];
-    t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+    t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr, nullptr, rw);
     const T w = (k < L) ? eps : T(0.5) * eps;
     for (int i = lane; i < P; i += WAVE) p[i] = p[i] + w * l.gr[i];
   }
@@ -590,18 +672,18 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
   const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
   const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
   const bool acc = u < rate;  // strict <; NaN rate => reject (hmc.py:148)
-  if (acc) {
+  if (acc && w0) {
     for (int i = lane; i < P; i += WAVE) {
       theta[c * P + i] = l.th[i];
       grad[c * P + i] = l.gr[i];
     }
   }
   if (acc) t_state = t;
-  if (rec_samples) {  // the state the chain is left in (what ChainList.update stores, chain_list.py:64-67)
+  if (rec_samples && w0) {  // the state the chain is left in (what ChainList.update stores, chain_list.py:64-67)
     T* so = rec_samples + ((int64_t)it * C + c) * P;
     for (int i = lane; i < P; i += WAVE) so[i] = acc ? l.th[i] : theta[c * P + i];
   }
-  if (lane == 0) {
+  if (lane == 0 && w0) {
     if (acc) target[c] = t;
     accepted[c] = acc ? 1 : 0;
     if (rate_o) rate_o[c] = rate;
@@ -616,13 +698,15 @@ __global__ void __launch_bounds__(WAVE) k_hmc(EyModel m, T* theta, T* target, T*
 }
 
 // HMC.leapfrog as a standalone operator (hmc.py:100-124): L+1 evaluations, momentum negated.
-template <typename T, class TINY>
-__global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, T step, const T* step_vec, int L,
+template <typename T, class TINY, bool RW = false>
+__global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_leapfrog(EyModel m, T* theta, T* pio, T step, const T* step_vec, int L,
                                                    const T* temp, T* target, T* grad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds<T> l = carve<T>(m, smem, 3);
+  const RowWaves rw = RW ? row_waves<T>(m, smem, 3) : RowWaves{0, 1, nullptr};  // RW false: one wave, all of this folds away
+  const Lds<T> l = carve<T>(m, smem + (RW ? (size_t)rw.wave * lds_bytes(m, 3, sizeof(T)) : 0), 3);
+  const bool w0 = rw.wave == 0;  // the wave that writes to global memory (ROW WAVES)
   const int64_t c = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = RW ? (threadIdx.x & (WAVE - 1)) : threadIdx.x;
   const int P = m.P;
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
@@ -633,31 +717,35 @@ __global__ void __launch_bounds__(WAVE) k_leapfrog(EyModel m, T* theta, T* pio, 
     p[i] = pio[c * P + i];
   }
   __syncthreads();
-  T t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+  T t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr, nullptr, rw);
   for (int i = lane; i < P; i += WAVE) p[i] = p[i] + T(0.5) * eps * l.gr[i];
   for (int k = 1; k <= L; ++k) {
     for (int i = lane; i < P; i += WAVE) l.th[i] = l.th[i] + eps * p[i];
-    t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+    t = eval_target<T, true, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr, nullptr, rw);
     const T w = (k < L) ? eps : T(0.5) * eps;
     for (int i = lane; i < P; i += WAVE) p[i] = p[i] + w * l.gr[i];
   }
-  for (int i = lane; i < P; i += WAVE) {
-    theta[c * P + i] = l.th[i];
-    pio[c * P + i] = -p[i];
-    grad[c * P + i] = l.gr[i];
+  if (w0) {
+    for (int i = lane; i < P; i += WAVE) {
+      theta[c * P + i] = l.th[i];
+      pio[c * P + i] = -p[i];
+      grad[c * P + i] = l.gr[i];
+    }
+    if (lane == 0) target[c] = t;
   }
-  if (lane == 0) target[c] = t;
 }
 
-template <typename T, class TINY>
-__global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T* grad, const T* z_in, const T* u_in,
+template <typename T, class TINY, bool RW = false>
+__global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_mala(EyModel m, T* theta, T* target, T* grad, const T* z_in, const T* u_in,
                                                T step, T sqrt_step, const T* step_vec, const T* temp, uint64_t seed,
                                                uint64_t iter0, uint64_t chain_offset, unsigned char* accepted,
                                                T* log_rate_o, EyRun run, int64_t C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds<T> l = carve<T>(m, smem, 4);
+  const RowWaves rw = RW ? row_waves<T>(m, smem, 4) : RowWaves{0, 1, nullptr};  // RW false: one wave, all of this folds away
+  const Lds<T> l = carve<T>(m, smem + (RW ? (size_t)rw.wave * lds_bytes(m, 4, sizeof(T)) : 0), 4);
+  const bool w0 = rw.wave == 0;  // the wave that writes to global memory (ROW WAVES)
   const int64_t c = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = RW ? (threadIdx.x & (WAVE - 1)) : threadIdx.x;
   const int P = m.P;
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
@@ -686,7 +774,7 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
     qf += d * d;
   }
   __syncthreads();
-  const T tv = eval_target<T, true, TINY>(m, l, prop, gp, ht, tc, nullptr, nullptr);
+  const T tv = eval_target<T, true, TINY>(m, l, prop, gp, ht, tc, nullptr, nullptr, nullptr, rw);
   T qb = T(0);
   for (int i = lane; i < P; i += WAVE) {
     const T loc2 = prop[i] + T(0.5) * eps * gp[i];
@@ -702,16 +790,17 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
   const bool acc = Num<T>::log(u) < log_rate;  // mala.py:66
   if (acc) {
     t_state = tv;
-    for (int i = lane; i < P; i += WAVE) {
-      theta[c * P + i] = prop[i];
-      grad[c * P + i] = gp[i];
-    }
+    if (w0)
+      for (int i = lane; i < P; i += WAVE) {
+        theta[c * P + i] = prop[i];
+        grad[c * P + i] = gp[i];
+      }
   }
-  if (run.samples) {  // the state the chain is left in (what ChainList.update stores, chain_list.py:64-67)
+  if (run.samples && w0) {  // the state the chain is left in (what ChainList.update stores, chain_list.py:64-67)
     T* so = static_cast<T*>(run.samples) + ((int64_t)it * C + c) * P;
     for (int i = lane; i < P; i += WAVE) so[i] = acc ? prop[i] : l.th[i];
   }
-  if (lane == 0) {
+  if (lane == 0 && w0) {
     if (acc) target[c] = tv;
     accepted[c] = acc ? 1 : 0;
     if (log_rate_o) log_rate_o[c] = log_rate;
@@ -723,15 +812,17 @@ __global__ void __launch_bounds__(WAVE) k_mala(EyModel m, T* theta, T* target, T
   }
 }
 
-template <typename T, class TINY>
-__global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, const T* z_in, const T* u_in,
+template <typename T, class TINY, bool RW = false>
+__global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_mh(EyModel m, T* theta, T* target, const T* z_in, const T* u_in,
                                              const T* scale, const T* temp, uint64_t seed, uint64_t iter0,
                                              uint64_t chain_offset, unsigned char* accepted, T* log_rate_o, EyRun run,
                                              int64_t C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds<T> l = carve<T>(m, smem, 2);
+  const RowWaves rw = RW ? row_waves<T>(m, smem, 2) : RowWaves{0, 1, nullptr};  // RW false: one wave, all of this folds away
+  const Lds<T> l = carve<T>(m, smem + (RW ? (size_t)rw.wave * lds_bytes(m, 2, sizeof(T)) : 0), 2);
+  const bool w0 = rw.wave == 0;  // the wave that writes to global memory (ROW WAVES)
   const int64_t c = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = RW ? (threadIdx.x & (WAVE - 1)) : threadIdx.x;
   const int P = m.P;
   const bool ht = temp != nullptr;
   const T tc = ht ? temp[c] : T(1);
@@ -745,20 +836,21 @@ __global__ void __launch_bounds__(WAVE) k_mh(EyModel m, T* theta, T* target, con
     l.th[i] = theta[c * P + i] + scale[i] * zi;  // NormalKernel(theta, scale).sample()
   }
   __syncthreads();
-  const T tv = eval_target<T, false, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr);
+  const T tv = eval_target<T, false, TINY>(m, l, l.th, l.gr, ht, tc, nullptr, nullptr, nullptr, rw);
   const T log_rate = tv - t_state;  // symmetric kernel (metropolis_hastings.py:50)
   const EyRng ru = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_UNIFORM);
   const T u = u_in ? u_in[c] : ey_rng_uniform<T>(ru);
   const bool acc = Num<T>::log(u) < log_rate;  // :56
   if (acc) {
     t_state = tv;
-    for (int i = lane; i < P; i += WAVE) theta[c * P + i] = l.th[i];
+    if (w0)
+      for (int i = lane; i < P; i += WAVE) theta[c * P + i] = l.th[i];
   }
-  if (run.samples) {
+  if (run.samples && w0) {
     T* so = static_cast<T*>(run.samples) + ((int64_t)it * C + c) * P;
     for (int i = lane; i < P; i += WAVE) so[i] = acc ? l.th[i] : theta[c * P + i];
   }
-  if (lane == 0) {
+  if (lane == 0 && w0) {
     if (acc) target[c] = tv;
     accepted[c] = acc ? 1 : 0;
     if (log_rate_o) log_rate_o[c] = log_rate;
@@ -824,22 +916,35 @@ static int prep(K kernel, size_t bytes) {
   return EY_OK;
 }
 
+// the kernels' row-waves instantiation (RW) where the launch uses several waves per chain, the lean one otherwise
+template <class TINY, typename F>
+static int with_row_waves(int nw, F f) {
+  if constexpr (TINY::on) {
+    if (nw > 1) return f(std::true_type{});
+  }
+  return f(std::false_type{});
+}
+
 template <typename T, class TINY>
 static int launch_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                              void* target, void* grad, hipStream_t s, void* rows = nullptr) {
-  const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
-  int rc;
-  if (grad) {
-    if ((rc = prep(k_log_target<T, true, TINY>, bytes))) return rc;
-    hipLaunchKernelGGL((k_log_target<T, true, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
-                       (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)grad, (T*)nullptr);
-  } else {
-    if ((rc = prep(k_log_target<T, false, TINY>, bytes))) return rc;
-    hipLaunchKernelGGL((k_log_target<T, false, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (const T*)theta,
-                       (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)nullptr, (T*)rows);
-  }
-  EY_HIP(hipGetLastError());
-  return EY_OK;
+  const int nw = row_waves_for(pl, TINY::on, C);
+  const size_t bytes = lds_total(pl->m, 2, sizeof(T), nw);
+  return with_row_waves<TINY>(nw, [&](auto rwtag) -> int {
+    constexpr bool RW = decltype(rwtag)::value;
+    int rc;
+    if (grad) {
+      if ((rc = prep(k_log_target<T, true, TINY, RW>, bytes))) return rc;
+      hipLaunchKernelGGL((k_log_target<T, true, TINY, RW>), dim3((unsigned)C), dim3(nw * WAVE), bytes, s, pl->m,
+                         (const T*)theta, (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)grad, (T*)nullptr);
+    } else {
+      if ((rc = prep(k_log_target<T, false, TINY, RW>, bytes))) return rc;
+      hipLaunchKernelGGL((k_log_target<T, false, TINY, RW>), dim3((unsigned)C), dim3(nw * WAVE), bytes, s, pl->m,
+                         (const T*)theta, (const T*)temp, (T*)lik, (T*)prior, (T*)target, (T*)nullptr, (T*)rows);
+    }
+    EY_HIP(hipGetLastError());
+    return (int)EY_OK;
+  });
 }
 
 int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
@@ -856,17 +961,21 @@ static int launch_hmc(ey_plan* pl, void* theta, void* target, void* grad, const 
                       const void* step_vec, int L, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                       uint64_t chain_offset, uint32_t flags, void* accepted, void* rate, void* hcur, void* hprop,
                       hipStream_t s, const EyRun* run) {
-  const size_t bytes = lds_bytes(pl->m, 3, sizeof(T));
-  int rc;
-  if ((rc = prep(k_hmc<T, TINY>, bytes))) return rc;
-  hipLaunchKernelGGL((k_hmc<T, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
-                     (const T*)p0, (const T*)u, (T)step, (const T*)step_vec, L, (const T*)temp, seed, iter,
-                     chain_offset, (int)((flags & EY_RECOMPUTE_INITIAL_GRAD) != 0), (unsigned char*)accepted, (T*)rate,
-                     (T*)hcur, (T*)hprop, run ? run->n_iters : 1, run ? (T*)run->samples : nullptr,
-                     run ? (T*)run->targets : nullptr, run ? (unsigned char*)run->accepted : nullptr,
-                     run ? run->accept_count : nullptr, C);
-  EY_HIP(hipGetLastError());
-  return EY_OK;
+  const int nw = row_waves_for(pl, TINY::on, C);
+  const size_t bytes = lds_total(pl->m, 3, sizeof(T), nw);
+  return with_row_waves<TINY>(nw, [&](auto rwtag) -> int {
+    constexpr bool RW = decltype(rwtag)::value;
+    int rc;
+    if ((rc = prep(k_hmc<T, TINY, RW>, bytes))) return rc;
+    hipLaunchKernelGGL((k_hmc<T, TINY, RW>), dim3((unsigned)C), dim3(nw * WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
+                       (const T*)p0, (const T*)u, (T)step, (const T*)step_vec, L, (const T*)temp, seed, iter,
+                       chain_offset, (int)((flags & EY_RECOMPUTE_INITIAL_GRAD) != 0), (unsigned char*)accepted, (T*)rate,
+                       (T*)hcur, (T*)hprop, run ? run->n_iters : 1, run ? (T*)run->samples : nullptr,
+                       run ? (T*)run->targets : nullptr, run ? (unsigned char*)run->accepted : nullptr,
+                       run ? run->accept_count : nullptr, C);
+    EY_HIP(hipGetLastError());
+    return (int)EY_OK;
+  });
 }
 
 int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void* p0, const void* u, double step,
@@ -880,13 +989,17 @@ int ey_generic_hmc(ey_plan* pl, void* theta, void* target, void* grad, const voi
 template <typename T, class TINY>
 static int launch_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
                            int64_t C, void* target, void* grad, hipStream_t s) {
-  const size_t bytes = lds_bytes(pl->m, 3, sizeof(T));
-  int rc;
-  if ((rc = prep(k_leapfrog<T, TINY>, bytes))) return rc;
-  hipLaunchKernelGGL((k_leapfrog<T, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)p, (T)step,
-                     (const T*)step_vec, L, (const T*)temp, (T*)target, (T*)grad);
-  EY_HIP(hipGetLastError());
-  return EY_OK;
+  const int nw = row_waves_for(pl, TINY::on, C);
+  const size_t bytes = lds_total(pl->m, 3, sizeof(T), nw);
+  return with_row_waves<TINY>(nw, [&](auto rwtag) -> int {
+    constexpr bool RW = decltype(rwtag)::value;
+    int rc;
+    if ((rc = prep(k_leapfrog<T, TINY, RW>, bytes))) return rc;
+    hipLaunchKernelGGL((k_leapfrog<T, TINY, RW>), dim3((unsigned)C), dim3(nw * WAVE), bytes, s, pl->m, (T*)theta, (T*)p, (T)step,
+                       (const T*)step_vec, L, (const T*)temp, (T*)target, (T*)grad);
+    EY_HIP(hipGetLastError());
+    return (int)EY_OK;
+  });
 }
 
 int ey_generic_leapfrog(ey_plan* pl, void* theta, void* p, double step, const void* step_vec, int L, const void* temp,
@@ -899,15 +1012,19 @@ static int launch_mala(ey_plan* pl, void* theta, void* target, void* grad, const
                        const void* step_vec, const void* temp, int64_t C, uint64_t seed, uint64_t iter,
                        uint64_t chain_offset, void* accepted, void* log_rate, hipStream_t s, const EyRun* run) {
   const EyRun one = {1, nullptr, nullptr, nullptr, nullptr};
-  const size_t bytes = lds_bytes(pl->m, 4, sizeof(T));
-  int rc;
-  if ((rc = prep(k_mala<T, TINY>, bytes))) return rc;
-  // scale = np.sqrt(step) on the python float, then cast to the model dtype (mala.py:39)
-  hipLaunchKernelGGL((k_mala<T, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
-                     (const T*)z, (const T*)u, (T)step, (T)sqrt(step), (const T*)step_vec, (const T*)temp, seed, iter,
-                     chain_offset, (unsigned char*)accepted, (T*)log_rate, run ? *run : one, C);
-  EY_HIP(hipGetLastError());
-  return EY_OK;
+  const int nw = row_waves_for(pl, TINY::on, C);
+  const size_t bytes = lds_total(pl->m, 4, sizeof(T), nw);
+  return with_row_waves<TINY>(nw, [&](auto rwtag) -> int {
+    constexpr bool RW = decltype(rwtag)::value;
+    int rc;
+    if ((rc = prep(k_mala<T, TINY, RW>, bytes))) return rc;
+    // scale = np.sqrt(step) on the python float, then cast to the model dtype (mala.py:39)
+    hipLaunchKernelGGL((k_mala<T, TINY, RW>), dim3((unsigned)C), dim3(nw * WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (T*)grad,
+                       (const T*)z, (const T*)u, (T)step, (T)sqrt(step), (const T*)step_vec, (const T*)temp, seed, iter,
+                       chain_offset, (unsigned char*)accepted, (T*)log_rate, run ? *run : one, C);
+    EY_HIP(hipGetLastError());
+    return (int)EY_OK;
+  });
 }
 
 int ey_generic_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
@@ -922,14 +1039,18 @@ static int launch_mh(ey_plan* pl, void* theta, void* target, const void* z, cons
                      const void* temp, int64_t C, uint64_t seed, uint64_t iter, uint64_t chain_offset, void* accepted,
                      void* log_rate, hipStream_t s, const EyRun* run) {
   const EyRun one = {1, nullptr, nullptr, nullptr, nullptr};
-  const size_t bytes = lds_bytes(pl->m, 2, sizeof(T));
-  int rc;
-  if ((rc = prep(k_mh<T, TINY>, bytes))) return rc;
-  hipLaunchKernelGGL((k_mh<T, TINY>), dim3((unsigned)C), dim3(WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (const T*)z,
-                     (const T*)u, (const T*)scale, (const T*)temp, seed, iter, chain_offset, (unsigned char*)accepted,
-                     (T*)log_rate, run ? *run : one, C);
-  EY_HIP(hipGetLastError());
-  return EY_OK;
+  const int nw = row_waves_for(pl, TINY::on, C);
+  const size_t bytes = lds_total(pl->m, 2, sizeof(T), nw);
+  return with_row_waves<TINY>(nw, [&](auto rwtag) -> int {
+    constexpr bool RW = decltype(rwtag)::value;
+    int rc;
+    if ((rc = prep(k_mh<T, TINY, RW>, bytes))) return rc;
+    hipLaunchKernelGGL((k_mh<T, TINY, RW>), dim3((unsigned)C), dim3(nw * WAVE), bytes, s, pl->m, (T*)theta, (T*)target, (const T*)z,
+                       (const T*)u, (const T*)scale, (const T*)temp, seed, iter, chain_offset, (unsigned char*)accepted,
+                       (T*)log_rate, run ? *run : one, C);
+    EY_HIP(hipGetLastError());
+    return (int)EY_OK;
+  });
 }
 
 int ey_generic_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,

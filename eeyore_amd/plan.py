@@ -70,6 +70,21 @@ class Plan:
                                            L.EY_PRODUCTS_EXACT if mode == "exact" else L.EY_PRODUCTS_BF16X3),
                 "ey_plan_set_option")
 
+    @property
+    def row_waves(self):
+        """'off', 'on' or 'auto': several waves per chain for tiny models on batches of two row tiles or more
+        (EY_OPT_ROW_WAVES in include/eeyore_amd.h: a latency option that changes the order of the gradient sums)."""
+        v = ct.c_int()
+        L.check(L.lib().ey_plan_get_option(self.handle, L.EY_OPT_ROW_WAVES, ct.byref(v)), "ey_plan_get_option")
+        return ("off", "on", "auto")[v.value]
+
+    @row_waves.setter
+    def row_waves(self, mode):
+        if mode not in ("off", "on", "auto"):
+            raise ValueError("row_waves must be 'off', 'on' or 'auto'")
+        L.check(L.lib().ey_plan_set_option(self.handle, L.EY_OPT_ROW_WAVES, ("off", "on", "auto").index(mode)),
+                "ey_plan_set_option")
+
     def set_variant(self, variant):
         """Diagnostic switches of THIS plan (ey_plan_set_variant); returns the previous value."""
         return L.lib().ey_plan_set_variant(self.handle, int(variant))

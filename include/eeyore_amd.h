@@ -58,8 +58,15 @@ enum ey_dtype { EY_F32 = 0, EY_F64 = 1 }; /* model.dtype, eeyore/models/model.py
  *     relu; CE-sum on 3 logits or BCE-sum on one sigmoid output), which otherwise run on "fused16";
  *   EY_PRODUCTS_EXACT: v_mfma_f32_32x32x2_f32 (16x16x4 on "fused16"), bit for bit a k-ordered f32 fma chain.
  * The environment variable EY_F32_PRODUCTS=exact|bf16x3 sets what new plans start with. */
-enum ey_option { EY_OPT_F32_PRODUCTS = 1 };
+enum ey_option { EY_OPT_F32_PRODUCTS = 1, EY_OPT_ROW_WAVES = 2 };
 enum ey_products { EY_PRODUCTS_BF16X3 = 0, EY_PRODUCTS_EXACT = 1 };
+/* EY_OPT_ROW_WAVES: tiny models (at most three layers, eight inputs, other widths <= 4: the reference's own test and example
+ * models) on batches of 128 rows or more may give a chain up to four waves, each taking every fourth 64-row tile of an
+ * evaluation; the waves' partial gradients are added in a fixed order, which is not the order one wave adds them in, so the
+ * two differ in the last bits.  EY_ROW_WAVES_AUTO (default; environment EY_ROW_WAVES=0|1|2) uses them while one wave per
+ * chain would leave the chip idle (chains <= 4 x CUs): BASELINE config 2 (MALA, 256 chains, N = 256) 7.7 -> 5.4 us per draw;
+ * a caller who needs a chain's bits not to depend on how many chains share its launch sets _OFF or _ON. */
+enum ey_row_waves { EY_ROW_WAVES_OFF = 0, EY_ROW_WAVES_ON = 1, EY_ROW_WAVES_AUTO = 2 };
 
 enum ey_flags {
   EY_RECOMPUTE_INITIAL_GRAD = 1, /* HMC: re-evaluate the gradient at the start of the trajectory exactly as

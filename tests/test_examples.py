@@ -32,7 +32,10 @@ def test_bench_contract_small_run():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["vs_baseline"] is None
+    # the arithmetic type is f32; the default form of the kernel's products is named beside it, both forms' rates recorded
+    assert d["dtype"] == "f32 (bf16x3 products, f32 accumulate)" and d["config"]["f32_products"] == "bf16x3"
+    assert set(d["config"]["kernels"]) == {"bf16x3", "exact"} and d["roofline"]["f32_equivalent"] is True
     assert d["config"]["kernel"] == "mfma32" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "TFLOP/s"

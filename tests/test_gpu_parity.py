@@ -1149,6 +1149,73 @@ def test_tiny_models_register_resident_evaluation(dims, acts, bias, lik, tag):
         L.lib().ey_debug_set_variant(0)
 
 
+def test_row_waves_option_tiny_models():
+    """EY_OPT_ROW_WAVES: a tiny model on a batch of several 64-row tiles may give a chain up to four waves (each every fourth
+    tile, partial gradients added in a fixed order).  Both settings against the oracle on every entry point; with the option
+    pinned ('on' / 'off') a chain's bits do not depend on how many chains share its launch; 'auto' is 'on' for few chains
+    and 'off' for many."""
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(3)
+    for dims, acts, lik, N, dt, npdt, tol in (([2, 3, 2, 1], [1, 1, 1], 0, 256, torch.float32, np.float32, 2e-4),
+                                              ([4, 3, 3], [1, 0], 1, 150, torch.float64, np.float64, 1e-10),
+                                              ([3, 4, 2, 2], [2, 3, 0], 1, 333, torch.float64, np.float64, 1e-10)):
+        x = rng.random((N, dims[0]))
+        y = (rng.random((N, dims[-1])) < 0.5).astype(np.float64) if lik == 0 else np.eye(dims[-1])[rng.integers(0, dims[-1], N)]
+        P = sum((dims[l] + 1) * dims[l + 1] for l in range(len(dims) - 1))
+        mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+        pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV)
+        pl.set_data(_t(x, dt), _t(y, dt))
+        pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+        assert pl.row_waves == "auto"
+        with pytest.raises(ValueError):
+            pl.row_waves = "sometimes"
+        co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, nthreads=4)
+        C = 9
+        th0 = (0.3 * rng.standard_normal((C, P))).astype(npdt)
+        p0 = rng.standard_normal((C, P)).astype(npdt); u = rng.random(C).astype(npdt)
+        res = {}
+        for mode in ("off", "on"):
+            pl.row_waves = mode
+            t, g = pl.log_target_grad(_t(th0, dt))
+            rows = pl.log_lik_rows(_t(th0, dt))
+            for c in range(C):
+                to, go, _, _ = co.log_target_grad(th0[c])
+                np.testing.assert_allclose(t[c].item(), to, rtol=tol, atol=tol * 10)
+                np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=tol * 10, atol=tol * max(1.0, np.abs(go).max()))
+            a = [_t(th0, dt).clone(), t.clone(), g.clone()]
+            o = pl.hmc_step(*a, 0.01, 4, p0=_t(p0, dt), u=_t(u, dt))
+            tho, tvo, go2 = th0.copy(), t.cpu().numpy().astype(npdt), g.cpu().numpy().astype(npdt)
+            acc, hc, hp = co.hmc_draw(tho, tvo, go2, p0, u, 0.01, 4)
+            np.testing.assert_allclose(o["h_prop"].cpu().numpy(), hp, rtol=tol * 10, atol=tol * 100)
+            b = [_t(th0, dt).clone(), t.clone(), g.clone()]
+            om = pl.mala_step(*b, 1e-3, z=_t(p0, dt), u=_t(u, dt))
+            cm = [_t(th0, dt).clone(), t.clone()]
+            oh = pl.mh_step(cm[0], cm[1], torch.full((P,), 0.01, dtype=dt), z=_t(p0, dt), u=_t(u, dt))
+            # blocks of iterations on the in-kernel streams == single steps, bit for bit, in either mode
+            r1 = [_t(th0, dt).clone(), t.clone(), g.clone()]
+            r2 = [_t(th0, dt).clone(), t.clone(), g.clone()]
+            pl.mala_run(*r1, 1e-3, 3, seed=5, it=2)
+            for i in range(3):
+                pl.mala_step(*r2, 1e-3, seed=5, it=2 + i)
+            assert all(torch.equal(p_, q_) for p_, q_ in zip(r1, r2))
+            res[mode] = (t, g, rows, o["h_prop"], om["log_rate"], oh["log_rate"], a[0])
+        for va, vb in zip(res["off"], res["on"]):  # two summation orders of the same numbers
+            np.testing.assert_allclose(va.cpu().numpy(), vb.cpu().numpy(), rtol=tol * 10, atol=tol * 100)
+        # pinned: chain 0's bits are the same alone and among 5000 chains; auto: 'on' for few chains, 'off' for many
+        big = torch.cat([_t(th0[:1], dt)] * 5000)
+        for mode in ("off", "on"):
+            pl.row_waves = mode
+            g1 = pl.log_target_grad(_t(th0[:1], dt))[1]
+            gN = pl.log_target_grad(big)[1]
+            assert torch.equal(g1[0], gN[0]) and torch.equal(gN[0], gN[-1])
+        pl.row_waves = "auto"
+        assert torch.equal(pl.log_target_grad(_t(th0, dt))[1], res["on"][1])
+        pl.row_waves = "off"
+        g_off_big = pl.log_target_grad(big)[1]
+        pl.row_waves = "auto"
+        assert torch.equal(pl.log_target_grad(big)[1], g_off_big)
+
+
 # --------------------------------------------------------------------------------------------- generic kernel breadth
 @pytest.mark.parametrize("dims,acts,bias,lik,tag", [
     ([3, 5, 4, 2], [2, 3, 0], [1, 1, 1], 1, "f64"),      # tanh, relu, linear + CE
