@@ -40,11 +40,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // The carve depends on BF3 (a compile-time constant in scope wherever these are used): the bf16x3 form keeps the three
 // bf16 pieces of W1's rows (the A operand of the F1 product) in 6 private 16-byte slots per lane and needs the f32
 // image of W1 only while those are made (it then lies in the first transpose buffer).
+// BF3 = 2 (few row tiles: the data image leaves room for it): delta1 crosses to the row-contracting product dW1 as the
+// bf16 pieces it is split into anyway (the A operand of dH0), through a [piece][row][32 features] image of 6 KB that
+// ds_read_b64_tr_b16 reads transposed, in place of an f32 round trip and a second split; the image takes the first
+// transpose buffer's place (H1's transposed copy, dead by then, lies in its first 4.5 KB).
 #define O_W1P 0        // BF3: [piece 0..2][k-step 0..1][lane] x 16 bytes
 #define O_W1IMG (BF3 ? 1536 : 0)
 #define O_TB0 (BF3 ? 1536 : 1152)
-#define O_TB1 (BF3 ? 2688 : 2304)
-#define O_SMALL (BF3 ? 3840 : 3456)
+#define O_TB1 (BF3 == 2 ? 3072 : (BF3 ? 2688 : 2304))
+#define O_SMALL (BF3 == 2 ? 4224 : (BF3 ? 3840 : 3456))
 #define O_W0IMG (O_SMALL + 0)     // [32][5]
 #define O_W2IMG (O_SMALL + 160)   // [4][36]
 #define O_W2TIMG (O_SMALL + 304)  // [32][4]
@@ -55,8 +59,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // its four 16-byte pieces from jj = 0..3, which 32 floats apart land on the same banks for jj and jj + 2 (a two-way
 // conflict on eight reads per tile: the 10 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 1); 36 apart they do not.
 #define D2S 36
-#define WAVE_FLOATS (BF3 ? 4480 : 4096)
-#define WAVE_FLOATS_OF(bf3) ((bf3) ? 4480 : 4096)
+#define WAVE_FLOATS (BF3 == 2 ? 4864 : (BF3 ? 4480 : 4096))
+#define WAVE_FLOATS_OF(bf3) ((bf3) == 2 ? 4864 : ((bf3) ? 4480 : 4096))
 #define XTILE_FLOATS 304  // per row tile: [32][5] (x0..x3, label) + [4][D2S] (x regrouped for the 4x4x1 product)
 
 // canonical offsets of MLP(4-32-32-3) in theta
@@ -357,7 +361,7 @@ __device__ __forceinline__ void for_each2(Vec<DKV>& a, Vec<DKV>& b, F f) {
 }
 
 // stage the operand images of theta in this wave's LDS region
-template <bool BF3, typename SH>
+template <int BF3, typename SH>
 __device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, int c, int h, int lane) {
   constexpr float SC = ActScale<SH::ACT>::value;
 #pragma unroll
@@ -440,12 +444,17 @@ __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
 // latency the end of every evaluation then waits for (four serial round trips per leapfrog step before this).
 // GRAD = false: the value only (random-walk MH needs no gradient, metropolis_hastings.py:41-73): the forward products
 // and the row log-sum-exp, about a third of the work.
-template <int PARK, bool UPRIOR, bool BF3, typename SH, bool GRAD = true>
+template <int PARK, bool UPRIOR, int BF3, typename SH, bool GRAD = true>
 __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec<SH::DK>& g, bool has_temp, float temp,
                       int c, int h, int lane, bool need_value, Pace& pc) {
   constexpr int DKV = SH::DK;
+  constexpr bool TRD = BF3 == 2 && GRAD;
   const int jj = lane & 3;
-  f32x16 dW1;
+  f32x16 dW1, db1T;
+  if constexpr (TRD) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) db1T[r] = 0.0f;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) dW1[r] = 0.0f;
   f32x4 dW0a = {0, 0, 0, 0}, dW0b = {0, 0, 0, 0}, dW2a = {0, 0, 0, 0}, dW2b = {0, 0, 0, 0};
@@ -612,12 +621,76 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
     }
     PH(5);
     D1 = times_dact<SH::ACT>(D1, H1);
+    f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
+    if constexpr (TRD) {
+      // ---- delta1 is split once: its pieces are the A operand of dH0 below and, read back transposed from the piece
+      // image, of dW1; db1 is summed in the tile layout (reduced over the rows once per evaluation)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 s2 = f32x2{db1T[r], db1T[r + 1]} + f32x2{D1[r], D1[r + 1]};
+        db1T[r] = s2[0];
+        db1T[r + 1] = s2[1];
+      }
+      Pieces Ad;
+      split16(D1, Ad);
+      wave_lds_fence();  // the transposed reads of H1 (dW2) are done: the image takes that buffer's place
+      {
+        // [piece][row c][four 16-byte units]: unit 2s+h holds features 16s+4h .. +3 and 16s+8+4h .. +3 of the row (the
+        // lane's elements 8s .. 8s+7), at position (2s+h) ^ ((c>>1)&3) so that eight consecutive rows fill all banks
+        u32x4* pb = reinterpret_cast<u32x4*>(lw + O_TB0) + c * 4;
+        const int sw = (c >> 1) & 3;
+        const int u0 = h ^ sw, u1 = (2 + h) ^ sw;
+        pb[0 * 128 + u0] = Ad.hi[0]; pb[0 * 128 + u1] = Ad.hi[1];
+        pb[1 * 128 + u0] = Ad.mid[0]; pb[1 * 128 + u1] = Ad.mid[1];
+        pb[2 * 128 + u0] = Ad.lo[0]; pb[2 * 128 + u1] = Ad.lo[1];
+      }
+      wave_lds_fence();
+      PH(6);
+      // ---- B1(1): dH0 = delta1 W1 computed UNtransposed (A = delta1 tile with M = rows, B = theta's own W1 registers)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      acc = product_bf3(Ad, Bw, acc);
+      PH(7);
+      // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in]
+#pragma unroll
+      for (int r = 4 * SG; r < 16; ++r) H0U[r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < SG; ++s) {
+        const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB1 + c * TS36 + 8 * s + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) H0U[4 * s + i] = hu[i];
+      }
+      // lane 4q+p of a 16-lane group supplies rows 8s+4h+q, features 16(group&1) + 4p .. +3; lane i of the group receives
+      // feature 16(group&1) + i of the four rows: elements 4s .. 4s+3 of the lane <-> feature layout, already packed
+      Pieces AdU;
+      {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int q = (lane >> 2) & 3, pp = lane & 3, cb = (lane >> 4) & 1;
+        const int n0 = 4 * h + q;
+        const int byte = n0 * 64 + 16 * ((2 * cb + (pp & 1)) ^ ((n0 >> 1) & 3)) + 8 * (pp >> 1);
+        const char* base = reinterpret_cast<const char*>(lw + O_TB0) + byte;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const s16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 0 * 2048 + 512 * s));
+          const s16x4 vm = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 1 * 2048 + 512 * s));
+          const s16x4 vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 2 * 2048 + 512 * s));
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 wh = __builtin_bit_cast(u32x2, vh), wm = __builtin_bit_cast(u32x2, vm), wl = __builtin_bit_cast(u32x2, vl);
+          AdU.hi[s >> 1][2 * (s & 1)] = wh[0]; AdU.hi[s >> 1][2 * (s & 1) + 1] = wh[1];
+          AdU.mid[s >> 1][2 * (s & 1)] = wm[0]; AdU.mid[s >> 1][2 * (s & 1) + 1] = wm[1];
+          AdU.lo[s >> 1][2 * (s & 1)] = wl[0]; AdU.lo[s >> 1][2 * (s & 1) + 1] = wl[1];
+        }
+      }
+      Pieces Bh;
+      split16(H0U, Bh);
+      dW1 = product_bf3(AdU, Bh, dW1);
+    } else {
     wave_lds_fence();
     store_T(lw + O_TB0, D1, c, h);
     wave_lds_fence();
     PH(6);
     // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in];  db1 += sum_n delta1
-    f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
     f32x16 D1U;  // BF3: delta1 likewise (lane <-> output feature)
 #pragma unroll
     for (int r = 4 * SG; r < 16; ++r) { H0U[r] = 0.0f; D1U[r] = 0.0f; }
@@ -654,6 +727,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
+    }
     }
     const f32x16 D0u = times_dact<SH::ACT>(acc, H0U);
     PH(8);
@@ -700,6 +774,18 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
     th.b0 = lw[at + 8 * 64];
 #pragma unroll
     for (int o = 0; o < 3; ++o) th.b2[o] = lw[at + (9 + o) * 64];
+  }
+  if constexpr (TRD) {
+    // db1: the tile-layout sums (lane <-> row) through the transpose buffer, each lane then adds its feature's 16 rows
+    wave_lds_fence();
+    store_T(lw + O_TB0, db1T, c, h);
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB0 + c * TS36 + 8 * s + 4 * h);
+      db1 += (du[0] + du[1]) + (du[2] + du[3]);
+    }
+    wave_lds_fence();
   }
   // ---- combine the two row-parity halves and the lanes
   if (GRAD) {
@@ -816,7 +902,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec<DKV>& n
 // l, l + 64, ... (ey_rng_normal4: one Philox call per block) into the two transpose buffers of this wave's LDS region
 // (free between evaluations), from where every lane then picks the 29 elements of its register layout.  One call
 // per element in every lane, as a lane-local draw needs, costs 29 Philox calls per lane instead of at most 6.
-template <bool BF3, int DKV>
+template <int BF3, int DKV>
 __device__ __forceinline__ const float* stage_normals(float* lw, const EyRng& rn, int lane) {
   float* st = lw + O_TB0;  // O_TB0 and O_TB1 are adjacent: 2304 floats >= NPAR + 3
   constexpr int NB = (NPAR + 3) / 4;
@@ -830,7 +916,7 @@ __device__ __forceinline__ const float* stage_normals(float* lw, const EyRng& rn
 }
 
 // One chain of one launch: everything between reading theta and writing the accepted state back.
-template <int MODE, int PARK, bool UPRIOR, bool DA, bool BF3, typename SH>
+template <int MODE, int PARK, bool UPRIOR, bool DA, int BF3, typename SH>
 __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, const int64_t chain, const int it,
                                           const int c, const int h, const int lane, Pace& pc) {
   constexpr int DKV = SH::DK;
@@ -1034,7 +1120,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
 // Two waves share a SIMD because f32 MFMA runs on the vector ALUs: the partner hides latency (LDS round trips, MFMA
 // result latency) rather than adding throughput (tools/coexec_probe*.hip).  WAVES = 4 is the former layout (two
 // 4-wave workgroups per CU, one chain per wave), kept for A/B runs (ey_debug_set_variant bit 0).
-template <int MODE, int WAVES, int PARK, bool UPRIOR, bool DA, bool BF3, typename SH>
+template <int MODE, int WAVES, int PARK, bool UPRIOR, bool DA, int BF3, typename SH>
 __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   constexpr int MF_WAVES = WAVES, MF_THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1123,11 +1209,12 @@ int ey_mfma32_kind(const ey_plan* pl) {
 }
 bool ey_mfma32_supports(const ey_plan* pl) { return ey_mfma32_kind(pl) != 0; }
 
-static size_t mf_lds_bytes(int ntiles, int waves, int park, bool bf3) {
+static size_t mf_lds_bytes(int ntiles, int waves, int park, int bf3) {
   return sizeof(float) * ((size_t)ntiles * XTILE_FLOATS + (size_t)waves * (WAVE_FLOATS_OF(bf3) + 64 * park)) +
          sizeof(int) * 2 * waves;
 }
 #define MF_BF3_TILES 16   // the bf16x3 form's larger per-wave region leaves room for 16 row tiles (N <= 512)
+#define MF_TRD_TILES 6    // ... and with the piece image of delta1 (BF3 = 2) for 6 (N <= 192)
 #define MF_PARK 12        // position elements parked in LDS during the tile loop ...
 #define MF_PARK_TILES 6   // ... when the data image leaves room for it (N <= 192 rows)
 
@@ -1180,13 +1267,13 @@ int ey_mfma32_set_data(ey_plan* pl, hipStream_t s) {
   return EY_OK;
 }
 
-template <int MODE, int WAVES, int PARK, bool UPRIOR = false, bool DA = true, bool BF3 = false, typename SH = MfHeadline>
+template <int MODE, int WAVES, int PARK, bool UPRIOR = false, bool DA = true, int BF3 = 0, typename SH = MfHeadline>
 static int mf_launch_v(MfArgs& a, int n_cu, hipStream_t s) {
   const size_t bytes = mf_lds_bytes(a.ntiles, WAVES, PARK, BF3);
   // per launch: function attributes are per device and plans on different devices / threads share this code
   EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32<MODE, WAVES, PARK, UPRIOR, DA, BF3, SH>),
                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)mf_lds_bytes(BF3 ? MF_BF3_TILES : (PARK ? MF_PARK_TILES : MF_MAX_TILES), WAVES, PARK, BF3)));
+                             (int)mf_lds_bytes(BF3 == 2 ? MF_TRD_TILES : (BF3 ? MF_BF3_TILES : (PARK ? MF_PARK_TILES : MF_MAX_TILES)), WAVES, PARK, BF3)));
   // 8 waves: one persistent workgroup per CU, or one per chain when there are fewer chains than CUs (then only wave
   // 0 of a workgroup has work and every chain gets a CU to itself); 4 waves: a workgroup per 4 chains
   const unsigned grid = WAVES == 8 ? (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256)
@@ -1239,6 +1326,9 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
     const int variant = t_ey_variant & 15;
     if (variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);
     if (bf3) {
+      if (a.prior_uniform && a.ntiles <= MF_TRD_TILES && !(variant & 4))
+        return a.da_state ? mf_launch_v<MODE, 8, 0, true, true, 2>(a, pl->n_cu, s)
+                          : mf_launch_v<MODE, 8, 0, true, false, 2>(a, pl->n_cu, s);
       if (a.prior_uniform)
         return a.da_state ? mf_launch_v<MODE, 8, 0, true, true, true>(a, pl->n_cu, s)
                           : mf_launch_v<MODE, 8, 0, true, false, true>(a, pl->n_cu, s);
