@@ -40,15 +40,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // The carve depends on BF3 (a compile-time constant in scope wherever these are used): the bf16x3 form keeps the three
 // bf16 pieces of W1's rows (the A operand of the F1 product) in 6 private 16-byte slots per lane and needs the f32
 // image of W1 only while those are made (it then lies in the first transpose buffer).
-// BF3 = 2 (few row tiles: the data image leaves room for it): delta1 crosses to the row-contracting product dW1 as the
-// bf16 pieces it is split into anyway (the A operand of dH0), through a [piece][row][32 features] image of 6 KB that
-// ds_read_b64_tr_b16 reads transposed, in place of an f32 round trip and a second split; the image takes the first
-// transpose buffer's place (H1's transposed copy, dead by then, lies in its first 4.5 KB).
-#define O_W1P 0        // BF3: [piece 0..2][k-step 0..1][lane] x 16 bytes
-#define O_W1IMG (BF3 ? 1536 : 0)
-#define O_TB0 (BF3 ? 1536 : 1152)
-#define O_TB1 (BF3 == 2 ? 3072 : (BF3 ? 2688 : 2304))
-#define O_SMALL (BF3 == 2 ? 4224 : (BF3 ? 3840 : 3456))
+// BF3 = 2 (batches of at most MF_TRD_TILES row tiles: the data image leaves room for it): H0 and delta1 cross to the
+// row-contracting product dW1 as the bf16 pieces they are split into anyway (the B operand of F1, the B operand of dH0),
+// through two [piece][row][32 features] images of 6 KB each that ds_read_b64_tr_b16 reads transposed, in place of two f32
+// round trips and two more splits.  The images take the transpose buffers' places (H1's transposed copy, dead by then,
+// lies in the first 4.5 KB of delta1's image; delta0's, made when dW1 has read both, in H0's); the low pieces of W1's rows
+// stay in registers (8), which makes the room.
+#define O_W1P 0        // BF3: [piece 0..2][k-step 0..1][lane] x 16 bytes (BF3 = 2: pieces 0..1)
+#define O_W1IMG (BF3 == 2 ? 2560 : (BF3 ? 1536 : 0))
+#define O_TB0 (BF3 == 2 ? 2560 : (BF3 ? 1536 : 1152))
+#define O_TB1 (BF3 == 2 ? 1024 : (BF3 ? 2688 : 2304))
+#define O_SMALL (BF3 == 2 ? 4096 : (BF3 ? 3840 : 3456))
+#define O_STAGE (BF3 == 2 ? O_TB1 : O_TB0)  // >= 2304 contiguous floats that are free between evaluations
 #define O_W0IMG (O_SMALL + 0)     // [32][5]
 #define O_W2IMG (O_SMALL + 160)   // [4][36]
 #define O_W2TIMG (O_SMALL + 304)  // [32][4]
@@ -59,8 +62,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // its four 16-byte pieces from jj = 0..3, which 32 floats apart land on the same banks for jj and jj + 2 (a two-way
 // conflict on eight reads per tile: the 10 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 1); 36 apart they do not.
 #define D2S 36
-#define WAVE_FLOATS (BF3 == 2 ? 4864 : (BF3 ? 4480 : 4096))
-#define WAVE_FLOATS_OF(bf3) ((bf3) == 2 ? 4864 : ((bf3) ? 4480 : 4096))
+#define WAVE_FLOATS (BF3 == 2 ? 4736 : (BF3 ? 4480 : 4096))
+#define WAVE_FLOATS_OF(bf3) ((bf3) == 2 ? 4736 : ((bf3) ? 4480 : 4096))
 #define XTILE_FLOATS 304  // per row tile: [32][5] (x0..x3, label) + [4][D2S] (x regrouped for the 4x4x1 product)
 
 // canonical offsets of MLP(4-32-32-3) in theta
@@ -180,12 +183,13 @@ __device__ unsigned long long g_ey_wave_t[3 * 8192];  // per chain: kernel entry
 #define PH(i) do { if (ph_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += n_ - ph_t; ph_t = n_; } } while (0)
 #define KO(i) do { if (kt_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ko_acc[i] += n_ - ko_t; ko_t = n_; } } while (0)
 #else
-// BF3: a scheduling barrier at the phase boundaries selected by EY_SB keeps the instruction scheduler from overlapping
-// whole phases (it fills the 256 registers two waves per SIMD allow, and the allocator then spills)
+// BF3 = 2: a scheduling barrier at the phase boundaries selected by EY_SB keeps the instruction scheduler from overlapping
+// whole phases (it fills the 256 registers two waves per SIMD allow, and the allocator then spills).  After F0 and after
+// F1: +1.5 % against none in two interleaved rounds of whole-library builds, the backward boundaries nothing.
 #ifndef EY_SB
-#define EY_SB 0
+#define EY_SB 0x03
 #endif
-#define PH(i) do { if (BF3 && ((EY_SB >> (i)) & 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PH(i) do { if (BF3 == 2 && ((EY_SB >> (i)) & 1)) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define KO(i) do { } while (0)
 #endif
 // Packed f32 math (two elements per instruction at the rate of one): written on two-element vectors so that the
@@ -282,17 +286,30 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 // acc += A B over the 32 contracted indices both operands hold as elements 8s+j of k-step s
+// (SWAPPED: the piece products in the order product_bf3(B, A) takes them, for a product whose operands changed sides:
+// the same sums, term for term, as before the change)
+template <bool SWAPPED = false>
 __device__ __forceinline__ f32x16 product_bf3(const Pieces& A, const Pieces& B, f32x16 acc) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    acc = mfma_bf16(A.hi[s], B.lo[s], acc);
-    acc = mfma_bf16(A.lo[s], B.hi[s], acc);
+    if (SWAPPED) {
+      acc = mfma_bf16(A.lo[s], B.hi[s], acc);
+      acc = mfma_bf16(A.hi[s], B.lo[s], acc);
+    } else {
+      acc = mfma_bf16(A.hi[s], B.lo[s], acc);
+      acc = mfma_bf16(A.lo[s], B.hi[s], acc);
+    }
     acc = mfma_bf16(A.mid[s], B.mid[s], acc);
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    acc = mfma_bf16(A.hi[s], B.mid[s], acc);
-    acc = mfma_bf16(A.mid[s], B.hi[s], acc);
+    if (SWAPPED) {
+      acc = mfma_bf16(A.mid[s], B.hi[s], acc);
+      acc = mfma_bf16(A.hi[s], B.mid[s], acc);
+    } else {
+      acc = mfma_bf16(A.hi[s], B.mid[s], acc);
+      acc = mfma_bf16(A.mid[s], B.hi[s], acc);
+    }
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) acc = mfma_bf16(A.hi[s], B.hi[s], acc);
@@ -361,8 +378,9 @@ __device__ __forceinline__ void for_each2(Vec<DKV>& a, Vec<DKV>& b, F f) {
 }
 
 // stage the operand images of theta in this wave's LDS region
+struct W1Lo { u32x4 v[2]; };  // BF3 = 2: the low pieces of W1's row c (the A operand of F1), kept in registers
 template <int BF3, typename SH>
-__device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, int c, int h, int lane) {
+__device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, int c, int h, int lane, W1Lo& wl) {
   constexpr float SC = ActScale<SH::ACT>::value;
 #pragma unroll
   for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = SC * th.w1[r];
@@ -394,7 +412,11 @@ __device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, i
     u32x4* pv = reinterpret_cast<u32x4*>(lw + O_W1P) + lane;
     pv[0 * 64] = A.hi[0]; pv[1 * 64] = A.hi[1];
     pv[2 * 64] = A.mid[0]; pv[3 * 64] = A.mid[1];
-    pv[4 * 64] = A.lo[0]; pv[5 * 64] = A.lo[1];
+    if constexpr (BF3 == 2) {
+      wl.v[0] = A.lo[0]; wl.v[1] = A.lo[1];
+    } else {
+      pv[4 * 64] = A.lo[0]; pv[5 * 64] = A.lo[1];
+    }
     wave_lds_fence();
   }
 }
@@ -434,6 +456,38 @@ __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
   else __builtin_amdgcn_s_setprio(1);
 }
 
+// ---- the piece images of BF3 = 2: a tile X[feature][row] in the T layout, already split, goes to LDS as
+// [piece][row c][four 16-byte units] -- unit 2s+h holds features 16s+4h .. +3 and 16s+8+4h .. +3 of the row (the lane's
+// elements 8s .. 8s+7), at position (2s+h) ^ ((c>>1)&3) so that eight consecutive rows of a store fill all banks -- and
+// comes back with lane <-> feature: ds_read_b64_tr_b16 gives lane i of a 16-lane group feature 16(group&1) + i of the
+// four rows 8s+4h+q whose addresses lanes 4q+p supply (features 16(group&1) + 4p .. +3): elements 4s .. 4s+3 of the
+// lane <-> feature layout, packed in pairs as the products take them.  Conflict-free both ways.
+__device__ __forceinline__ void store_pieces(float* img, const Pieces& P, int c, int h) {
+  u32x4* pb = reinterpret_cast<u32x4*>(img) + c * 4;
+  const int sw = (c >> 1) & 3;
+  const int u0 = h ^ sw, u1 = (2 + h) ^ sw;
+  pb[0 * 128 + u0] = P.hi[0]; pb[0 * 128 + u1] = P.hi[1];
+  pb[1 * 128 + u0] = P.mid[0]; pb[1 * 128 + u1] = P.mid[1];
+  pb[2 * 128 + u0] = P.lo[0]; pb[2 * 128 + u1] = P.lo[1];
+}
+__device__ __forceinline__ void load_pieces_transposed(const float* img, Pieces& P, int h, int lane) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const int q = (lane >> 2) & 3, pp = lane & 3, cb = (lane >> 4) & 1;
+  const int n0 = 4 * h + q;
+  const char* base = reinterpret_cast<const char*>(img) + n0 * 64 + 16 * ((2 * cb + (pp & 1)) ^ ((n0 >> 1) & 3)) + 8 * (pp >> 1);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const u32x2 wh = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 0 * 2048 + 512 * s)));
+    const u32x2 wm = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 1 * 2048 + 512 * s)));
+    const u32x2 wl = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 2 * 2048 + 512 * s)));
+    P.hi[s >> 1][2 * (s & 1)] = wh[0]; P.hi[s >> 1][2 * (s & 1) + 1] = wh[1];
+    P.mid[s >> 1][2 * (s & 1)] = wm[0]; P.mid[s >> 1][2 * (s & 1) + 1] = wm[1];
+    P.lo[s >> 1][2 * (s & 1)] = wl[0]; P.lo[s >> 1][2 * (s & 1) + 1] = wl[1];
+  }
+}
+
 // log-target and gradient of the position whose images are staged in lw.  Returns the (tempered) log-target.
 // `need_value` (wave-uniform) = false skips the value-only work (row log-sum-exp terms, quadratic form of the prior
 // and their reductions): inside a trajectory only the gradient is consumed, hmc.py:108-121.
@@ -446,7 +500,7 @@ __device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
 // and the row log-sum-exp, about a third of the work.
 template <int PARK, bool UPRIOR, int BF3, typename SH, bool GRAD = true>
 __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec<SH::DK>& g, bool has_temp, float temp,
-                      int c, int h, int lane, bool need_value, Pace& pc) {
+                      int c, int h, int lane, bool need_value, Pace& pc, const W1Lo& wl) {
   constexpr int DKV = SH::DK;
   constexpr bool TRD = BF3 == 2 && GRAD;
   const int jj = lane & 3;
@@ -511,7 +565,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw[O_W0IMG + c * 5 + 2 * s + h], xt[c * 5 + 2 * s + h], acc, 0, 0, 0);
     const int lab = __float_as_int(xt[c * 5 + 4]);
     const f32x16 H0 = act_tile<SH::ACT>(acc);
-    if (GRAD) store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
+    if (GRAD && BF3 != 2) store_T(lw + O_TB1, H0, c, h);  // transposed copy for dW1, needed only after the backward chain: issue it early
     PH(0);
     // ---- F1: H1^T = sigmoid(W1 H0^T + b1)
 #pragma unroll
@@ -525,10 +579,15 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       // elements 8s+j of k-step s are features 16s + 8(j>>2) + 4h + (j&3) in both
       Pieces B1p, A1p;
       split16(H0, B1p);
+      if constexpr (TRD) store_pieces(lw + O_TB1, B1p, c, h);  // for dW1, read back transposed after the backward chain
       const u32x4* pv = reinterpret_cast<const u32x4*>(lw + O_W1P) + lane;
       A1p.hi[0] = pv[0 * 64]; A1p.hi[1] = pv[1 * 64];
       A1p.mid[0] = pv[2 * 64]; A1p.mid[1] = pv[3 * 64];
-      A1p.lo[0] = pv[4 * 64]; A1p.lo[1] = pv[5 * 64];
+      if constexpr (BF3 == 2) {
+        A1p.lo[0] = wl.v[0]; A1p.lo[1] = wl.v[1];
+      } else {
+        A1p.lo[0] = pv[4 * 64]; A1p.lo[1] = pv[5 * 64];
+      }
       acc = product_bf3(A1p, B1p, acc);
     } else {
 #pragma unroll
@@ -623,8 +682,8 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
     D1 = times_dact<SH::ACT>(D1, H1);
     f32x16 H0U;  // H0 with lane <-> feature, register 4s+i <-> row 8s+4h+i
     if constexpr (TRD) {
-      // ---- delta1 is split once: its pieces are the A operand of dH0 below and, read back transposed from the piece
-      // image, of dW1; db1 is summed in the tile layout (reduced over the rows once per evaluation)
+      // ---- delta1 is split once: its pieces are the B operand of dH0 below and, read back transposed from the piece
+      // image, the A operand of dW1; db1 is summed in the tile layout (reduced over the rows once per evaluation)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 s2 = f32x2{db1T[r], db1T[r + 1]} + f32x2{D1[r], D1[r + 1]};
@@ -633,58 +692,36 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       }
       Pieces Ad;
       split16(D1, Ad);
-      wave_lds_fence();  // the transposed reads of H1 (dW2) are done: the image takes that buffer's place
-      {
-        // [piece][row c][four 16-byte units]: unit 2s+h holds features 16s+4h .. +3 and 16s+8+4h .. +3 of the row (the
-        // lane's elements 8s .. 8s+7), at position (2s+h) ^ ((c>>1)&3) so that eight consecutive rows fill all banks
-        u32x4* pb = reinterpret_cast<u32x4*>(lw + O_TB0) + c * 4;
-        const int sw = (c >> 1) & 3;
-        const int u0 = h ^ sw, u1 = (2 + h) ^ sw;
-        pb[0 * 128 + u0] = Ad.hi[0]; pb[0 * 128 + u1] = Ad.hi[1];
-        pb[1 * 128 + u0] = Ad.mid[0]; pb[1 * 128 + u1] = Ad.mid[1];
-        pb[2 * 128 + u0] = Ad.lo[0]; pb[2 * 128 + u1] = Ad.lo[1];
-      }
+      wave_lds_fence();  // the transposed reads of H1 (dW2) are done: delta1's image takes that buffer's place
+      store_pieces(lw + O_TB0, Ad, c, h);
       wave_lds_fence();
       PH(6);
-      // ---- B1(1): dH0 = delta1 W1 computed UNtransposed (A = delta1 tile with M = rows, B = theta's own W1 registers)
+      // ---- B1(1): dH0^T = W1^T delta1^T with A = theta's own W1 registers (M = input feature, k = output feature) and
+      // B = delta1's pieces: the accumulator is a T tile like H0, so delta0 = dH0 * H0 (1 - H0) takes H0 from registers
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      acc = product_bf3(Ad, Bw, acc);
+      acc = product_bf3<true>(Bw, Ad, acc);
+      const f32x16 D0 = times_dact<SH::ACT>(acc, H0);
       PH(7);
-      // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in]
+      // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in]: both operands from the piece images, transposed
+      {
+        Pieces AdU, BhU;
+        load_pieces_transposed(lw + O_TB0, AdU, h, lane);
+        load_pieces_transposed(lw + O_TB1, BhU, h, lane);
+        dW1 = product_bf3(AdU, BhU, dW1);
+      }
+      // delta0 with lane <-> feature for the dW0 product, through H0's image (read by now)
+      wave_lds_fence();
+      store_T(lw + O_TB1, D0, c, h);
+      wave_lds_fence();
 #pragma unroll
       for (int r = 4 * SG; r < 16; ++r) H0U[r] = 0.0f;
 #pragma unroll
       for (int s = 0; s < SG; ++s) {
-        const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_TB1 + c * TS36 + 8 * s + 4 * h);
+        const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_TB1 + c * TS36 + 8 * s + 4 * h);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) H0U[4 * s + i] = hu[i];
+        for (int i = 0; i < 4; ++i) H0U[4 * s + i] = du[i];
       }
-      // lane 4q+p of a 16-lane group supplies rows 8s+4h+q, features 16(group&1) + 4p .. +3; lane i of the group receives
-      // feature 16(group&1) + i of the four rows: elements 4s .. 4s+3 of the lane <-> feature layout, already packed
-      Pieces AdU;
-      {
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const int q = (lane >> 2) & 3, pp = lane & 3, cb = (lane >> 4) & 1;
-        const int n0 = 4 * h + q;
-        const int byte = n0 * 64 + 16 * ((2 * cb + (pp & 1)) ^ ((n0 >> 1) & 3)) + 8 * (pp >> 1);
-        const char* base = reinterpret_cast<const char*>(lw + O_TB0) + byte;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const s16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 0 * 2048 + 512 * s));
-          const s16x4 vm = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 1 * 2048 + 512 * s));
-          const s16x4 vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 2 * 2048 + 512 * s));
-          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-          const u32x2 wh = __builtin_bit_cast(u32x2, vh), wm = __builtin_bit_cast(u32x2, vm), wl = __builtin_bit_cast(u32x2, vl);
-          AdU.hi[s >> 1][2 * (s & 1)] = wh[0]; AdU.hi[s >> 1][2 * (s & 1) + 1] = wh[1];
-          AdU.mid[s >> 1][2 * (s & 1)] = wm[0]; AdU.mid[s >> 1][2 * (s & 1) + 1] = wm[1];
-          AdU.lo[s >> 1][2 * (s & 1)] = wl[0]; AdU.lo[s >> 1][2 * (s & 1) + 1] = wl[1];
-        }
-      }
-      Pieces Bh;
-      split16(H0U, Bh);
-      dW1 = product_bf3(AdU, Bh, dW1);
     } else {
     wave_lds_fence();
     store_T(lw + O_TB0, D1, c, h);
@@ -729,7 +766,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D1[r], th.w1[r], acc, 0, 0, 0);
     }
     }
-    const f32x16 D0u = times_dact<SH::ACT>(acc, H0U);
+    const f32x16 D0u = TRD ? H0U : times_dact<SH::ACT>(acc, H0U);  // (TRD: H0U holds delta0 itself)
     PH(8);
     // ---- B2(0): dW0[out][in] += sum_n delta0[n][out] x[n][in];  db0 += sum_n delta0
     const float* x2 = xt + 160 + jj * D2S + h * 16;
@@ -904,7 +941,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec<DKV>& n
 // per element in every lane, as a lane-local draw needs, costs 29 Philox calls per lane instead of at most 6.
 template <int BF3, int DKV>
 __device__ __forceinline__ const float* stage_normals(float* lw, const EyRng& rn, int lane) {
-  float* st = lw + O_TB0;  // O_TB0 and O_TB1 are adjacent: 2304 floats >= NPAR + 3
+  float* st = lw + O_STAGE;  // the two transpose buffers are adjacent: 2304 floats >= NPAR + 3
   constexpr int NB = (NPAR + 3) / 4;
   for (int b = lane; b < NB; b += 64) {
     float o[4];
@@ -939,11 +976,12 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   const float eps = A.step_vec ? A.step_vec[chain] : A.step;
 
   Vec th, g, p;
+  W1Lo wl;
   for_each(th, c, h, lane, [&](float& v, int idx, bool) { v = thg[idx]; });
 
   if (MODE == MODE_GRAD) {
-    write_images<BF3, SH>(lw, th, c, h, lane);
-    const float t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3, SH>(lw, th, c, h, lane, wl);
+    const float t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc, wl);
     for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
     if (lane == 0) A.target[chain] = t;
     return;
@@ -971,8 +1009,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
       }
     });
     wave_lds_fence();  // the staged normals have been read; the evaluation reuses that LDS
-    write_images<BF3, SH>(lw, p, c, h, lane);
-    const float tv = eval<PARK, UPRIOR, BF3, SH, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3, SH>(lw, p, c, h, lane, wl);
+    const float tv = eval<PARK, UPRIOR, BF3, SH, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc, wl);
     const float t_old = A.target[chain];
     float log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
     if (MODE == MODE_MALA) {
@@ -1030,8 +1068,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   const float h_cur = -t_cur + 0.5f * kin;  // hmc.py:91-98,137
   float t = t_cur;
   if (MODE == MODE_LEAPFROG || A.recompute) {  // hmc.py:104
-    write_images<BF3, SH>(lw, th, c, h, lane);
-    t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc);
+    write_images<BF3, SH>(lw, th, c, h, lane, wl);
+    t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc, wl);
   }
   // leapfrog, hmc.py:100-124 (grad_potential = -grad)
   for_each2(p, g, [&](float& pv, float& gv) { pv = pv + 0.5f * eps * gv; });
@@ -1040,9 +1078,9 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   for (int k = 1; k <= A.L; ++k) {
     for_each2(th, p, [&](float& tv, float& pv) { tv = tv + eps * pv; });
     KO(1);
-    write_images<BF3, SH>(lw, th, c, h, lane);
+    write_images<BF3, SH>(lw, th, c, h, lane, wl);
     KO(2);
-    t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc);
+    t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc, wl);
     KO(3);
     const float w = (k < A.L) ? eps : 0.5f * eps;
     for_each2(p, g, [&](float& pv, float& gv) { pv = pv + w * gv; });
@@ -1214,12 +1252,13 @@ static size_t mf_lds_bytes(int ntiles, int waves, int park, int bf3) {
          sizeof(int) * 2 * waves;
 }
 #define MF_BF3_TILES 16   // the bf16x3 form's larger per-wave region leaves room for 16 row tiles (N <= 512)
-#define MF_TRD_TILES 6    // ... and with the piece image of delta1 (BF3 = 2) for 6 (N <= 192)
+#define MF_TRD_TILES 10   // ... and with the piece images of H0 and delta1 (BF3 = 2) for 10 (N <= 320)
 #define MF_PARK 12        // position elements parked in LDS during the tile loop ...
 #define MF_PARK_TILES 6   // ... when the data image leaves room for it (N <= 192 rows)
 
 // kernel variant (A/B knob): bit 0 = former launch shape (4-wave workgroups, one chain per wave), bit 1 = no priority
-// balancing between the two waves of a SIMD, bit 2 = no momentum parking, bit 4 = route f32 plans through the layerwise
+// balancing between the two waves of a SIMD, bit 2 = no momentum parking (exact form) / no piece
+// images (bf16x3 form: BF3 = 1 where BF3 = 2 would serve), bit 4 = route f32 plans through the layerwise
 // path, bit 5 = the layerwise path's register-staged GEMM instead of the LDS-DMA one, bit 6 = the layerwise path's
 // narrow last layer as separate launches instead of the fused tail kernel, bit 7 = the layerwise path's leapfrog update
 // as a separate kernel instead of in the gradient kernels' epilogues
@@ -1312,7 +1351,12 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
     // the other 4-32-32 models: one instantiation per mode (bf16x3 form, any prior, in-kernel tuner compiled in)
     if (!bf3) EY_FAIL(EY_ERR_UNSUPPORTED, "mfma32: this model is served in the bf16x3 form only");
     const int act = m.act[0];
-#define MF_SHAPE_LAUNCH(SHAPE) return mf_launch_v<MODE, 8, 0, false, true, true, SHAPE>(a, pl->n_cu, s)
+#define MF_SHAPE_LAUNCH(SHAPE)                                                                              \
+  do {                                                                                                     \
+    if (MODE == MODE_HMC && a.ntiles <= MF_TRD_TILES && !(t_ey_variant & 4))                               \
+      return mf_launch_v<MODE, 8, 0, false, true, MODE == MODE_HMC ? 2 : 1, SHAPE>(a, pl->n_cu, s);       \
+    return mf_launch_v<MODE, 8, 0, false, true, 1, SHAPE>(a, pl->n_cu, s);                                 \
+  } while (0)
     if (m.lik == EY_LIK_CE_SUM) {
       if (act == EY_ACT_TANH) MF_SHAPE_LAUNCH(MfShape<3 MF_COMMA EY_ACT_TANH MF_COMMA EY_LIK_CE_SUM>);
       MF_SHAPE_LAUNCH(MfShape<3 MF_COMMA EY_ACT_RELU MF_COMMA EY_LIK_CE_SUM>);
@@ -1332,6 +1376,7 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
       if (a.prior_uniform)
         return a.da_state ? mf_launch_v<MODE, 8, 0, true, true, true>(a, pl->n_cu, s)
                           : mf_launch_v<MODE, 8, 0, true, false, true>(a, pl->n_cu, s);
+      if (a.ntiles <= MF_TRD_TILES && !(variant & 4)) return mf_launch_v<MODE, 8, 0, false, true, 2>(a, pl->n_cu, s);
       return mf_launch_v<MODE, 8, 0, false, true, true>(a, pl->n_cu, s);
     }
     // the headline shape (few row tiles, one Normal(m, s) prior for all parameters) has its own, leaner instantiation
@@ -1339,6 +1384,8 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
       return a.da_state ? mf_launch_v<MODE, 8, MF_PARK, true, true>(a, pl->n_cu, s)
                         : mf_launch_v<MODE, 8, MF_PARK, true, false>(a, pl->n_cu, s);
   }
+  if (bf3 && MODE != MODE_MH && a.ntiles <= MF_TRD_TILES && !(t_ey_variant & 4))
+    return mf_launch_v<MODE, 8, 0, false, true, MODE != MODE_MH ? 2 : 1>(a, pl->n_cu, s);
   if (bf3) return mf_launch_v<MODE, 8, 0, false, true, true>(a, pl->n_cu, s);
   return mf_launch_v<MODE, 8, 0>(a, pl->n_cu, s);
 }

@@ -181,3 +181,40 @@ def test_batches_beyond_the_bf16x3_image_take_the_exact_form():
         res[mode] = pl2.log_target_grad(th)
     assert not torch.equal(res["bf16x3"][1], res["exact"][1])  # two different summation orders
     np.testing.assert_allclose(res["bf16x3"][1].cpu().numpy(), res["exact"][1].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("n_rows", [141, 320, 352])
+def test_both_layouts_of_the_bf16x3_form(n_rows):
+    """Batches of at most ten row tiles (N <= 320) run the bf16x3 form with H0 and delta1 crossing to the dW1 product as
+    bf16 pieces through transposed-read images; larger ones (and plans with variant bit 2 set) keep the f32 round trips and
+    the second pair of splits.  The two differ in the order of two piece products of dH0 and in db1's summation order only:
+    same log-targets to the last bits, gradients within a few ulp of the largest entry, the same draws; and each against the
+    f64 oracle on 24 chains at the row count given (320 = the last batch the images fit, 352 = the first they do not)."""
+    rec = _headline()
+    pl, x, y = _plan(rec, n_rows=n_rows)
+    o64 = COracle(rec["dims"].tolist(), rec["acts"].tolist(), int(rec["lik"]), np.asarray(x, np.float32).astype(np.float64), y,
+                  rec["prior_mu"], np.asarray(rec["prior_sigma"], np.float32).astype(np.float64), dtype=np.float64, nthreads=8)
+    C = 24
+    th = (0.3 * pl.philox_normal(C, seed=21, it=0)).contiguous()
+    thn = th.cpu().numpy().astype(np.float64)
+    res = {}
+    for variant in (0, 4):
+        pl.set_variant(variant)
+        t, g = pl.log_target_grad(th)
+        a = [th.clone(), t.clone(), g.clone()]
+        out = pl.hmc_step(a[0], a[1], a[2], 0.01, 6, seed=5, it=1)
+        res[variant] = (t.cpu().numpy(), g.cpu().numpy(), a[0].cpu().numpy(), out["accepted"].cpu().numpy(),
+                        out["h_prop"].cpu().numpy())
+    pl.set_variant(0)
+    for c in range(C):
+        tt, gg, _, _ = o64.log_target_grad(thn[c])
+        for variant in (0, 4):
+            np.testing.assert_allclose(res[variant][0][c], tt, rtol=2e-6, atol=2e-4)
+            np.testing.assert_allclose(res[variant][1][c], gg, rtol=1e-5, atol=2e-6 * np.abs(gg).max())
+    np.testing.assert_allclose(res[0][0], res[4][0], rtol=1e-6)
+    np.testing.assert_allclose(res[0][1], res[4][1], rtol=0, atol=4e-6 * np.abs(res[4][1]).max())
+    assert (res[0][3] == res[4][3]).all()
+    np.testing.assert_allclose(res[0][2], res[4][2], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res[0][4], res[4][4], rtol=1e-5, atol=1e-3)
+    if n_rows > 320:  # one layout serves such a batch whatever the variant says
+        assert np.array_equal(res[0][1], res[4][1]) and np.array_equal(res[0][2], res[4][2])

@@ -41,6 +41,9 @@ def both(pl, fn):
     return out
 
 
+RMS_RATIOS, FIXTURE_RATIOS = [], []
+
+
 def report(label, errs):
     """errs: {kernel: (abs error array, scale array)}"""
     row = []
@@ -49,6 +52,9 @@ def report(label, errs):
         r = e / sc
         row.append((r.max(), np.sqrt((r ** 2).mean())))
     ratio = row[1][0] / max(row[0][0], 1e-300)
+    RMS_RATIOS.append(row[1][1] / max(row[0][1], 1e-300))
+    if label.startswith("G"):
+        FIXTURE_RATIOS.append(ratio)
     print(f"{label:58s} exact max {row[0][0]:.3e} rms {row[0][1]:.3e} | bf16x3 max {row[1][0]:.3e} rms {row[1][1]:.3e} "
           f"| max ratio {ratio:.2f}")
     return ratio
@@ -130,7 +136,10 @@ def main():
     for i, (nm, tr) in enumerate((("theta_L", thL), ("p_L", pL), ("gradient", gL))):
         worst = max(worst, report(f"256 trajectories, L = 20, step 0.024: {nm}",
                                   {k: (np.abs(v[i] - tr), np.abs(tr).max(1, keepdims=True) + 0 * tr) for k, v in res.items()}))
-    print(f"worst ratio of maximum errors, bf16x3 / exact: {worst:.2f}  (bar: <= 1.5)")
+    print(f"worst ratio of maximum errors, bf16x3 / exact: {worst:.2f}  (bar: <= 1.5); on the G2 / G3 fixtures alone "
+          f"{max(FIXTURE_RATIOS):.2f}; worst ratio of rms errors {max(RMS_RATIOS):.2f}\n"
+          "(the maxima over 256 chaotic trajectories of 20 steps are order statistics of a few hundred thousand elements: the\n"
+          " rms columns are the stable comparison)")
     return 0 if worst <= 1.5 else 1
 
 
