@@ -115,25 +115,59 @@ struct Nm;
 template <>
 struct Nm<float> {
   static __device__ __forceinline__ float exp(float v) { return __expf(v); }  // v_exp_f32 / v_log_f32, as ey_mfma32.hip
+  static __device__ __forceinline__ float exp_fast(float v) { return __expf(v); }
   static __device__ __forceinline__ float log(float v) { return __logf(v); }
   static __device__ __forceinline__ float tanh(float v) { return tanhf(v); }
   static __device__ __forceinline__ float sqrt(float v) { return sqrtf(v); }
 };
+// exp in f64 for the activations and the softmax: n = rint(x log2 e), r = x - n ln 2 in two pieces (|r| <= 0.3466), the
+// Taylor polynomial of degree 13 (remainder 4e-18 relative), v_ldexp_f64 (which overflows to inf and underflows through
+// the denormals to 0 as exp does; v_cvt_i32_f64 saturates; NaN passes through): 19 instructions where the library's takes
+// about 45, accurate to a few ulp -- the reference's f64 values to 1e-10 need 1e5 times less.
+__device__ __forceinline__ double f16_exp_f64(double x) {
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = __builtin_fma(p, r, 1.0 / 479001600.0);
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
 template <>
 struct Nm<double> {
   static __device__ __forceinline__ double exp(double v) { return ::exp(v); }
+  static __device__ __forceinline__ double exp_fast(double v) { return f16_exp_f64(v); }
   static __device__ __forceinline__ double log(double v) { return ::log(v); }
   static __device__ __forceinline__ double tanh(double v) { return ::tanh(v); }
   static __device__ __forceinline__ double sqrt(double v) { return ::sqrt(v); }
 };
-// sigmoid and tanh.  f64: the library functions, as the generic kernels (1e-10 parity with the reference's fp64).  f32:
+// 1 / d for d in [1, inf] in f64: v_rcp_f64 and two Newton steps (five instructions, ~1 ulp) where the IEEE division is
+// thirteen; d is capped so that an overflowed exp gives 1e-300, not the NaN of inf * 0.
+__device__ __forceinline__ double f16_recip_ge1(double d) {
+  d = fmin(d, 1e300);
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  return __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+}
+// sigmoid and tanh.  f64: the library exp / tanh, as the generic kernels (1e-10 parity with the reference's fp64).  f32:
 // one v_exp_f32 and one v_rcp_f32 per element, as ey_mfma32.hip (an IEEE division is ten vector instructions, and f32
 // MFMA shares the vector ALUs with them); both are accurate to ~1 ulp, far inside the stated 2e-4.
 template <typename T>
 __device__ __forceinline__ T f16_sigmoid(T g) {
   if (F16_ABLATE & 1) return T(0.25) * g + T(0.5);
   if constexpr (sizeof(T) == 4) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
-  else return T(1) / (T(1) + Nm<T>::exp(-g));
+  else return f16_recip_ge1(T(1) + Nm<T>::exp_fast(-g));
 }
 template <typename T>
 __device__ __forceinline__ T f16_tanh(T g) {
@@ -365,7 +399,7 @@ __device__ __forceinline__ v4<T> f16_ld4(const T* p) {
 template <typename T, int H, int V, typename A>
 __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>::NREG],
                                       T (&gr)[F16Cfg<H>::NREG], const bool GRAD, bool has_temp, T temp, int c, int g,
-                                      int lane, T* lik_out = nullptr, T* prior_out = nullptr) {
+                                      int lane, T* lik_out = nullptr, T* prior_out = nullptr, const bool need_value = true) {
   typedef F16Cfg<H, (V & 2) ? 4 : 2> K;
   typedef Lay<T> L;
   constexpr int MT = K::MT;
@@ -461,17 +495,29 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
       for (int o = 1; o < 4; ++o)
         if (o < a.dK) mx = fmax(mx, lg[o]);
-      T ssum = T(0), llab = T(0);
+      T e[4], ssum = T(0), llab = T(0);
+      if constexpr (sizeof(T) == 8) {
+        // the library exp is ~50 f64 instructions: lane group g takes output g of its row, the four groups exchange
+        const T mine_lg = g == 0 ? lg[0] : (g == 1 ? lg[1] : (g == 2 ? lg[2] : lg[3]));
+        const T e_own = g < a.dK ? Nm<T>::exp_fast(mine_lg - mx) : T(0);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) e[o] = __shfl(e_own, c + 16 * o, 64);
+      } else {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) e[o] = o < a.dK ? Nm<T>::exp(lg[o] - mx) : T(0);
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        ssum += e[o];  // (zero beyond dK)
+        if (o == lab) llab = lg[o];
+      }
+      if (need_value && mine) lik += llab - (mx + Nm<T>::log(ssum));
+      T inv;
+      if constexpr (sizeof(T) == 8) inv = f16_recip_ge1(ssum);  // the largest term is exp(0)
+      else inv = T(1) / ssum;
 #pragma unroll
       for (int o = 0; o < 4; ++o)
-        if (o < a.dK) {
-          ssum += Nm<T>::exp(lg[o] - mx);
-          if (o == lab) llab = lg[o];
-        }
-      if (mine) lik += llab - (mx + Nm<T>::log(ssum));
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (o < a.dK && mine) d2[o] = (o == lab ? T(1) : T(0)) - Nm<T>::exp(lg[o] - mx) / ssum;
+        if (o < a.dK && mine) d2[o] = (o == lab ? T(1) : T(0)) - e[o] * inv;
     } else {
 #pragma unroll
       for (int o = 0; o < 4; ++o)
@@ -479,9 +525,8 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
           const T pr = f16_act<T>(EY_ACT_SIGMOID, lg[o]);
           const T yy = xt[off_y + o * 16 + c];
           // naive logs exactly as eeyore/stats/loss.py:2 (NaN once a sigmoid saturates)
-          const T term = Nm<T>::log(pr) * yy + Nm<T>::log(T(1) - pr) * (T(1) - yy);
+          if (need_value && mine) lik += Nm<T>::log(pr) * yy + Nm<T>::log(T(1) - pr) * (T(1) - yy);
           if (mine) {
-            lik += term;
             d2[o] = (yy / pr - (T(1) - yy) / (T(1) - pr)) * f16_dact<T>(EY_ACT_SIGMOID, pr);
           }
         }
@@ -619,8 +664,11 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
       }
     }
   }
-  lik = f16_wsum(lik);
-  T prior = a.prior_const - T(0.5) * f16_wsum(qsum);
+  T prior = T(0);
+  if (need_value) {
+    lik = f16_wsum(lik);
+    prior = a.prior_const - T(0.5) * f16_wsum(qsum);
+  }
   if (has_temp) { lik *= temp; prior *= temp; }
   if (lik_out) *lik_out = lik;
   if (prior_out) *prior_out = prior;
@@ -789,7 +837,9 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
       F16_EACH(k) th[k] = th[k] + eps * p[k];
     }
     f16_write_images<T, H, (V & 2) ? 4 : 2>(lw, th, a, c, g);
-    t = f16_eval<T, H, V>(a, lw, th, gr, true, has_temp, temp, c, g, lane);
+    // (inside a trajectory only the gradient is consumed, hmc.py:108-121: the value-only work -- the logs of the
+    // likelihood terms -- runs at the end point alone)
+    t = f16_eval<T, H, V>(a, lw, th, gr, true, has_temp, temp, c, g, lane, nullptr, nullptr, kk == a.L);
     const T w = (kk > 0 && kk < a.L) ? eps : T(0.5) * eps;
     F16_EACH(k) p[k] = p[k] + w * gr[k];
   }
