@@ -336,16 +336,17 @@ __device__ __forceinline__ F16Slot f16_slot(int k, const A& a, int c, int g, int
   }
   if (k < K::S_B0) {
     const int f = 16 * (k - K::S_B1) + c;
-    const bool v = !TWO && (!PAD || f < h2);
+    const bool v = !TWO && (!PAD || (f < h2 && a.iB1 >= 0));  // (a layer without a bias, mlp.py:40-42: its slots hold nothing)
     return {a.iB1 + f, v, v && g == 0};
   }
   if (k < K::S_B2) {
     const int f = 16 * (k - K::S_B0) + c;
-    const bool v = !PAD || f < h1;
+    const bool v = !PAD || (f < h1 && a.iB0 >= 0);
     return {a.iB0 + f, v, v && g == 0};
   }
   const int o = k - K::S_B2;
-  return {a.iB2 + o, o < a.dK, lane == 0 && o < a.dK};
+  const bool v = o < a.dK && (!PAD || a.iB2 >= 0);
+  return {a.iB2 + o, v, lane == 0 && v};
 }
 #define F16_EACH(k) _Pragma("unroll") for (int k = 0; k < K::NREG; ++k)
 
@@ -966,8 +967,6 @@ bool ey_fused16_supports(const ey_plan* pl) {
   const int Hp = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
   if (8 * h1 * h2 < Hp * Hp) return false;
   if (m.dims[0] < 1 || m.dims[0] > 16 || m.dims[K] < 1 || m.dims[K] > 4) return false;
-  for (int l = 0; l < K; ++l)
-    if (!m.bias[l]) return false;
   for (int l = 0; l < K - 1; ++l)
     if (m.act[l] != EY_ACT_SIGMOID && m.act[l] != EY_ACT_TANH && m.act[l] != EY_ACT_RELU) return false;
   if (m.lik == EY_LIK_CE_SUM && m.act[K - 1] != EY_ACT_NONE) return false;
@@ -1019,7 +1018,8 @@ template <typename T, int H, int WAVES>
 static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   // (the exact 64-wide shape also takes the PAD instantiation: its register allocation happens to come out 19 % faster,
   // 8.7e6 against 7.3e6 leapfrog-steps/s x chains on MLP(4-64-64-3), same session)
-  const bool pad = a.h1 != H || a.h2 != H || H == 64 || a.d0 > 8;  // (more than 8 inputs: the padded forms' four k-steps)
+  // (more than 8 inputs: the padded forms' four k-steps; a layer without a bias: its slots are padding slots)
+  const bool pad = a.h1 != H || a.h2 != H || H == 64 || a.d0 > 8 || a.iB0 < 0 || a.iB2 < 0 || (!a.two && a.iB1 < 0);
   switch ((a.two ? 1 : 0) | (pad ? 2 : 0)) {
     case 0: return f16_launch_t<T, H, WAVES, 0>(a, n_cu, s);
     case 1: return f16_launch_t<T, H, WAVES, 1>(a, n_cu, s);
@@ -1034,7 +1034,7 @@ static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
   const int K = m.nl;
   a.two = K == 2;
   a.d0 = m.dims[0]; a.dK = m.dims[K]; a.act0 = m.act[0]; a.act1 = a.two ? m.act[0] : m.act[1]; a.lik = m.lik; a.P = m.P;
-  a.iW0 = m.woff[0]; a.iB0 = m.boff[0]; a.iW1 = a.two ? 0 : m.woff[1]; a.iB1 = a.two ? 0 : m.boff[1];
+  a.iW0 = m.woff[0]; a.iB0 = m.boff[0]; a.iW1 = a.two ? 0 : m.woff[1]; a.iB1 = a.two ? 0 : m.boff[1];  // (-1: no bias)
   a.iW2 = m.woff[K - 1]; a.iB2 = m.boff[K - 1];
   a.xpack = (const T*)pl->d_xpack16;
   a.ntiles = (m.N + 15) / 16;

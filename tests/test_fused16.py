@@ -255,3 +255,64 @@ def test_fused16_serves_the_reference_models_in_f64():
         np.testing.assert_allclose(t.item(), rec["target"], rtol=1e-9)
         m += 1
     assert m >= 2
+
+
+@pytest.mark.parametrize("dims,bias,acts,lik,tag,N", [
+    ([4, 32, 32, 3], [0, 1, 0], [1, 1, 0], 1, "f32", 150),   # the headline widths without two of the biases
+    ([4, 16, 16, 3], [0, 0, 0], [1, 2, 0], 1, "f64", 77),    # no bias anywhere (the reference's tests build such nets)
+    ([6, 20, 24, 2], [1, 0, 1], [2, 1, 0], 1, "f64", 40),    # off the tile grid as well
+    ([4, 32, 32, 1], [0, 0, 1], [3, 1, 1], 0, "f32", 90),    # BCE head
+    ([5, 20, 3], [1, 0], [1, 0], 1, "f64", 33),              # one hidden layer
+    ([3, 64, 64, 4], [0, 1, 0], [1, 1, 0], 1, "f32", 45),
+])
+def test_fused16_layers_without_bias(dims, bias, acts, lik, tag, N):
+    """mlp.py:36-43 builds a layer with or without a bias (`bias=[...]`): the fused kernels hold the missing biases as
+    padding slots (theta 0, gradient masked, no momentum).  Value, gradient, leapfrog and an HMC draw against the C oracle
+    built with the same flags; P counts no bias of such a layer."""
+    from eeyore_amd.plan import Plan
+    npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    rng = np.random.default_rng(sum(dims) + N + 17)
+    x = rng.standard_normal((N, dims[0]))
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(np.float64)
+    P = sum((dims[l] + bias[l]) * dims[l + 1] for l in range(len(dims) - 1))
+    mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
+    pl = Plan(dims, bias, acts, lik, dt, DEV)
+    pl.f32_products = "exact"
+    pl.set_data(_t(x, dt), _t(y, dt))
+    pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
+    assert pl.kernel == "fused16" and pl.P == P
+    co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, bias=bias, nthreads=4)
+    C = 9
+    th0 = (0.3 * rng.standard_normal((C, P))).astype(npdt)
+    tol = 1e-10 if tag == "f64" else 2e-4
+    t, g = pl.log_target_grad(_t(th0, dt))
+    for c in range(C):
+        to, go, _, _ = co.log_target_grad(th0[c])
+        gs = max(1.0, float(np.abs(go).max()))
+        np.testing.assert_allclose(t[c].item(), to, rtol=tol, atol=tol * 10)
+        np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=tol * 10, atol=tol * gs)
+    p0 = rng.standard_normal((C, P)).astype(npdt); u = rng.random(C).astype(npdt)
+    th, p = _t(th0, dt).clone(), _t(p0, dt).clone()
+    tl, _ = pl.leapfrog(th, p, 0.01, 4)
+    for c in range(0, C, 2):
+        tho, po_, to, _ = co.leapfrog(th0[c], p0[c], 0.01, 4)
+        np.testing.assert_allclose(th[c].cpu().numpy(), tho, rtol=tol * 10, atol=tol)
+        np.testing.assert_allclose(p[c].cpu().numpy(), po_, rtol=tol * 50, atol=tol * 50)
+        np.testing.assert_allclose(tl[c].item(), to, rtol=tol * 5, atol=tol * 20)
+    th, tv, gg = _t(th0, dt).clone(), t.clone(), g.clone()
+    out = pl.hmc_step(th, tv, gg, 0.01, 5, p0=_t(p0, dt), u=_t(u, dt))
+    tho, tvo, go = th0.copy(), t.cpu().numpy().astype(npdt), g.cpu().numpy().astype(npdt)
+    acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, 0.01, 5)
+    rate = np.minimum(np.exp(np.minimum(hc - hp, 0)), 1)
+    decided = np.abs(u - rate) > (1e-8 if tag == "f64" else 5e-3)
+    np.testing.assert_array_equal(out["accepted"].cpu().numpy()[decided], acc[decided])
+    np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=tol * 10, atol=tol * 100)
+    same = out["accepted"].cpu().numpy() == acc
+    np.testing.assert_allclose(th.cpu().numpy()[same], tho[same], rtol=tol * 10, atol=tol)
+    # in-kernel Philox momentum: a block of iterations == consecutive steps (no momentum leaks into a padding slot)
+    a = [th.clone(), tv.clone(), gg.clone()]
+    b = [th.clone(), tv.clone(), gg.clone()]
+    pl.hmc_run(a[0], a[1], a[2], 0.01, 3, 2, seed=4, it=7)
+    for i in range(2):
+        pl.hmc_step(b[0], b[1], b[2], 0.01, 3, seed=4, it=7 + i)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
