@@ -291,11 +291,12 @@ struct F16Cfg {
   static constexpr int O_TB1 = O_TB0 + H * F16_TS;      // [H][TS] transpose buffer: H0
   static constexpr int O_W0A = O_TB1 + H * F16_TS;      // [m][s < KSM][lane]: A operands of F0 (up to 4 KSM inputs)
   static constexpr int O_W2A = O_W0A + MT * KSM * 64;   // [m][r][lane]: A operands of the logits
-  static constexpr int O_W2T = O_W2A + MT * 4 * 64;     // [m][lane]: A operands of dH1
-  static constexpr int O_B0 = O_W2T + MT * 64;          // [H]
+  // (the padded configuration, KSM = 4, also serves 5 .. 16 outputs: four k-steps of dH1 and a whole delta2 tile)
+  static constexpr int O_W2T = O_W2A + MT * 4 * 64;     // [m][lane] ([m][s][lane]): A operands of dH1
+  static constexpr int O_B0 = O_W2T + MT * 64 * (KSM == 4 ? 4 : 1);  // [H]
   static constexpr int O_B1 = O_B0 + H;                 // [H]
-  static constexpr int O_D2 = O_B1 + H;                 // [4][16] delta2[o][row]
-  static constexpr int WAVE_ELEMS = O_D2 + 64;
+  static constexpr int O_D2 = O_B1 + H;                 // [4][16] delta2[o][row]  ([16][TS] transpose buffer of the delta2 tile)
+  static constexpr int WAVE_ELEMS = O_D2 + (KSM == 4 ? 16 * F16_TS : 64);
   // the N(0,1) stream of a draw is staged in [O_W1A, O_W0A) between evaluations: P <= H^2 + 14 H + 4 <= H^2 + 40 H
   static_assert(H * H + 14 * H + 4 <= O_W0A, "the staging area must hold P normals");
 };
@@ -345,6 +346,11 @@ __device__ __forceinline__ F16Slot f16_slot(int k, const A& a, int c, int g, int
     return {a.iB0 + f, v, v && g == 0};
   }
   const int o = k - K::S_B2;
+  if (PAD && a.dK > 4) {  // more than four outputs: slot r holds b2[fi(g, r)], the D layout of the logits tile
+    const int cls = Lay<T>::fi(g, o);
+    const bool v = cls < a.dK && a.iB2 >= 0;
+    return {a.iB2 + cls, v, v && c == 0};
+  }
   const bool v = o < a.dK && (!PAD || a.iB2 >= 0);
   return {a.iB2 + o, v, lane == 0 && v};
 }
@@ -376,7 +382,10 @@ __device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>:
     const int r = k & 3, n = k >> 2, o = L::fi(g, r);
     if (o < a.dK) {
       lw[K::O_W2A + (n * 4 + rk) * 64 + o + 16 * gk] = th[K::S_W2 + k];  // logits: A lane (o, gk), k-step (n, rk)
-      lw[K::O_W2T + n * 64 + c + 16 * o] = th[K::S_W2 + k];              // dH1: A lane (f & 15, k-slot o)
+      if (KSM == 4 && a.dK > 4)  // dH1 over four k-steps: k-step s, k-slot g' <-> output fi(g', s), which is (r, g) here
+        lw[K::O_W2T + (n * 4 + r) * 64 + c + 16 * g] = th[K::S_W2 + k];
+      else
+        lw[K::O_W2T + n * 64 + c + 16 * o] = th[K::S_W2 + k];            // dH1: A lane (f & 15, k-slot o)
     }
   }
   if (g == 0) {  // bias images in the order a vector read at 4g hands out the features fi(g, 0..3)
@@ -472,26 +481,59 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
     }
     // ---- output layer: logits[o][row c] = W2 H1^T + b2 comes out in register r of lane group g with fi(g, r) = o;
     // every lane then fetches the dK logits of its row c, so all four groups carry the same softmax
+    // WIDE (the padded instantiations, 5 .. 16 outputs, CE): the whole 16 x 16 logits tile is live -- register r of lane
+    // (c, g) is output fi(g, r) of row c -- and the softmax, delta2 and the products that consume it work on the tile
+    const bool WIDE = (V & 2) != 0 && a.dK > 4;  // wave-uniform
     v4<T> lacc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = L::fi(g, r);  // < 4 only for one (g, r) pair per output: a select, not an indexed read
-      lacc[r] = o >= a.dK ? T(0) : (o == 0 ? b2v[0] : (o == 1 ? b2v[1] : (o == 2 ? b2v[2] : b2v[3])));
+      lacc[r] = WIDE ? th[K::S_B2 + r]
+                     : (o >= a.dK ? T(0) : (o == 0 ? b2v[0] : (o == 1 ? b2v[1] : (o == 2 ? b2v[2] : b2v[3]))));
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) lacc = mfma16s<T>(lw[K::O_W2A + (m * 4 + r) * 64 + lane], H1[m][r], lacc);
     T lg[4];
+    if (!WIDE) {
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {  // o = fi(go, ro): f32 (0, o), f64 (o, 0)
-      const int go = sizeof(T) == 8 ? o : 0, ro = sizeof(T) == 8 ? 0 : o;
-      lg[o] = __shfl(lacc[ro], c + 16 * go, 64);
+      for (int o = 0; o < 4; ++o) {  // o = fi(go, ro): f32 (0, o), f64 (o, 0)
+        const int go = sizeof(T) == 8 ? o : 0, ro = sizeof(T) == 8 ? 0 : o;
+        lg[o] = __shfl(lacc[ro], c + 16 * go, 64);
+      }
     }
     // ---- log-likelihood and the output delta                                (constants.py:15-18, loss.py:1-11)
-    T d2[4] = {T(0), T(0), T(0), T(0)};
+    T d2[4] = {T(0), T(0), T(0), T(0)};  // WIDE: the delta2 tile (register r = output fi(g, r)), in every lane group
     const bool mine = valid && g == 0;
-    if (a.lik == EY_LIK_CE_SUM) {
+    if (WIDE) {
+      // row maximum, sum of exponentials and the label's logit: over the lane's four outputs, then over the four lane
+      // groups of the row (two exchange rounds each); one exp per live (output, row) pair, no redundancy
+      T mx = T(-1e300);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (L::fi(g, r) < a.dK) mx = fmax(mx, lacc[r]);
+      mx = fmax(mx, __shfl_xor(mx, 16, 64));
+      mx = fmax(mx, __shfl_xor(mx, 32, 64));
+      T e[4], ssum = T(0), llab = T(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = L::fi(g, r);
+        e[r] = o < a.dK ? Nm<T>::exp_fast(lacc[r] - mx) : T(0);
+        ssum += e[r];
+        if (o == lab) llab = lacc[r];
+      }
+      ssum = f16_gsum(ssum);
+      if (need_value) {
+        llab = f16_gsum(llab);
+        if (mine) lik += llab - (mx + Nm<T>::log(ssum));
+      }
+      T inv;
+      if constexpr (sizeof(T) == 8) inv = f16_recip_ge1(ssum);
+      else inv = T(1) / ssum;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d2[r] = valid ? ((L::fi(g, r) == lab ? T(1) : T(0)) - e[r] * inv) : T(0);
+    } else if (a.lik == EY_LIK_CE_SUM) {
       T mx = lg[0];
 #pragma unroll
       for (int o = 1; o < 4; ++o)
@@ -533,6 +575,35 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
         }
     }
     if (!GRAD) continue;
+    v4<T> D1[MT];
+    if (WIDE) {
+      // db2 summed in the tile layout (reduced over the rows once per evaluation); the tile itself to its transpose buffer
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        db2[r] += d2[r];
+        lw[K::O_D2 + L::fi(g, r) * F16_TS + pc] = d2[r];
+      }
+      f16_fence();
+      // ---- dH1^T = W2^T delta2^T over four k-steps (k-step s, k-slot g <-> output fi(g, s): B = register s of the tile)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        v4<T> acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          if (sizeof(T) == 4 || 4 * s4 < a.dK)  // (f64: k-step s holds outputs 4s .. 4s+3)
+            acc = mfma16s<T>(lw[K::O_W2T + (m * 4 + s4) * 64 + lane], d2[s4], acc);
+        D1[m] = acc;
+      }
+      f16_dact_tiles<T, MT>(a.act1, D1, H1);
+      // ---- dW2[o][f] += sum_n delta2[n][o] H1[n][f]: lane c of the U tile is output c (rows of outputs >= dK are zero)
+      const v4<T> d2u = f16_ld4(lw + K::O_D2 + c * F16_TS + 4 * g);
+#pragma unroll
+      for (int n = 0; n < MT; ++n) {
+        const v4<T> h1u = f16_ld4(lw + K::O_TB0 + (16 * n + c) * F16_TS + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dW2[n] = mfma16s<T>(d2u[r], h1u[r], dW2[n]);
+      }
+    } else {
     if (g == 0) {
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
@@ -546,7 +617,6 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
     for (int o = 0; o < 4; ++o) d2all[o] = __shfl(d2[o], c, 64);
     const T d2b = g == 0 ? d2all[0] : (g == 1 ? d2all[1] : (g == 2 ? d2all[2] : d2all[3]));  // delta2[row c][o = g]
-    v4<T> D1[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) D1[m] = mfma16s<T>(lw[K::O_W2T + m * 64 + lane], d2b, v4<T>{0, 0, 0, 0});
     f16_dact_tiles<T, MT>(a.act1, D1, H1);
@@ -559,6 +629,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
         for (int r = 0; r < 4; ++r) dW2[n] = mfma16s<T>(c < 4 ? d2u[r] : T(0), h1u[r], dW2[n]);
       }
+    }
     }
     f16_fence();  // H1^T has been read: its buffer takes delta1^T
 #pragma unroll
@@ -627,8 +698,21 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
       gr[K::S_B1 + m] = f16_gsum(db1[m]);
       gr[K::S_B0 + m] = f16_gsum(db0[m]);
     }
+    if ((V & 2) != 0 && a.dK > 4) {
+      // the tile-layout sums over the rows: the 16 lanes of a lane group (DPP row reductions), total in every lane
 #pragma unroll
-    for (int o = 0; o < 4; ++o) gr[K::S_B2 + o] = f16_wsum(db2[o]);
+      for (int r = 0; r < 4; ++r) {
+        T v = db2[r];
+        v += f16_dpp<0xB1, 0xF>(v);
+        v += f16_dpp<0x4E, 0xF>(v);
+        v += f16_dpp<0x141, 0xF>(v);
+        v += f16_dpp<0x140, 0xF>(v);
+        gr[K::S_B2 + r] = v;
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) gr[K::S_B2 + o] = f16_wsum(db2[o]);
+    }
   }
   // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
   T qsum = T(0);
@@ -966,7 +1050,8 @@ bool ey_fused16_supports(const ey_plan* pl) {
   // same bound on the width squared
   const int Hp = H <= 16 ? 16 : (H <= 32 ? 32 : 64);
   if (8 * h1 * h2 < Hp * Hp) return false;
-  if (m.dims[0] < 1 || m.dims[0] > 16 || m.dims[K] < 1 || m.dims[K] > 4) return false;
+  // up to 16 outputs under CE-sum (the padded instantiations' whole delta2 tile), up to 4 under BCE-sum
+  if (m.dims[0] < 1 || m.dims[0] > 16 || m.dims[K] < 1 || m.dims[K] > (m.lik == EY_LIK_CE_SUM ? 16 : 4)) return false;
   for (int l = 0; l < K - 1; ++l)
     if (m.act[l] != EY_ACT_SIGMOID && m.act[l] != EY_ACT_TANH && m.act[l] != EY_ACT_RELU) return false;
   if (m.lik == EY_LIK_CE_SUM && m.act[K - 1] != EY_ACT_NONE) return false;
@@ -1019,7 +1104,7 @@ static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   // (the exact 64-wide shape also takes the PAD instantiation: its register allocation happens to come out 19 % faster,
   // 8.7e6 against 7.3e6 leapfrog-steps/s x chains on MLP(4-64-64-3), same session)
   // (more than 8 inputs: the padded forms' four k-steps; a layer without a bias: its slots are padding slots)
-  const bool pad = a.h1 != H || a.h2 != H || H == 64 || a.d0 > 8 || a.iB0 < 0 || a.iB2 < 0 || (!a.two && a.iB1 < 0);
+  const bool pad = a.h1 != H || a.h2 != H || H == 64 || a.d0 > 8 || a.iB0 < 0 || a.iB2 < 0 || (!a.two && a.iB1 < 0) || a.dK > 4;
   switch ((a.two ? 1 : 0) | (pad ? 2 : 0)) {
     case 0: return f16_launch_t<T, H, WAVES, 0>(a, n_cu, s);
     case 1: return f16_launch_t<T, H, WAVES, 1>(a, n_cu, s);

@@ -35,6 +35,13 @@ CASES = [
     ([5, 50, 30, 2], [1, 2, 0], 1, "f32", 77),
     ([3, 7, 12, 1], [2, 1, 1], 0, "f64", 40),     # 7 x 12 = 84 >= 256 / 8: still worth the 16 x 16 grid
     ([6, 33, 64, 4], [1, 3, 0], 1, "f32", 45),
+    # five to sixteen outputs under CE-sum (ten-class nets): the whole delta2 tile, four k-steps of dH1
+    ([8, 32, 32, 10], [1, 1, 0], 1, "f32", 150),
+    ([8, 32, 32, 10], [2, 1, 0], 1, "f64", 77),
+    ([4, 16, 16, 5], [1, 1, 0], 1, "f64", 33),
+    ([6, 64, 48, 16], [3, 1, 0], 1, "f32", 90),
+    ([5, 20, 7], [1, 0], 1, "f64", 49),
+    ([16, 24, 12], [2, 0], 1, "f32", 20),
     # one hidden layer: the kernel's middle layer is skipped
     ([4, 16, 3], [1, 0], 1, "f64", 150),
     ([8, 32, 2], [2, 0], 1, "f32", 77),
@@ -45,7 +52,7 @@ CASES = [
 
 def _random_cases(n, seed=2024):
     """Shapes the fused kernels take, drawn at random: hidden widths on and off the 16 / 32 / 64 tile grid (within the
-    dispatcher's padding limit), d0 <= 16, dK <= 4, every hidden activation, CE or BCE, f32 or f64 (f64: widths <= 32)."""
+    dispatcher's padding limit), d0 <= 16, dK <= 4 (BCE) or <= 16 (CE), every hidden activation, CE or BCE, f32 or f64 (f64: widths <= 32)."""
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
@@ -56,7 +63,7 @@ def _random_cases(n, seed=2024):
         if 8 * h1 * h2 < hp * hp:
             continue
         lik = int(rng.integers(0, 2))
-        dK = int(rng.integers(1, 5)) if lik == 0 else int(rng.integers(2, 5))
+        dK = int(rng.integers(1, 5)) if lik == 0 else int(rng.choice([2, 3, 4, 4, 5, 7, 10, 16]))
         if rng.random() < 0.35:   # one hidden layer (the kernel's middle layer is skipped)
             if 8 * h1 * h1 < (16 if h1 <= 16 else (32 if h1 <= 32 else 64)) ** 2:
                 continue

@@ -7,9 +7,15 @@ from eeyore_amd.datasets import synthetic
 from eeyore_amd.plan import Plan
 dev = torch.device('cuda', 0)
 xs, ys = synthetic.iris_shaped_arrays(seed=0)
-for dims, tdt in (([4, 32, 32, 3], torch.float64), ([4, 64, 64, 3], torch.float32)):
+CASES = [([4, 32, 32, 3], torch.float64), ([4, 64, 64, 3], torch.float32)]
+if len(sys.argv) > 1 and sys.argv[1] == '--wide':  # ten-class heads (the padded forms' whole delta2 tile)
+    CASES = [([8, 32, 32, 10], torch.float32), ([8, 32, 32, 10], torch.float64), ([8, 64, 64, 10], torch.float32)]
+for dims, tdt in CASES:
     pl = Plan(dims, [1, 1, 1], [1, 1, 0], 1, tdt, dev)
-    pl.set_data(torch.tensor(xs, dtype=tdt, device=dev), torch.tensor(ys, dtype=tdt, device=dev))
+    rng = np.random.default_rng(1)
+    xd = rng.standard_normal((150, dims[0])) if dims[0] != 4 else xs
+    yd = np.eye(dims[-1])[rng.integers(0, dims[-1], 150)] if dims[-1] != 3 else ys
+    pl.set_data(torch.tensor(xd, dtype=tdt, device=dev), torch.tensor(yd, dtype=tdt, device=dev))
     pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), float(np.sqrt(3.0))))
     C = 4096
     th = 0.1 * pl.philox_normal(C, seed=0, it=0)
