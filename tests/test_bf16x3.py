@@ -218,3 +218,31 @@ def test_both_layouts_of_the_bf16x3_form(n_rows):
     np.testing.assert_allclose(res[0][4], res[4][4], rtol=1e-5, atol=1e-3)
     if n_rows > 320:  # one layout serves such a batch whatever the variant says
         assert np.array_equal(res[0][1], res[4][1]) and np.array_equal(res[0][2], res[4][2])
+
+
+@pytest.mark.parametrize("n_rows", [1, 8, 24, 25, 32, 33, 56, 57, 64, 96, 129, 160])
+def test_row_counts_around_the_tile_edges(n_rows):
+    """One row to five tiles, with last tiles of every kind (full, more than 24 rows, at most 24 rows: the peeled copy whose
+    fourth 8-row k-group is all padding): value and gradient of both product forms against the f64 oracle, and a fused HMC
+    draw with in-kernel momentum that is the same in a block of iterations and in single launches."""
+    rec = _headline()
+    pl, x, y = _plan(rec, n_rows=n_rows)
+    o64 = COracle(rec["dims"].tolist(), rec["acts"].tolist(), int(rec["lik"]), np.asarray(x, np.float32).astype(np.float64), y,
+                  rec["prior_mu"], np.asarray(rec["prior_sigma"], np.float32).astype(np.float64), dtype=np.float64, nthreads=8)
+    C = 16
+    th = (0.5 * pl.philox_normal(C, seed=31 + n_rows, it=0)).contiguous()
+    thn = th.cpu().numpy().astype(np.float64)
+    for mode in MODES:
+        pl.f32_products = mode
+        t, g = pl.log_target_grad(th)
+        for c in range(C):
+            tt, gg, _, _ = o64.log_target_grad(thn[c])
+            np.testing.assert_allclose(t[c].item(), tt, rtol=2e-6, atol=2e-4)
+            np.testing.assert_allclose(g[c].cpu().numpy(), gg, rtol=1e-5, atol=2e-6 * max(1.0, np.abs(gg).max()))
+        a = [th.clone(), t.clone(), g.clone()]
+        b = [th.clone(), t.clone(), g.clone()]
+        pl.hmc_run(a[0], a[1], a[2], 0.01, 4, 3, seed=6, it=2)
+        for i in range(3):
+            pl.hmc_step(b[0], b[1], b[2], 0.01, 4, seed=6, it=2 + i)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert torch.isfinite(a[1]).all()
