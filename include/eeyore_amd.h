@@ -85,8 +85,10 @@ int ey_plan_destroy(ey_plan* plan);
 /* Model.num_params (eeyore/models/model.py:34-36) */
 int ey_plan_num_params(const ey_plan* plan, int64_t* P);
 /* name of the kernel family that serves ey_hmc_step for this plan: "mfma32" (fused f32 trajectory, 4-32-32-dK), "fused16"
- * (fused 16x16x4 trajectory, f32 and f64), "bgemm" (layerwise batched GEMMs for models beyond LDS, f32 and f64) or
- * "generic" */
+ * (fused 16x16x4 trajectory, f32 and f64: one or two hidden layers of at most 64 units (32 in f64), at most 16 inputs,
+ * CE-sum on at most 16 logits or BCE-sum on at most 4 sigmoid outputs, every layer with or without a bias), "bgemm"
+ * (layerwise batched GEMMs for models beyond LDS and for wide ones that fit, f32 and f64) or "generic" (anything mlp.py
+ * builds) */
 const char* ey_plan_kernel(const ey_plan* plan);
 int ey_plan_set_option(ey_plan* plan, int option, int value);
 int ey_plan_get_option(const ey_plan* plan, int option, int* value);
