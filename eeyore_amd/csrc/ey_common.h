@@ -85,6 +85,10 @@ struct ey_plan {
   // layerwise batched-GEMM path for models whose parameters do not fit LDS (ey_large.hip): workspace it owns
   void* d_work;
   size_t work_bytes;
+  // ... and the data matrix split into bf16 pieces once per batch, in both orientations (ey_large.hip: ensure_xpre)
+  void* d_xpre = nullptr;
+  size_t xpre_bytes = 0;
+  uint64_t data_version = 0, xpre_version = ~0ull;  // ey_plan_set_data counts; the images remember which batch they hold
 };
 
 // The diagnostic switches of the plan a C-ABI call is serving, for the dispatch code below the entry points (thread-local:

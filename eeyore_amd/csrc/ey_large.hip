@@ -49,6 +49,11 @@ struct BGT {
   const T* lf_step_vec;
   T lf_step, lf_wp, lf_wt;
   int lf_slot0, lf_nslots, lf_store_g;
+  // bf16x3 form: an A operand the whole batch shares (the data matrix x in the first layer's forward product) already
+  // split into its three bf16 pieces, in the staging image's own order [k-chunk][piece][row][2 granules] x 16 bytes
+  // (k_bf3_presplit), pre_rows rows
+  const void* pre;
+  int pre_rows;
 };
 using BG = BGT<float>;
 
@@ -707,7 +712,33 @@ __device__ __forceinline__ void bf3_fetch(const float* rowp, long sK, int K, int
     }
   }
 }
-template <bool AK, bool BK_>
+// The shared operand split once per batch: element (row r, k) = src[r sRow + k sK]; thread (k-chunk, row, granule).
+__global__ void __launch_bounds__(256) k_bf3_presplit(const float* __restrict__ src, long sRow, long sK, int R, int K,
+                                                      u32x4_t* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int ktiles = (K + BK3 - 1) / BK3;
+  if (i >= (long)ktiles * R * 2) return;
+  const int gi = (int)(i & 1);
+  const long t = i >> 1;
+  const int row = (int)(t % R), kt = (int)(t / R);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kt * BK3 + 8 * gi + j;
+    v[j] = k < K ? src[(long)row * sRow + (long)k * sK] : 0.0f;
+  }
+  u32x4_t hi, mid, lo;
+  l_split8(v, hi, mid, lo);
+  const long unit = (long)row * 2 + gi, chunk = (long)R * 2;
+  out[(long)(kt * 3 + 0) * chunk + unit] = hi;
+  out[(long)(kt * 3 + 1) * chunk + unit] = mid;
+  out[(long)(kt * 3 + 2) * chunk + unit] = lo;
+}
+// PRE: the A operand comes pre-split from g.pre -- three coalesced 16-byte loads per thread and chunk instead of the f32
+// loads and the split, which every workgroup of every chain otherwise repeats on the same data: config 5's forward
+// product 4.54 -> 4.24 ms.  (The same for x as the B operand of the first layer's weight gradient measured 5 % SLOWER,
+// 6.97 -> 7.35 ms: 48 bytes per task instead of 32 through an L2 that product already saturates.  Not kept.)
+template <bool AK, bool BK_, bool PRE = false>
 __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
   __shared__ __attribute__((aligned(16))) u32x4_t As[2][3 * 128 * 2];
   __shared__ __attribute__((aligned(16))) u32x4_t Bs[2][3 * 128 * 2];
@@ -729,7 +760,7 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int ktiles = (g.K + BK3 - 1) / BK3;
-  const bool want_rowsum = g.rowsum != nullptr && bid.x == 0;
+  const bool want_rowsum = !PRE && g.rowsum != nullptr && bid.x == 0;  // (a pre-split A is never a delta: no row sums)
   float rsum = 0.0f;
   // staging tasks: k contiguous -> consecutive lanes take the two granules of a row; rows contiguous -> consecutive lanes
   // take consecutive rows
@@ -742,14 +773,29 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
   const float* arow = A + (long)min(m0 + ar, g.M - 1) * g.sAm;
   const float* brow = B + (long)min(n0 + br, g.N - 1) * g.sBn;
   float va[8], vb[8];
+  // the pre-split operand: thread (row tid >> 1, granule tid & 1), consecutive threads consecutive 16-byte units
+  const int pr = tid >> 1, pg = tid & 1;
+  const int p_slot = pr * 2 + (pg ^ ((pr >> 3) & 1));
+  const long pre_chunk = (long)g.pre_rows * 2;  // 16-byte units per (k-chunk, piece)
+  const u32x4_t* pre = !PRE ? nullptr : reinterpret_cast<const u32x4_t*>(g.pre) + (long)min(m0 + pr, g.M - 1) * 2 + pg;
+  u32x4_t vp[3];
+  auto fetch_pre = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) vp[p] = pre[(long)(kt * 3 + p) * pre_chunk];
+  };
   auto stage = [&](int st) {
     u32x4_t hi, mid, lo;
-    l_split8(va, hi, mid, lo);
-    As[st][0 * 256 + a_slot] = hi; As[st][1 * 256 + a_slot] = mid; As[st][2 * 256 + a_slot] = lo;
+    if constexpr (PRE) {
+      As[st][0 * 256 + p_slot] = vp[0]; As[st][1 * 256 + p_slot] = vp[1]; As[st][2 * 256 + p_slot] = vp[2];
+    } else {
+      l_split8(va, hi, mid, lo);
+      As[st][0 * 256 + a_slot] = hi; As[st][1 * 256 + a_slot] = mid; As[st][2 * 256 + a_slot] = lo;
+    }
     l_split8(vb, hi, mid, lo);
     Bs[st][0 * 256 + b_slot] = hi; Bs[st][1 * 256 + b_slot] = mid; Bs[st][2 * 256 + b_slot] = lo;
   };
-  bf3_fetch<AK>(arow, g.sAk, g.K, 0, ag, va);
+  if constexpr (PRE) fetch_pre(0);
+  else bf3_fetch<AK>(arow, g.sAk, g.K, 0, ag, va);
   bf3_fetch<BK_>(brow, g.sBk, g.K, 0, bg, vb);
   if (want_rowsum) rsum += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
   stage(0);
@@ -758,7 +804,8 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
     const int cur = kt & 1;
     const bool more = kt + 1 < ktiles;
     if (more) {
-      bf3_fetch<AK>(arow, g.sAk, g.K, kt + 1, ag, va);
+      if constexpr (PRE) fetch_pre(kt + 1);
+      else bf3_fetch<AK>(arow, g.sAk, g.K, kt + 1, ag, va);
       bf3_fetch<BK_>(brow, g.sBk, g.K, kt + 1, bg, vb);
     }
     u32x4_t pa[2][3], pb[2][3];  // [tile][piece: hi, mid, lo]
@@ -1076,7 +1123,8 @@ static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry) {
     bool kfast = false;
     const bool a_k = g.sAk == 1, b_k = g.sBk == 1;
     if (t_ey_products == EY_PRODUCTS_BF16X3 && (a_k || g.sAm == 1) && (b_k || g.sBn == 1)) {
-      if (a_k && b_k) hipLaunchKernelGGL((k_bgemm_bf3<true, true>), grid, dim3(256), 0, s, g);
+      if (g.pre && a_k && b_k && !g.rowsum) hipLaunchKernelGGL((k_bgemm_bf3<true, true, true>), grid, dim3(256), 0, s, g);
+      else if (a_k && b_k) hipLaunchKernelGGL((k_bgemm_bf3<true, true>), grid, dim3(256), 0, s, g);
       else if (a_k) hipLaunchKernelGGL((k_bgemm_bf3<true, false>), grid, dim3(256), 0, s, g);
       else if (b_k) hipLaunchKernelGGL((k_bgemm_bf3<false, true>), grid, dim3(256), 0, s, g);
       else hipLaunchKernelGGL((k_bgemm_bf3<false, false>), grid, dim3(256), 0, s, g);
@@ -1803,6 +1851,37 @@ void ey_large_free(ey_plan* pl) {
   (void)hipFree(pl->d_work);
   pl->d_work = nullptr;
   pl->work_bytes = 0;
+  (void)hipFree(pl->d_xpre);
+  pl->d_xpre = nullptr;
+  pl->xpre_bytes = 0;
+}
+
+// The data matrix x [N, d0] as the first layer's forward product takes it in the bf16x3 form (its A operand: rows n, k =
+// input), split once per batch (ey_plan_set_data counts the batches) on the caller's stream: 4.8 MB for config 5's
+// 1024 x 784; every workgroup of every chain then copies its pieces instead of splitting the same numbers again.
+static int ensure_xpre(ey_plan* pl, hipStream_t s, const void** out) {
+  const EyModel& m = pl->m;
+  const int N = m.N, d0 = m.dims[0];
+  const int ktiles = (d0 + BK3 - 1) / BK3;
+  const size_t bytes = (size_t)16 * ktiles * 3 * N * 2;
+  if (pl->xpre_bytes < bytes) {
+    EY_HIP(hipDeviceSynchronize());
+    (void)hipFree(pl->d_xpre);
+    pl->d_xpre = nullptr;
+    pl->xpre_bytes = 0;
+    EY_HIP(hipMalloc(&pl->d_xpre, bytes));
+    pl->xpre_bytes = bytes;
+    pl->xpre_version = ~0ull;
+  }
+  if (pl->xpre_version != pl->data_version) {
+    const long tasks = (long)ktiles * N * 2;
+    hipLaunchKernelGGL(k_bf3_presplit, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, (const float*)m.x, (long)d0, 1L, N,
+                       d0, (u32x4_t*)pl->d_xpre);
+    EY_HIP(hipGetLastError());
+    pl->xpre_version = pl->data_version;
+  }
+  *out = pl->d_xpre;
+  return EY_OK;
 }
 
 static int ensure_work(ey_plan* pl, size_t bytes) {
@@ -1866,6 +1945,12 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
     }
   }
   int rc, cursor = 0;
+  // bf16x3 form, first layer wide enough for the 128-wide product: x comes pre-split (variant bit 11 switches it off)
+  const void* xpre = nullptr;
+  if constexpr (sizeof(T) == 4) {
+    if (t_ey_products == EY_PRODUCTS_BF16X3 && N > 32 && m.dims[1] > 32 && m.dims[0] >= 16 && !EY_VBIT(11))
+      if ((rc = ensure_xpre(pl, s, &xpre))) return rc;
+  }
   // f32 only: in f64 the fused kernel measured SLOWER than the separate launches (every lane of a row repeats the
   // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
   const bool tail = sizeof(T) == 4 && tail_ok(m) && !EY_VBIT(6);
@@ -1880,6 +1965,9 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
     g.sCm = m.dims[l + 1]; g.sCn = 1; g.bC = (long)N * m.dims[l + 1];
     g.bias = m.boff[l] >= 0 ? theta + m.boff[l] : nullptr; g.bBias = P;
     g.act = m.act[l];
+    if constexpr (sizeof(T) == 4) {
+      if (l == 0 && xpre) { g.pre = xpre; g.pre_rows = N; }
+    }
     if ((rc = bgemm(g, C, s))) return rc;
   }
   if constexpr (sizeof(T) == 4) {  // (the kernel is written for both types; only float is instantiated, see above)

@@ -244,7 +244,8 @@ int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* ta
  * shape / issue-priority / parking variants of the fused f32 trajectory kernel; 4: f32 plans through the layerwise path;
  * 5, 6, 7: that path without LDS-DMA staging / fused last layer / fused leapfrog update; 8, 9: tiny models never / always
  * through the register-resident evaluation of the generic kernels; 10 (ey_debug_set_variant only): new plans, and
- * ey_debug_bgemm, start with EY_PRODUCTS_EXACT.  Results agree to rounding across them. */
+ * ey_debug_bgemm, start with EY_PRODUCTS_EXACT; 11: the layerwise path's bf16x3 products split the data matrix in every
+ * workgroup instead of taking it pre-split.  Results agree to rounding across them (bit for bit across bit 11). */
 int ey_plan_set_variant(ey_plan* plan, int variant);
 int ey_debug_set_variant(int variant);
 
