@@ -2465,3 +2465,38 @@ def test_batched_gemm_vs_torch_bmm(M, N, K, kfast, act, products):
     tol = 2e-5 * (K ** 0.5)
     assert torch.isfinite(C).all()
     assert (C.double() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dims,N", [([784, 128, 10], 96), ([100, 64, 3], 200), ([45, 40, 40, 5], 77)])
+def test_bgemm_path_presplit_data_matrix_is_the_same_arithmetic(dims, N):
+    """bf16x3 form of the layerwise path: the first layer's forward product takes the data matrix already split into its
+    bf16 pieces (made once per batch) instead of splitting it in every workgroup: bit-identical values and gradients
+    (variant bit 11 switches the image off), also for K that is not a multiple of the 16-deep chunk (100, 45), and the
+    image follows a new batch handed over with set_data (same size and a larger one)."""
+    from eeyore_amd.plan import Plan
+    K = len(dims) - 1
+    rng = np.random.default_rng(5)
+    pl = Plan(dims, [1] * K, [1] * (K - 1) + [0], 1, torch.float32, DEV)
+    assert pl.kernel == "bgemm" and pl.f32_products == "bf16x3"
+    pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
+    C = 5
+    th = _t((0.05 * rng.standard_normal((C, pl.P))).astype(np.float32), torch.float32)
+    prev = None
+    for n_rows in (N, N, N + 64):
+        x = rng.standard_normal((n_rows, dims[0]))
+        y = np.eye(dims[-1])[rng.integers(0, dims[-1], n_rows)]
+        pl.set_data(_t(x, torch.float32), _t(y, torch.float32))
+        res = {}
+        for variant in (0, 2048, 0):
+            pl.set_variant(variant)
+            res.setdefault(variant, []).append(pl.log_target_grad(th))
+        pl.set_variant(0)
+        for t, g in res[0]:
+            assert torch.equal(t, res[2048][0][0]) and torch.equal(g, res[2048][0][1])
+        if prev is not None:
+            assert not torch.equal(prev, res[0][0][0])  # a new batch, new values
+        prev = res[0][0][0].clone()
+        co64 = COracle(dims, [1] * (K - 1) + [0], 1, x, y, 0.0, 1.0, dtype=np.float64, nthreads=8)
+        to, go, _, _ = co64.log_target_grad(th[0].cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(res[0][0][0][0].item(), to, rtol=5e-6)
+        np.testing.assert_allclose(res[0][0][1][0].cpu().numpy(), go, rtol=2e-3, atol=2e-4 * np.abs(go).max())
