@@ -75,7 +75,7 @@ def _random_cases(n, seed=2024):
     return out
 
 
-CASES += _random_cases(int(os.environ.get("EY_FUZZ_SEEDS", "10")))
+CASES += _random_cases(int(os.environ.get("EY_FUZZ_SEEDS", "48")))
 
 
 def _mfma32_too(dims, acts, lik, tag):
