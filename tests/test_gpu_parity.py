@@ -2500,3 +2500,44 @@ def test_bgemm_path_presplit_data_matrix_is_the_same_arithmetic(dims, N):
         to, go, _, _ = co64.log_target_grad(th[0].cpu().numpy().astype(np.float64))
         np.testing.assert_allclose(res[0][0][0][0].item(), to, rtol=5e-6)
         np.testing.assert_allclose(res[0][0][1][0].cpu().numpy(), go, rtol=2e-3, atol=2e-4 * np.abs(go).max())
+
+
+def test_model_surface_ten_classes_and_layers_without_bias():
+    """The reference's constructor surface for what the fused kernels took on in round 3: `mlp.Hyperparameters(dims,
+    bias=[...])` with a layer without a bias (mlp.py:36-43) and a ten-class head.  num_params counts no missing bias, the
+    plan behind the model is a fused one, log_target / upto_grad_log_target equal the C oracle built with the same flags,
+    and HMC runs on it through the sampler surface with several chains."""
+    from torch.distributions import Normal
+    from eeyore_amd.chains import ChainList
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    dims, bias, N = [8, 24, 24, 10], [True, False, True], 90
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((N, dims[0]))
+    y = np.eye(10)[rng.integers(0, 10, N)]
+    hp = mlp.Hyperparameters(dims=dims, bias=bias, activations=[torch.sigmoid, torch.tanh, None])
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'], hparams=hp, dtype=torch.float64, device=DEV)
+    P = 8 * 24 + 24 + 24 * 24 + 24 * 10 + 10
+    assert model.num_params() == P
+    model.prior = Normal(torch.zeros(P, dtype=torch.float64, device=DEV), torch.full((P,), 2.0, dtype=torch.float64, device=DEV))
+    xs, ys = _t(x), _t(y)
+    co = COracle(dims, [1, 2, 0], 1, x, y, 0.0, 2.0, dtype=np.float64, bias=[1, 0, 1], nthreads=4)
+    th = 0.2 * rng.standard_normal(P)
+    to, go, _, _ = co.log_target_grad(th)
+    t, g = model.upto_grad_log_target(_t(th), xs, ys)
+    assert model._plan(xs, ys).kernel == "fused16"
+    np.testing.assert_allclose(t.item(), to, rtol=1e-10)
+    np.testing.assert_allclose(g.cpu().numpy(), go, rtol=1e-9, atol=1e-10 * np.abs(go).max())
+    np.testing.assert_allclose(model.log_target(_t(th), xs, ys).item(), to, rtol=1e-10)
+    from torch.utils.data import DataLoader
+    from eeyore_amd.datasets import XYDataset
+    loader = DataLoader(XYDataset(xs, ys), batch_size=N, shuffle=False)
+    torch.manual_seed(3)
+    theta0 = _t(0.1 * rng.standard_normal((6, P)))
+    s = HMC(model, theta0=theta0, dataloader=loader, step=0.02, num_steps=5, seed=7)
+    s.run(num_epochs=12, num_burnin_epochs=2)
+    ch = s.get_chain()
+    assert ch.get_samples().shape == (10, 6, P)
+    assert 0.05 < ch.acceptance_rate().mean().item() <= 1.0
+    assert torch.isfinite(ch.get_target_vals()).all()
