@@ -152,13 +152,16 @@ struct Nm<double> {
   static __device__ __forceinline__ double tanh(double v) { return ::tanh(v); }
   static __device__ __forceinline__ double sqrt(double v) { return ::sqrt(v); }
 };
-// 1 / d for d in [1, inf] in f64: v_rcp_f64 and two Newton steps (five instructions, ~1 ulp) where the IEEE division is
-// thirteen; d is capped so that an overflowed exp gives 1e-300, not the NaN of inf * 0.
+// 1 / d for d in [1, inf] in f64: v_rcp_f64 and two Newton steps (~1 ulp) where the IEEE division is thirteen
+// instructions.  d is capped at 1e300 for the iteration (inf * 0 would be NaN) and d = inf returns exactly 0: a sigmoid
+// whose exp overflowed is exactly 0, and the reference's naive BCE logs then give -inf / NaN, which rejects
+// (eeyore/stats/loss.py:2).  (Between 1e300 and the overflow, logits of 691 .. 709, the result is 1e-300.)
 __device__ __forceinline__ double f16_recip_ge1(double d) {
-  d = fmin(d, 1e300);
-  double y = __builtin_amdgcn_rcp(d);
-  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
-  return __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  const double dc = fmin(d, 1e300);
+  double y = __builtin_amdgcn_rcp(dc);
+  y = __builtin_fma(y, __builtin_fma(-dc, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-dc, y, 1.0), y);
+  return d > 1.7e308 ? 0.0 : y;
 }
 // sigmoid and tanh.  f64: the library exp / tanh, as the generic kernels (1e-10 parity with the reference's fp64).  f32:
 // one v_exp_f32 and one v_rcp_f32 per element, as ey_mfma32.hip (an IEEE division is ten vector instructions, and f32

@@ -323,3 +323,33 @@ def test_fused16_layers_without_bias(dims, bias, acts, lik, tag, N):
     for i in range(2):
         pl.hmc_step(b[0], b[1], b[2], 0.01, 3, seed=4, it=7 + i)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_fused16_saturated_bce_is_nan_and_rejected(tag):
+    """eeyore/stats/loss.py:2 on the fused kernels: an output sigmoid that rounds to exactly 1 or 0 makes log(1 - h) (1 - y)
+    or log(h) y the product -inf * 0 = NaN (or -inf), and a NaN / -inf Hamiltonian is rejected (hmc.py:148).  In f64 that
+    takes logits beyond +-709 (exp overflows); the lean reciprocal of the f64 path must return exactly 0 there."""
+    from eeyore_amd.plan import Plan
+    dt = torch.float64 if tag == "f64" else torch.float32
+    dims = [4, 16, 16, 1]
+    rng = np.random.default_rng(2)
+    N = 24
+    x = np.abs(rng.standard_normal((N, 4))) + 0.5
+    y = (np.arange(N) % 2).astype(np.float64)[:, None]
+    pl = Plan(dims, [1, 1, 1], [3, 3, 1], 0, dt, DEV)   # relu hidden layers: the logit grows with the weights
+    pl.set_data(_t(x, dt), _t(y, dt))
+    pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), 100.0))
+    assert pl.kernel == "fused16"
+    th = torch.zeros(3, pl.P, dtype=dt, device=DEV)
+    th[0] = 3.0      # every weight 3: logits of order 4 * 16 * 16 * 27 -> the sigmoid is exactly 1, rows with y = 0 are NaN
+    th[1] = 0.01     # a tame state
+    th[2] = 3.0
+    th[2, -17:] = -3.0  # the last layer negative: the sigmoid is exactly 0, rows with y = 1 are -inf, rows with y = 0 NaN
+    lik, _ = pl.log_target(th)
+    assert not torch.isfinite(lik[0]) and torch.isfinite(lik[1]) and not torch.isfinite(lik[2])
+    t, g = pl.log_target_grad(th)
+    th2 = th.clone()
+    out = pl.hmc_step(th2, t, g, 1e-3, 3, seed=1, it=0)
+    assert out["accepted"][0].item() == 0 and out["accepted"][2].item() == 0
+    assert torch.equal(th2[0], th[0]) and torch.equal(th2[2], th[2])
