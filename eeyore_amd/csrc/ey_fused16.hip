@@ -92,6 +92,16 @@ using v4 = typename V4<T>::type;
 
 template <typename T>
 __device__ __forceinline__ v4<T> mfma16(T a, T b, v4<T> c);
+// v_mfma_f64_4x4x4_4b_f64 (measured, tools/mfma44_probe.hip: 15 cycles against 58 for 16x16x4): four blocks b of
+// D_b[i][j] += sum_k A_b[i][k] B_b[k][j]; A_b[i][k] is lane 16k + 4b + i, B_b[k][j] lane 16k + 4b + j, D_b[i][j] lane
+// 16i + 4b + j, one register each.  In the coordinates of the 16x16x4 layouts -- lane (c, g) = 16g + c -- the B operand is
+// a T or U tile register as it stands (k-slot g, column c = 4b + j), the A operand a tile whose column index only counts
+// modulo four (row i = c & 3 of a four-row matrix, repeated for every block), and D is register 0 of a D tile whose rows
+// 0 .. 3 are the lane groups: exactly what the products with at most four outputs need (f64: output o lives in lane group o).
+__device__ __forceinline__ double mfma44(double a, double b, double c) {
+  if (F16_ABLATE & 2) return c + a * b;
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
 template <typename T>
 __device__ __forceinline__ v4<T> mfma16s(T a, T b, v4<T> c) {  // the skinny products
   if (F16_ABLATE & 2) { c[0] += a * b; return c; }
@@ -398,6 +408,11 @@ __device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>:
   for (int k = 0; k < K::NW2; ++k) {  // W2[o = fi(g, r)][16n + c]
     const int r = k & 3, n = k >> 2, o = L::fi(g, r);
     if (o < a.dK) {
+      if (sizeof(T) == 8 && !(KSM == 4 && a.dK > 4)) {
+        // f64, at most four outputs: the logits are a 4x4x4 product (mfma44): row o of W2 in every block of four lanes
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) lw[K::O_W2A + (n * 4 + rk) * 64 + 4 * b4 + o + 16 * gk] = th[K::S_W2 + k];
+      } else
       lw[K::O_W2A + (n * 4 + rk) * 64 + o + 16 * gk] = th[K::S_W2 + k];  // logits: A lane (o, gk), k-step (n, rk)
       if (KSM == 4 && a.dK > 4)  // dH1 over four k-steps: k-step s, k-slot g' <-> output fi(g', s), which is (r, g) here
         lw[K::O_W2T + (n * 4 + r) * 64 + c + 16 * g] = th[K::S_W2 + k];
@@ -508,10 +523,24 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
       lacc[r] = WIDE ? th[K::S_B2 + r]
                      : (o >= a.dK ? T(0) : (o == 0 ? b2v[0] : (o == 1 ? b2v[1] : (o == 2 ? b2v[2] : b2v[3]))));
     }
+    // Q44 (f64, at most four outputs): logits and dW2 as 4x4x4 products on one register (see mfma44)
+    const bool Q44 = sizeof(T) == 8 && !WIDE;
+    if constexpr (sizeof(T) == 8) {
+      if (Q44) {
+        double lq = lacc[0];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lacc = mfma16s<T>(lw[K::O_W2A + (m * 4 + r) * 64 + lane], H1[m][r], lacc);
+          for (int r = 0; r < 4; ++r) lq = mfma44(lw[K::O_W2A + (m * 4 + r) * 64 + lane], H1[m][r], lq);
+        lacc[0] = lq;
+      }
+    }
+    if (!Q44) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lacc = mfma16s<T>(lw[K::O_W2A + (m * 4 + r) * 64 + lane], H1[m][r], lacc);
+    }
     T lg[4];
     if (!WIDE) {
 #pragma unroll
@@ -643,8 +672,15 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 #pragma unroll
       for (int n = 0; n < MT; ++n) {
         const v4<T> h1u = f16_ld4(lw + K::O_TB0 + (16 * n + c) * F16_TS + 4 * g);
+        if constexpr (sizeof(T) == 8) {  // (Q44: not WIDE here)
+          double q = dW2[n][0];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dW2[n] = mfma16s<T>(c < 4 ? d2u[r] : T(0), h1u[r], dW2[n]);
+          for (int r = 0; r < 4; ++r) q = mfma44(d2u[r], h1u[r], q);
+          dW2[n][0] = q;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dW2[n] = mfma16s<T>(c < 4 ? d2u[r] : T(0), h1u[r], dW2[n]);
+        }
       }
     }
     }
@@ -690,6 +726,8 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
       T xu[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) xu[r] = (F16_ABLATE & 4) ? T(0.02 * lane) : xt[off_xu + r * 64 + lane];
+      // (the 4x4x4 form was measured here too, for at most four inputs: x fetched with the input index modulo four and the
+      // one result register moved into the slot layout once per evaluation by eight exchanges: +0.5 %, not kept)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
 #pragma unroll
