@@ -166,21 +166,23 @@ struct Nm<double> {
 // instructions.  d is capped at 1e300 for the iteration (inf * 0 would be NaN) and d = inf returns exactly 0: a sigmoid
 // whose exp overflowed is exactly 0, and the reference's naive BCE logs then give -inf / NaN, which rejects
 // (eeyore/stats/loss.py:2).  (Between 1e300 and the overflow, logits of 691 .. 709, the result is 1e-300.)
+template <bool EXACT_ZERO = true>
 __device__ __forceinline__ double f16_recip_ge1(double d) {
   const double dc = fmin(d, 1e300);
   double y = __builtin_amdgcn_rcp(dc);
   y = __builtin_fma(y, __builtin_fma(-dc, y, 1.0), y);
   y = __builtin_fma(y, __builtin_fma(-dc, y, 1.0), y);
-  return d > 1.7e308 ? 0.0 : y;
+  // (hidden units and the softmax do without the select: 1e-300 for an exact 0 reaches nothing at f64 precision)
+  return EXACT_ZERO && d > 1.7e308 ? 0.0 : y;
 }
 // sigmoid and tanh.  f64: the library exp / tanh, as the generic kernels (1e-10 parity with the reference's fp64).  f32:
 // one v_exp_f32 and one v_rcp_f32 per element, as ey_mfma32.hip (an IEEE division is ten vector instructions, and f32
 // MFMA shares the vector ALUs with them); both are accurate to ~1 ulp, far inside the stated 2e-4.
-template <typename T>
+template <typename T, bool OUTPUT = true>  // OUTPUT: a sigmoid whose saturation to exactly 0 matters (the BCE head)
 __device__ __forceinline__ T f16_sigmoid(T g) {
   if (F16_ABLATE & 1) return T(0.25) * g + T(0.5);
   if constexpr (sizeof(T) == 4) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
-  else return f16_recip_ge1(T(1) + Nm<T>::exp_fast(-g));
+  else return f16_recip_ge1<OUTPUT>(T(1) + Nm<T>::exp_fast(-g));
 }
 template <typename T>
 __device__ __forceinline__ T f16_tanh(T g) {
@@ -188,7 +190,7 @@ __device__ __forceinline__ T f16_tanh(T g) {
   else {
     // tanh |g| = 2 / (1 + exp(-2 |g|)) - 1 on the 19-instruction exp (the library's tanh is 139 f64 instructions per
     // element); below |g| = 0.125, where that form cancels, the odd Taylor polynomial to g^15 (remainder 2e-18 relative)
-    const T big = T(2) * f16_recip_ge1(T(1) + Nm<T>::exp_fast(-T(2) * __builtin_fabs(g))) - T(1);
+    const T big = T(2) * f16_recip_ge1<false>(T(1) + Nm<T>::exp_fast(-T(2) * __builtin_fabs(g))) - T(1);
     const T g2 = g * g;
     T p = T(-929569.0 / 638512875.0);
     p = __builtin_fma(p, g2, T(21844.0 / 6081075.0));
@@ -227,7 +229,7 @@ __device__ __forceinline__ void f16_act_tiles(int code, typename V4<T>::type (&h
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[m][r] = f16_sigmoid<T>(h[m][r]);
+      for (int r = 0; r < 4; ++r) h[m][r] = f16_sigmoid<T, false>(h[m][r]);
   } else if (code == EY_ACT_TANH) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -575,7 +577,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
         if (mine) lik += llab - (mx + Nm<T>::log(ssum));
       }
       T inv;
-      if constexpr (sizeof(T) == 8) inv = f16_recip_ge1(ssum);
+      if constexpr (sizeof(T) == 8) inv = f16_recip_ge1<false>(ssum);
       else inv = T(1) / ssum;
 #pragma unroll
       for (int r = 0; r < 4; ++r) d2[r] = valid ? ((L::fi(g, r) == lab ? T(1) : T(0)) - e[r] * inv) : T(0);
@@ -602,7 +604,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
       }
       if (need_value && mine) lik += llab - (mx + Nm<T>::log(ssum));
       T inv;
-      if constexpr (sizeof(T) == 8) inv = f16_recip_ge1(ssum);  // the largest term is exp(0)
+      if constexpr (sizeof(T) == 8) inv = f16_recip_ge1<false>(ssum);  // the largest term is exp(0)
       else inv = T(1) / ssum;
 #pragma unroll
       for (int o = 0; o < 4; ++o)
