@@ -353,3 +353,27 @@ def test_fused16_saturated_bce_is_nan_and_rejected(tag):
     out = pl.hmc_step(th2, t, g, 1e-3, 3, seed=1, it=0)
     assert out["accepted"][0].item() == 0 and out["accepted"][2].item() == 0
     assert torch.equal(th2[0], th[0]) and torch.equal(th2[2], th[2])
+
+
+def test_heads_the_fused_kernels_do_not_take_are_routed_elsewhere():
+    """BCE-sum on more than four sigmoid outputs and CE-sum on more than sixteen logits are outside the fused kernels'
+    range: the plan must say so (another family serves it) and the values must still be the oracle's."""
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(12)
+    for dims, acts, lik in (([8, 16, 16, 6], [1, 1, 1], 0), ([8, 32, 20], [2, 0], 1)):
+        N = 40
+        x = rng.standard_normal((N, dims[0]))
+        y = (rng.random((N, dims[-1])) < 0.5).astype(np.float64) if lik == 0 else np.eye(dims[-1])[rng.integers(0, dims[-1], N)]
+        P = sum((dims[l] + 1) * dims[l + 1] for l in range(len(dims) - 1))
+        for dt, npdt, tol in ((torch.float64, np.float64, 1e-10), (torch.float32, np.float32, 2e-4)):
+            pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV)
+            pl.set_data(_t(x, dt), _t(y, dt))
+            pl.set_prior(torch.zeros(P), torch.ones(P))
+            assert pl.kernel != "fused16"
+            co = COracle(dims, acts, lik, x, y, 0.0, 1.0, dtype=npdt, nthreads=4)
+            th0 = (0.2 * rng.standard_normal((4, P))).astype(npdt)
+            t, g = pl.log_target_grad(_t(th0, dt))
+            for c in range(4):
+                to, go, _, _ = co.log_target_grad(th0[c])
+                np.testing.assert_allclose(t[c].item(), to, rtol=tol * 5, atol=tol * 10)
+                np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=tol * 50, atol=tol * 5 * max(1.0, np.abs(go).max()))
