@@ -246,3 +246,40 @@ def test_row_counts_around_the_tile_edges(n_rows):
             pl.hmc_step(b[0], b[1], b[2], 0.01, 4, seed=6, it=2 + i)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
         assert torch.isfinite(a[1]).all()
+
+
+@pytest.mark.parametrize("n_rows", [96, 352])
+def test_other_4_32_32_models_in_both_layouts(n_rows):
+    """The tanh / CE and sigmoid / BCE 4-32-32 models on the fused f32 kernel (bf16x3 form only): batches of at most ten row
+    tiles take the piece images in HMC launches, larger ones the first layout; value, gradient and an HMC draw with
+    recorded randomness against the f64 / f32 oracles at both sizes."""
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(40 + n_rows)
+    for dims, acts, lik in (([4, 32, 32, 3], [2, 2, 0], 1), ([4, 32, 32, 1], [1, 1, 1], 0)):
+        x = rng.standard_normal((n_rows, 4))
+        y = np.eye(3)[rng.integers(0, 3, n_rows)] if lik == 1 else (rng.random((n_rows, 1)) < 0.5).astype(np.float64)
+        pl = Plan(dims, [1, 1, 1], acts, lik, torch.float32, DEV)
+        pl.set_data(_t(x), _t(y))
+        P = pl.P
+        pl.set_prior(torch.zeros(P), torch.full((P,), 1.5))
+        assert pl.kernel == "mfma32" and pl.f32_products == "bf16x3"
+        x32, y32 = x.astype(np.float32), y.astype(np.float32)
+        o64 = COracle(dims, acts, lik, x32.astype(np.float64), y, 0.0, 1.5, dtype=np.float64, nthreads=8)
+        o32 = COracle(dims, acts, lik, x32, y32, 0.0, 1.5, dtype=np.float32, nthreads=8)
+        C = 12
+        th0 = (0.25 * rng.standard_normal((C, P))).astype(np.float32)
+        t, g = pl.log_target_grad(_t(th0))
+        for c in range(C):
+            tt, gg, _, _ = o64.log_target_grad(th0[c].astype(np.float64))
+            np.testing.assert_allclose(t[c].item(), tt, rtol=5e-6, atol=5e-4)
+            np.testing.assert_allclose(g[c].cpu().numpy(), gg, rtol=2e-4, atol=5e-6 * max(1.0, np.abs(gg).max()))
+        p0 = rng.standard_normal((C, P)).astype(np.float32); u = rng.random(C).astype(np.float32)
+        th, tv, gv = _t(th0).clone(), t.clone(), g.clone()
+        out = pl.hmc_step(th, tv, gv, 0.01, 6, p0=_t(p0), u=_t(u))
+        tho, tvo, go = th0.copy(), t.cpu().numpy().copy(), g.cpu().numpy().copy()
+        acc, hc, hp = o32.hmc_draw(tho, tvo, go, p0, u, 0.01, 6)
+        rate = np.minimum(np.exp(np.minimum(hc - hp, 0.0)), 1)
+        decided = np.abs(u - rate) > 2e-3 * np.maximum(1.0, np.abs(hc - hp))
+        got = out["accepted"].cpu().numpy()
+        assert decided.sum() > 0.7 * C and (got[decided] == acc[decided]).all()
+        np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=3e-4, atol=3e-2)
