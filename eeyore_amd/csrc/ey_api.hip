@@ -99,7 +99,7 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
   pl->products = (g_ey_default_variant.load() & 1024) ? EY_PRODUCTS_EXACT : ey_default_products();
   {
     const char* e = getenv("EY_ROW_WAVES");
-    pl->row_waves = (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ? e[0] - '0' : EY_ROW_WAVES_AUTO;
+    pl->row_waves = (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ? e[0] - '0' : EY_ROW_WAVES_OFF;
   }
   pl->mfma32_kind = ey_mfma32_kind(pl);
   pl->mfma32_ok = pl->mfma32_kind != 0;

@@ -81,13 +81,15 @@ struct ey_plan {
   int n_cu;
   int variant = 0;   // diagnostic switches (ey_plan_set_variant; bits as documented in include/eeyore_amd.h)
   int products = 0;  // EY_OPT_F32_PRODUCTS: EY_PRODUCTS_BF16X3 (0) or EY_PRODUCTS_EXACT (1)
-  int row_waves = 2; // EY_OPT_ROW_WAVES: EY_ROW_WAVES_OFF (0), _ON (1), _AUTO (2)
+  int row_waves = 0; // EY_OPT_ROW_WAVES: EY_ROW_WAVES_OFF (0, default), _ON (1), _AUTO (2)
   // layerwise batched-GEMM path for models whose parameters do not fit LDS (ey_large.hip): workspace it owns
   void* d_work;
   size_t work_bytes;
   // ... and the data matrix split into bf16 pieces once per batch, in both orientations (ey_large.hip: ensure_xpre)
   void* d_xpre = nullptr;
   size_t xpre_bytes = 0;
+  hipEvent_t xpre_event = nullptr;   // recorded behind the split on the stream that ran it: a consumer on another stream waits for it
+  hipStream_t xpre_stream = nullptr;
   uint64_t data_version = 0, xpre_version = ~0ull;  // ey_plan_set_data counts; the images remember which batch they hold
 };
 

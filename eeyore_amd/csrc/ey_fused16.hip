@@ -132,9 +132,14 @@ struct Nm<float> {
 };
 // exp in f64 for the activations and the softmax: n = rint(x log2 e), r = x - n ln 2 in two pieces (|r| <= 0.3466), the
 // Taylor polynomial of degree 13 (remainder 4e-18 relative), v_ldexp_f64 (which overflows to inf and underflows through
-// the denormals to 0 as exp does; v_cvt_i32_f64 saturates; NaN passes through): 19 instructions where the library's takes
-// about 45, accurate to a few ulp -- the reference's f64 values to 1e-10 need 1e5 times less.
+// the denormals to 0 as exp does; NaN passes through): 24 instructions where the library's takes about 45, accurate to a
+// few ulp -- the reference's f64 values to 1e-10 need 1e5 times less.
 __device__ __forceinline__ double f16_exp_f64(double x) {
+  // the argument clamped to where exp leaves the doubles anyway (exp(-746) = 0, exp(710) = inf through v_ldexp_f64): -inf /
+  // +inf and products that overflow give the library's 0 / inf instead of inf - inf = NaN in the reduction; NaN passes
+  // through (v_max / v_min return the other operand for a quiet NaN, so the select keeps it explicit)
+  const double xc = x != x ? x : __builtin_fmax(__builtin_fmin(x, 710.0), -746.0);
+  x = xc;
   const double n = __builtin_rint(x * 1.4426950408889634);
   double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
   r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
@@ -279,6 +284,10 @@ __device__ __forceinline__ T f16_dpp(T v) {
 }
 template <typename T>
 __device__ __forceinline__ T f16_wsum(T v) {
+#ifdef F16_WSUM_SHFL  // diagnostic builds: the butterfly through ds_bpermute instead (a different order of additions)
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+#endif
   v += f16_dpp<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
   v += f16_dpp<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
   v += f16_dpp<0x141, 0xF>(v);  // row_half_mirror
@@ -831,7 +840,11 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   const bool has_temp = a.temp != nullptr;
   const T temp = has_temp ? a.temp[chain] : T(1);
   const T eps = a.step_vec ? a.step_vec[chain] : a.step;
+#ifdef F16_ONLY_MODE  // diagnostic builds: one mode compiled in (a kernel a fifth of the size)
+  const int mode = F16_ONLY_MODE;
+#else
   const int mode = a.mode;
+#endif
 
   T th[K::NREG], gr[K::NREG];
   F16_EACH(k) {
@@ -1145,6 +1158,13 @@ int ey_fused16_set_data(ey_plan* pl, hipStream_t s) {
 
 template <typename T, int H, int WAVES, int V>
 static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
+#ifdef F16_ONLY_H  // diagnostic builds (tools/f16_bisect.sh): one instantiation only, the others refuse
+  if constexpr (!(sizeof(T) == F16_ONLY_SIZE && H == F16_ONLY_H && V == F16_ONLY_V)) {
+    ey_set_error("fused16: instantiation compiled out of this diagnostic build");
+    return EY_ERR_UNSUPPORTED;
+  } else
+#endif
+  {
   const size_t bytes = sizeof(T) * (size_t)WAVES * F16Cfg<H, (V & 2) ? 4 : 2>::WAVE_ELEMS;
   EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, V>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -1152,6 +1172,7 @@ static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
   hipLaunchKernelGGL((k_fused16<T, H, WAVES, V>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
   EY_HIP(hipGetLastError());
   return EY_OK;
+  }
 }
 // The variant V = TWO | 2 PAD is a template parameter: one hidden layer (the middle layer skipped) and hidden widths
 // below the tile grid are separate instantiations -- as run-time flags they cost the exact two-hidden-layer shapes

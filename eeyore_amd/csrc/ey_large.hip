@@ -1854,6 +1854,8 @@ void ey_large_free(ey_plan* pl) {
   (void)hipFree(pl->d_xpre);
   pl->d_xpre = nullptr;
   pl->xpre_bytes = 0;
+  if (pl->xpre_event) (void)hipEventDestroy(pl->xpre_event);
+  pl->xpre_event = nullptr;
 }
 
 // The data matrix x [N, d0] as the first layer's forward product takes it in the bf16x3 form (its A operand: rows n, k =
@@ -1878,7 +1880,13 @@ static int ensure_xpre(ey_plan* pl, hipStream_t s, const void** out) {
     hipLaunchKernelGGL(k_bf3_presplit, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, (const float*)m.x, (long)d0, 1L, N,
                        d0, (u32x4_t*)pl->d_xpre);
     EY_HIP(hipGetLastError());
+    if (!pl->xpre_event) EY_HIP(hipEventCreateWithFlags(&pl->xpre_event, hipEventDisableTiming));
+    EY_HIP(hipEventRecord(pl->xpre_event, s));
+    pl->xpre_stream = s;
     pl->xpre_version = pl->data_version;
+  } else if (pl->xpre_event && s != pl->xpre_stream) {
+    // the image was split on another stream (the first evaluation of this batch): order this stream behind it
+    EY_HIP(hipStreamWaitEvent(s, pl->xpre_event, 0));
   }
   *out = pl->d_xpre;
   return EY_OK;

@@ -73,7 +73,9 @@ class Plan:
     @property
     def row_waves(self):
         """'off', 'on' or 'auto': several waves per chain for tiny models on batches of two row tiles or more
-        (EY_OPT_ROW_WAVES in include/eeyore_amd.h: a latency option that changes the order of the gradient sums)."""
+        (EY_OPT_ROW_WAVES in include/eeyore_amd.h: a latency option that changes the order of the gradient sums).  'off' is
+        the default: a chain's bits then do not depend on how many chains share its launch; 'auto' opts in to the waves
+        whenever the launch would leave the chip idle."""
         v = ct.c_int()
         L.check(L.lib().ey_plan_get_option(self.handle, L.EY_OPT_ROW_WAVES, ct.byref(v)), "ey_plan_get_option")
         return ("off", "on", "auto")[v.value]

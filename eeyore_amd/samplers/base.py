@@ -221,7 +221,8 @@ class SingleChainSerialSampler(SerialSampler):
             kw = dict(device=self._target.device, dtype=self._target.dtype)
             # no temperature so far = temperature one (bayesian_model.py:33-34: `if self.temperature is not None`)
             t_old = torch.ones((), **kw) if old is None else torch.as_tensor(old, **kw)
-            t_new = torch.ones((), **kw) if temperature is None else torch.as_tensor(temperature, **kw)
+            new = self._temp()   # as `old` was obtained: a sampler without its own falls back to the model's
+            t_new = torch.ones((), **kw) if new is None else torch.as_tensor(new, **kw)
             ratio = (t_new / t_old).expand(self._target.shape[0]).contiguous()
             self._target *= ratio
             if getattr(self, '_grad', None) is not None:

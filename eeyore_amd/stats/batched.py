@@ -11,6 +11,7 @@ import torch
 from eeyore_amd import _lib as L
 
 _DT = {torch.float32: L.EY_F32, torch.float64: L.EY_F64}
+MV_WIDTH_MAX = 16   # parameters per chain ey_inse_multivariate takes (MV_PMAX in csrc/ey_stats.hip)
 
 
 def inse_univariate(samples):
@@ -90,13 +91,15 @@ def multi_rhat_from_parts(w_sum, means, n):
     their MC covariances, ``means`` [m,p] the chain means, n iterations per chain.  This is the form the sharded
     statistic takes: ranks all-reduce w_sum and all-gather means.
     Returns (rhat, imag part of the leading eigenvalue, W, B, is_w_pd, is_b_pd) as the reference does."""
-    from .diagnostics import cov as _cov, is_pos_def, nearest_pd
+    from .linalg import is_pos_def, nearest_pd
     m = means.shape[0]
     w = w_sum / m
     is_w_pd = is_pos_def(w)
     if not is_w_pd:
         w = nearest_pd(w)
-    b = _cov(means, rowvar=False)
+    b = torch.cov(means.mT)   # unbiased covariance of the chain means (eeyore/stats/cov.py:5-15)
+    if b.dim() == 0:
+        b = b.reshape(1, 1)
     is_b_pd = is_pos_def(b)
     if not is_b_pd:
         b = nearest_pd(b)
@@ -112,9 +115,9 @@ def multi_rhat_device(samples, layout="ncp"):
     return multi_rhat_from_parts(r["sig"].sum(0), r["mean"], r["n"])
 
 
-def inse_mc_cov_chains(x):
+def inse_mc_cov_chains(x, adjust=False):
     """(torch-batched form, any device; the HIP form is ``inse_multivariate``.)  The reference's multivariate initial-sequence estimator (eeyore/stats/inse_mc_cov.py:9-83, adjust=False) for C
-    chains at once: x [C, n, p] -> [C, p, p].  Every lag pair is ONE batched product over all chains (the reference's
+    chains at once: x [C, n, p] -> [C, p, p] (``adjust=True``: the eigenvalue correction of :72-81 as well).  Every lag pair is ONE batched product over all chains (the reference's
     torch.ger double loop, :24-31), the positive-definiteness test (:41, a Cholesky attempt on a symmetric matrix,
     eeyore/linalg/is_pos_def.py:3-11) and the determinant test (:62-65) are batched too; chains leave the loop one by
     one through masks.  Chains for which the reference raises 'Not enough samples' (:45-46) come back as NaN.
@@ -127,7 +130,8 @@ def inse_mc_cov_chains(x):
 
     def gam(lag):                                                        # :24-31 for every chain
         g = torch.matmul(xc[:, :n - lag].transpose(1, 2), xc[:, lag:]) / n
-        if lag == 0:  # exactly symmetric, as the reference's sum of x_i x_i^T is (see diagnostics._gam)
+        if lag == 0:  # the reference's sum of x_i x_i^T is symmetric to the last bit and its positive-definiteness test
+            # demands exactly that (is_pos_def.py:4); a BLAS product need not be, so the upper triangle is mirrored
             g = torch.triu(g) + torch.triu(g, 1).transpose(1, 2)
         return g
 
@@ -139,6 +143,7 @@ def inse_mc_cov_chains(x):
     sig = torch.zeros(C, p, p, dtype=x.dtype, device=x.device)
     last = torch.zeros(C, dtype=x.dtype, device=x.device)
     state = torch.zeros(C, dtype=torch.int8, device=x.device)            # 0 searching, 1 extending, 2 stopped
+    lift = torch.zeros_like(sig) if adjust else None                     # :17-18, the sum of the negative parts
     for m in range(ub):
         if bool((state == 2).all()):
             break
@@ -157,8 +162,14 @@ def inse_mc_cov_chains(x):
         grow = extending & (det_new > last)
         sig = torch.where(grow[:, None, None], cand, sig)
         last = torch.where(grow, det_new, last)
+        if adjust and bool(grow.any()):                                  # :72-79: the negative part of this lag pair's Gam
+            lam, vec = torch.linalg.eigh(G)
+            neg = (vec * lam.clamp(max=0)[:, None, :]) @ vec.transpose(1, 2)
+            lift = torch.where(grow[:, None, None], lift - neg, lift)
         state = torch.where(found, torch.ones_like(state), state)
         state = torch.where(extending & ~grow, torch.full_like(state, 2), state)
+    if adjust:
+        sig = sig + 2 * lift                                             # :81
     sig = torch.where((state == 0)[:, None, None], torch.full_like(sig, float('nan')), sig)
     return sig
 

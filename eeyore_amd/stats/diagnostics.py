@@ -1,175 +1,140 @@
-"""Post-hoc chain diagnostics with the reference's definitions: sample covariance, the
-initial-sequence (INSE) Monte Carlo covariance of Dai & Jones as implemented in mcmcse's insec.cpp, multivariate ESS
-and multivariate R-hat.  The reference walks every lag with a Python double loop of outer products
-(eeyore/stats/inse_mc_cov.py:20-33); here each lag's autocovariance is one matmul, on whatever device holds the chain.
-"""
+"""Post-hoc chain diagnostics behind the reference's function names (eeyore/stats/*.py): sample
+covariance, the initial-sequence Monte Carlo covariance (Dai & Jones 2017, the estimator of mcmcse's insec.cpp),
+multivariate effective sample size and multivariate R-hat.
+
+Where the work is done:
+* samples on the ROCm device go through the HIP kernels (``stats.batched.inse_multivariate`` -> ``ey_inse_multivariate``,
+  every chain in one launch) whenever the kernel takes the width;
+* anything else -- the reference's own use: one small chain in host memory -- runs the chain-batched torch form
+  (``stats.batched.inse_mc_cov_chains``: every lag pair one batched product, the stopping rules as masks), with the single
+  chain as a batch of one.  The reference walks every lag with a Python double loop of outer products
+  (eeyore/stats/inse_mc_cov.py:20-31, O(n^2 p^2) interpreter steps).
+Signatures, argument meaning and error behaviour are the reference's."""
 import torch
 
+from . import batched
+from .linalg import is_pos_def, nearest_pd  # noqa: F401  (re-exported: eeyore.linalg's names)
 
-def is_pos_def(x):
-    """eeyore/linalg/is_pos_def.py:3-11."""
-    if torch.equal(x, x.t()):
-        try:
-            torch.linalg.cholesky(x)
-            return True
-        except RuntimeError:
-            return False
-    return False
+_NOT_ENOUGH = 'Not enough samples'   # the reference's message, inse_mc_cov.py:45-46
 
 
-def nearest_pd(A):
-    """Nearest positive-definite matrix (Higham 1988, as eeyore/linalg/nearest_pd.py:9-42; the reference's loop uses
-    the removed torch.eig, torch.linalg.eigvalsh stands in)."""
-    B = (A + A.T) / 2
-    _, s, Vh = torch.linalg.svd(B)
-    H = Vh.T @ torch.diag(s) @ Vh
-    A3 = (B + H) / 2
-    A3 = (A3 + A3.T) / 2
-    if is_pos_def(A3):
-        return A3
-    spacing = torch.finfo(A.dtype).eps * torch.norm(A).item()
-    eye = torch.eye(A.shape[0], dtype=A.dtype, device=A.device)
-    k = 1
-    while not is_pos_def(A3):
-        mineig = torch.linalg.eigvalsh(A3).min().item()
-        A3 = A3 + eye * (-mineig * k**2 + spacing)
-        k += 1
-    return A3
+def _on_device_kernel(x, width, adjust):
+    return x.is_cuda and not adjust and width <= batched.MV_WIDTH_MAX and x.dtype in (torch.float32, torch.float64)
 
 
+def _chain_mc_covs(chains, adjust):
+    """Initial-sequence covariance of every chain of ``chains`` [m, n, p] -> [m, p, p] in the chains' dtype; raises the
+    reference's RuntimeError if any chain has too few samples for a positive-definite estimate."""
+    m, n, p = chains.shape
+    if _on_device_kernel(chains, p, adjust):
+        res = batched.inse_multivariate(chains, layout="cnp")
+        short = res["pairs"] < 0
+        sig = res["sig"].to(chains.dtype)
+    else:
+        sig = batched.inse_mc_cov_chains(chains, adjust=adjust)
+        short = torch.isnan(sig).flatten(1).any(1)
+    if bool(short.any()):
+        raise RuntimeError(_NOT_ENOUGH)
+    return sig
+
+
+# ---------------------------------------------------------------------------------------------- covariance, correlation
 def cov(x, rowvar=False):
-    """eeyore/stats/cov.py:5-15: unbiased sample covariance; rows are observations unless rowvar."""
+    """Unbiased sample covariance (eeyore/stats/cov.py:5-15): observations in rows unless ``rowvar``; a vector is one
+    variable; more than two dimensions raise ValueError."""
     if x.dim() > 2:
         raise ValueError('x has more than 2 dimensions')
-    if x.dim() < 2:
-        x = x.view(1, -1)
-    if not rowvar and x.size(0) != 1:
-        x = x.t()
-    x_ctr = x - torch.mean(x, dim=1, keepdim=True)
-    return x_ctr.matmul(x_ctr.t()).squeeze() / (x.size(1) - 1)
+    variables = x.reshape(1, -1) if x.dim() < 2 else x
+    if not rowvar and variables.shape[0] != 1:
+        variables = variables.mT
+    return torch.cov(variables, correction=1)
 
 
 def cor_from_cov(x):
-    """eeyore/stats/cor_from_cov.py:3-7."""
-    d = 1 / torch.diag(x).sqrt()
-    return x * d[None, :] * d[:, None]
+    """Correlation matrix of a covariance matrix (eeyore/stats/cor_from_cov.py:3-7)."""
+    scale = torch.rsqrt(torch.diagonal(x))
+    return scale[:, None] * x * scale[None, :]
 
 
 def cor(x, rowvar=False):
-    return cor_from_cov(cov(x, rowvar=rowvar))
+    """Sample correlation matrix (eeyore/stats/cor.py)."""
+    return cor_from_cov(cov(x, rowvar))
 
 
-def _gam(x_ctr, lag, n):
-    """(1/n) sum_i x_ctr[i] (outer) x_ctr[i+lag]  --  inse_mc_cov.py:24-29 as one matmul.
-    At lag 0 the reference's sum of outer products x_i x_i^T is symmetric to the last bit, and its positive-definiteness
-    test demands exactly that (is_pos_def.py:4, torch.equal(x, x.t())); a BLAS product need not be, so the upper
-    triangle is mirrored."""
-    g = x_ctr[:x_ctr.shape[0] - lag].t() @ x_ctr[lag:] / n
-    if lag == 0:
-        g = torch.triu(g) + torch.triu(g, 1).t()
-    return g
-
-
+# ---------------------------------------------------------------------------------------------- Monte Carlo covariance
 def inse_mc_cov(x, adjust=False):
-    """eeyore/stats/inse_mc_cov.py:9-83."""
-    x_ctr = x - x.mean(0)
-    n, p = x.shape
-    ub = n // 2
-    sn = ub
-    if adjust:
-        Gamadj = torch.zeros([p, p], dtype=x.dtype, device=x.device)
-    Sig = None
-    for m in range(ub):
-        gam0, gam1 = _gam(x_ctr, 2 * m, n), _gam(x_ctr, 2 * m + 1, n)
-        Gam = gam0 + gam1
-        Gam = (Gam + Gam.t()) / 2
-        Sig = (-gam0 + 2 * Gam) if m == 0 else (Sig + 2 * Gam)
-        if is_pos_def(Sig):
-            sn = m
-            break
-    if sn > (ub - 1):
-        raise RuntimeError('Not enough samples')
-    last_dtm = torch.det(Sig).item()
-    for m in range(sn + 1, ub):
-        gam0, gam1 = _gam(x_ctr, 2 * m, n), _gam(x_ctr, 2 * m + 1, n)
-        Gam = gam0 + gam1
-        Gam = (Gam + Gam.t()) / 2
-        Sig1 = Sig + 2 * Gam
-        current_dtm = torch.det(Sig1).item()
-        if current_dtm <= last_dtm:
-            break
-        Sig = Sig1.clone()
-        last_dtm = current_dtm
-        if adjust:
-            eigenvals, eigenvecs = torch.linalg.eigh(Gam)  # the reference's torch.symeig (:76) no longer exists
-            eigenvals = torch.clamp(eigenvals, max=0)
-            Gamadj = Gamadj - eigenvecs @ torch.diag(eigenvals) @ eigenvecs.t()
-    if adjust:
-        Sig = Sig + 2 * Gamadj
-    return Sig
+    """Initial-sequence estimator of the asymptotic covariance of one chain x [n, p] (eeyore/stats/inse_mc_cov.py:9-83);
+    RuntimeError('Not enough samples') as there."""
+    return _chain_mc_covs(x.unsqueeze(0), adjust)[0]
+
+
+def _bad_method(method):
+    return ValueError('The method can be inse or iid, {} was given'.format(method))   # the reference's text, mc_cov.py:10
+
+
+_ESTIMATORS = {   # eeyore/stats/mc_cov.py:4-10
+    'inse': lambda x, adjust, rowvar: inse_mc_cov(x, adjust=adjust),
+    'iid': lambda x, adjust, rowvar: cov(x, rowvar=rowvar),   # the plain sample covariance
+}
 
 
 def mc_cov(x, method='inse', adjust=False, rowvar=False):
-    """eeyore/stats/mc_cov.py:4-10."""
-    if method == 'inse':
-        return inse_mc_cov(x, adjust=adjust)
-    elif method == 'iid':
-        return cov(x, rowvar=rowvar)
-    raise ValueError('The method can be inse or iid, {} was given'.format(method))
+    """Monte Carlo covariance of one chain by the named estimator (eeyore/stats/mc_cov.py:4-10)."""
+    if method not in _ESTIMATORS:
+        raise _bad_method(method)
+    return _ESTIMATORS[method](x, adjust, rowvar)
 
 
 def mc_se_from_cov(x):
-    return torch.diag(x).sqrt()
+    """Monte Carlo standard errors: root of the diagonal (eeyore/stats/mc_se_from_cov.py:3-4)."""
+    return torch.diagonal(x).sqrt()
 
 
-def mc_se(x, method='inse', adjust=False, rowvar=False):
-    return mc_se_from_cov(mc_cov(x, method=method, adjust=adjust, rowvar=rowvar))
+def _after_mc_cov(finish, cite):
+    def stat(x, method='inse', adjust=False, rowvar=False):
+        return finish(mc_cov(x, method, adjust, rowvar))
+    stat.__doc__ = f"{finish.__name__} of mc_cov(x, ...) ({cite})."
+    return stat
 
 
-def mc_cor(x, method='inse', adjust=False, rowvar=False):
-    return cor_from_cov(mc_cov(x, method=method, adjust=adjust, rowvar=rowvar))
+mc_se = _after_mc_cov(mc_se_from_cov, "eeyore/stats/mc_se.py:4-5")
+mc_cor = _after_mc_cov(cor_from_cov, "eeyore/stats/mc_cor.py")
 
 
+# ---------------------------------------------------------------------------------------------- ESS and R-hat
 def multi_ess(x, mc_cov_mat=None, method='inse', adjust=False):
-    """eeyore/stats/multi_ess.py:6-14: n (det(cov) / det(mc_cov))^(1/p)."""
-    num_iters, num_pars = x.shape
-    cov_mat_det = torch.det(cov(x, rowvar=False)).item()
-    mc_cov_mat_det = torch.det(
-        mc_cov(x, method=method, adjust=adjust, rowvar=False) if mc_cov_mat is None else mc_cov_mat
-    ).item()
-    return num_iters * ((cov_mat_det / mc_cov_mat_det) ** (1/num_pars))
+    """Multivariate effective sample size of one chain x [n, p]: n (det cov / det mc_cov)^(1/p)
+    (eeyore/stats/multi_ess.py:6-14), a Python float."""
+    n, p = x.shape
+    asymptotic = mc_cov(x, method=method, adjust=adjust) if mc_cov_mat is None else mc_cov_mat
+    ratio = torch.linalg.det(cov(x)).item() / torch.linalg.det(asymptotic).item()
+    return n * ratio ** (1 / p)
 
 
 def multi_rhat(x, mc_cov_mat=None, method='inse', adjust=False):
-    """eeyore/stats/multi_rhat.py:10-40.  x [num_chains, num_iters, num_pars].
-    Returns (rhat, imag part of the leading eigenvalue, W, B, is_w_pd, is_b_pd)."""
-    num_chains, num_iters, num_pars = x.shape
-    w = torch.zeros([num_pars, num_pars], dtype=x.dtype, device=x.device)
-    for i in range(num_chains):
-        w = w + (mc_cov(x[i], method=method, adjust=adjust, rowvar=False) if mc_cov_mat is None else mc_cov_mat[i])
-    w = w / num_chains
-    is_w_pd = is_pos_def(w)
-    if not is_w_pd:
-        w = nearest_pd(w)
-    b = cov(x.mean(1), rowvar=False)
-    is_b_pd = is_pos_def(b)
-    if not is_b_pd:
-        b = nearest_pd(b)
-    eigvals = torch.linalg.eigvals(torch.matmul(torch.inverse(w), b))
-    k = eigvals.real.argmax().item()
-    rhat = eigvals.real[k].item()
-    rhat = ((num_iters - 1) / num_iters) + ((num_chains + 1) / num_chains) * rhat
-    return rhat, eigvals.imag[k].item(), w, b, is_w_pd, is_b_pd
+    """Multivariate potential scale reduction of the chains x [m, n, p] (eeyore/stats/multi_rhat.py:10-40; Brooks &
+    Gelman 1998, lemma 2).  Returns, as the reference, (rhat, imaginary part of the leading eigenvalue, W, B, whether W
+    was positive definite, whether B was).  The within-chain matrices of all chains come from one batched pass."""
+    m, n, p = x.shape
+    if mc_cov_mat is not None:
+        within = torch.stack([mc_cov_mat[i] for i in range(m)])
+    elif method == 'inse':
+        within = _chain_mc_covs(x, adjust)
+    elif method in _ESTIMATORS:
+        within = torch.stack([mc_cov(x[i], method, adjust) for i in range(m)]).reshape(m, p, p)
+    else:
+        raise _bad_method(method)
+    return batched.multi_rhat_from_parts(within.sum(0), x.mean(1), n)
 
 
+# ---------------------------------------------------------------------------------------------- running means
 def running_mean(x, dim=0):
-    """eeyore/stats/running_mean.py:3-10."""
-    n = x.size(dim)
-    shape = [1] * x.dim()
-    shape[dim] = -1
-    return torch.cumsum(x, dim=dim) / torch.arange(1, n + 1, device=x.device).view(shape)
+    """Mean of the first k entries along ``dim`` for every k (eeyore/stats/running_mean.py:3-10)."""
+    counts = torch.arange(1, x.shape[dim] + 1, device=x.device, dtype=x.dtype if x.is_floating_point() else None)
+    return x.cumsum(dim) / counts.reshape([-1 if d == dim % x.dim() else 1 for d in range(x.dim())])
 
 
 def recursive_mean(lastmean, n, x, offset=0):
-    k = n - offset
-    return ((k - 1) * lastmean + x) / k
+    """The mean after the n-th value from the mean before it (eeyore/stats/recursive_mean.py)."""
+    seen = n - offset
+    return ((seen - 1) * lastmean + x) / seen

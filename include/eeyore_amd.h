@@ -7,8 +7,10 @@
  * Conventions
  *  - every `const void*` / `void*` data argument is a DEVICE pointer (torch.Tensor.data_ptr()) of the plan's
  *    dtype unless stated otherwise; the caller owns every buffer, the library never returns memory;
- *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); compute entry points are
- *    asynchronous on it; ey_plan_create / ey_plan_set_data / ey_plan_set_prior / ey_plan_destroy synchronise;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); compute entry points AND ey_plan_set_data
+ *    are asynchronous on it (set_data: device-to-device copies and packing kernels on `stream`; it allocates -- and
+ *    then synchronises the device -- only when a batch is larger than any before it); ey_plan_create /
+ *    ey_plan_set_prior / ey_plan_destroy synchronise;
  *  - return value 0 = EY_OK, negative = ey_status; ey_last_error() gives a thread-local message;
  *  - parameters are flat `theta[C, P]`, chain-major, each row in nn.Module.parameters() order: per layer
  *    W_l [d_{l+1} x d_l] row-major then b_l (eeyore/models/model.py:38-55, eeyore/models/mlp.py:37-43);
@@ -63,9 +65,12 @@ enum ey_products { EY_PRODUCTS_BF16X3 = 0, EY_PRODUCTS_EXACT = 1 };
 /* EY_OPT_ROW_WAVES: tiny models (at most three layers, eight inputs, other widths <= 4: the reference's own test and example
  * models) on batches of 128 rows or more may give a chain up to four waves, each taking every fourth 64-row tile of an
  * evaluation; the waves' partial gradients are added in a fixed order, which is not the order one wave adds them in, so the
- * two differ in the last bits.  EY_ROW_WAVES_AUTO (default; environment EY_ROW_WAVES=0|1|2) uses them while one wave per
- * chain would leave the chip idle (chains <= 4 x CUs): BASELINE config 2 (MALA, 256 chains, N = 256) 7.7 -> 5.4 us per draw;
- * a caller who needs a chain's bits not to depend on how many chains share its launch sets _OFF or _ON. */
+ * two differ in the last bits.  EY_ROW_WAVES_OFF is the default (environment EY_ROW_WAVES=0|1|2 sets what new plans start
+ * with): a chain's bits then depend on (seed, chain_offset + chain, iteration) alone -- not on how many chains share the
+ * launch, how they are sharded over ranks, or the device's CU count.  _ON pins the waves (same guarantee, the other
+ * summation order).  EY_ROW_WAVES_AUTO is the opt-in latency setting: the waves while one wave per chain would leave the
+ * chip idle (chains <= 4 x CUs), so a chain's last bits follow the launch's chain count: BASELINE config 2 (MALA, 256
+ * chains, N = 256) 7.7 -> 5.4 us per draw (tools/bench_configs.py opts in). */
 enum ey_row_waves { EY_ROW_WAVES_OFF = 0, EY_ROW_WAVES_ON = 1, EY_ROW_WAVES_AUTO = 2 };
 
 enum ey_flags {

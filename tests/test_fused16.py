@@ -377,3 +377,53 @@ def test_heads_the_fused_kernels_do_not_take_are_routed_elsewhere():
                 to, go, _, _ = co.log_target_grad(th0[c])
                 np.testing.assert_allclose(t[c].item(), to, rtol=tol * 5, atol=tol * 10)
                 np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=tol * 50, atol=tol * 5 * max(1.0, np.abs(go).max()))
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_fused16_f64_exp_limits_match_the_library(act):
+    """The lean f64 exp of the fused kernels at its limits: inputs of +-1e308 and products that overflow
+    to +-inf in the first layer saturate the hidden units exactly as torch / libm do (sigmoid 0 / 1, tanh -1 / 1) -- value
+    and gradient finite and equal to the C oracle's, which calls the library's exp.  (A sigmoid unit at -inf is 1e-300 here,
+    not 0 -- the lean reciprocal, DESIGN 4.4 -- which only shows against an input of 1e308, so the sigmoid case keeps W0 > 0.)"""
+    from eeyore_amd.plan import Plan
+    dims, acts, dt = [1, 16, 16, 2], [act, 1, 0], torch.float64
+    x = np.array([[1e308], [-1e308 if act == 2 else 3e307], [1e300], [-1e300 if act == 2 else 1e299], [1.0], [-0.5], [710.0], [-746.0]])
+    y = np.eye(2)[[0, 1, 1, 0, 0, 1, 0, 1]]
+    P = sum((dims[l] + 1) * dims[l + 1] for l in range(3))
+    rng = np.random.default_rng(5)
+    th0 = 0.3 * rng.standard_normal((4, P))
+    th0[:, :16] = (np.sign(th0[:, :16]) if act == 2 else 1.0) * (5.0 + 15.0 * rng.random((4, 16)))   # |w| in 5 .. 20: w x overflows
+    pl = Plan(dims, [1, 1, 1], acts, 1, dt, DEV)
+    pl.set_data(_t(x, dt), _t(y, dt))
+    pl.set_prior(torch.zeros(P), torch.full((P,), 10.0))
+    assert pl.kernel == "fused16"
+    co = COracle(dims, acts, 1, x, y, np.zeros(P), np.full(P, 10.0), dtype=np.float64, nthreads=2)
+    t, g = pl.log_target_grad(_t(th0, dt))
+    for c in range(4):
+        to, go, _, _ = co.log_target_grad(th0[c])
+        assert np.isfinite(to) and np.isfinite(go).all()
+        np.testing.assert_allclose(t[c].item(), to, rtol=1e-10)
+        np.testing.assert_allclose(g[c].cpu().numpy(), go, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(go).max()))
+
+
+def test_fused16_built_at_O1_passes_the_oracle_suite():
+    """the -O1 build of this family computed wrong results (MLP(13-29-4) BCE in f64 first of all) because the
+    compiler scheduled an LDS load into the SrcC registers of a running v_mfma_f64_16x16x4_f64 directly behind it; the
+    build now passes every translation unit's assembly through csrc/mfma_load_hazard.py.  `make o1` builds the family at
+    -O1 through the same pipeline (161 loads padded) and this test runs the oracle suite above -- every mode, the fixed
+    shapes and the random ones, the reproducer among them -- on that library in a child process."""
+    import subprocess
+    import sys
+    from eeyore_amd import _lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(L.O1_LIB_PATH):
+        subprocess.check_call(["make", "-C", L.CSRC, "-j8", "o1"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, EEYORE_AMD_LIB=L.O1_LIB_PATH, EY_FUZZ_SEEDS="32")
+    check = subprocess.run([sys.executable, os.path.join(root, "tools", "f16_check.py"), "13,29,4", "1,1", "0", "f64", "7"],
+                           env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert check.returncode == 0 and "PASS" in check.stdout, check.stdout[-2000:]
+    suite = subprocess.run([sys.executable, "-m", "pytest", "tests/test_fused16.py", "-q", "-x", "-p", "no:cacheprovider",
+                            "-k", "value_gradient_and_draws or philox_and_run_blocks or layers_without_bias"],
+                           env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert suite.returncode == 0, suite.stdout[-3000:]
+    assert " passed" in suite.stdout and "failed" not in suite.stdout

@@ -1166,7 +1166,7 @@ def test_row_waves_option_tiny_models():
         pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV)
         pl.set_data(_t(x, dt), _t(y, dt))
         pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
-        assert pl.row_waves == "auto"
+        assert pl.row_waves == "off"   # the default: a chain's bits do not depend on the launch's chain count
         with pytest.raises(ValueError):
             pl.row_waves = "sometimes"
         co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=npdt, nthreads=4)
@@ -1203,6 +1203,14 @@ def test_row_waves_option_tiny_models():
             np.testing.assert_allclose(va.cpu().numpy(), vb.cpu().numpy(), rtol=tol * 10, atol=tol * 100)
         # pinned: chain 0's bits are the same alone and among 5000 chains; auto: 'on' for few chains, 'off' for many
         big = torch.cat([_t(th0[:1], dt)] * 5000)
+        fresh = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV)   # an untouched plan: the default setting
+        fresh.set_data(_t(x, dt), _t(y, dt))
+        fresh.set_prior(torch.tensor(mu), torch.tensor(sigma))
+        d1 = [_t(th0[:1], dt).clone(), *fresh.log_target_grad(_t(th0[:1], dt))]
+        dN = [big.clone(), *fresh.log_target_grad(big)]
+        fresh.mala_run(*d1, 1e-3, 3, seed=11, it=0, chain_offset=40)
+        fresh.mala_run(*dN, 1e-3, 3, seed=11, it=0, chain_offset=40)
+        assert all(torch.equal(p_[0], q_[0]) for p_, q_ in zip(d1, dN)), "default: one chain alone == among 5000"
         for mode in ("off", "on"):
             pl.row_waves = mode
             g1 = pl.log_target_grad(_t(th0[:1], dt))[1]

@@ -65,3 +65,27 @@ def test_batched_multivariate_inse_and_ess_over_chains():
             assert torch.isnan(got[i]).all()
             continue
         np.testing.assert_allclose(got[i].numpy(), st.inse_mc_cov(y[i]).numpy(), rtol=1e-10, atol=1e-13)
+
+
+def test_adjusted_inse_adds_a_positive_semidefinite_lift():
+    """inse_mc_cov(adjust=True) (inse_mc_cov.py:72-81; the reference's own code calls the removed torch.symeig, so there is
+    no captured value): the adjusted estimate is the plain one plus twice the summed negative parts of the accepted lag
+    pairs' Gam, i.e. plus a positive semi-definite matrix; methods and error text as the reference."""
+    import pytest
+    z = load("g7_stats.npz")
+    x = torch.tensor(z["chains"])
+    for i in range(4):
+        plain, adj = st.inse_mc_cov(x[i]), st.inse_mc_cov(x[i], adjust=True)
+        lift = adj - plain
+        assert torch.equal(lift, lift.T) or torch.allclose(lift, lift.T, atol=1e-15)
+        assert torch.linalg.eigvalsh((lift + lift.T) / 2).min().item() > -1e-12
+        np.testing.assert_allclose(st.mc_se(x[i], adjust=True).numpy(), np.sqrt(np.diag(adj.numpy())), rtol=1e-12)
+    np.testing.assert_allclose(st.mc_cov(x[0], method='iid').numpy(), z["cov"][0], rtol=1e-12)
+    with pytest.raises(ValueError, match='The method can be inse or iid, nope was given'):
+        st.mc_cov(x[0], method='nope')
+    with pytest.raises(ValueError):
+        st.multi_rhat(x, method='nope')
+    with pytest.raises(RuntimeError, match='Not enough samples'):
+        st.inse_mc_cov(torch.ones(20, 3, dtype=torch.float64))
+    r_iid = st.multi_rhat(x, method='iid')[0]
+    assert np.isfinite(r_iid)

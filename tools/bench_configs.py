@@ -55,6 +55,7 @@ print(f"cfg1 as above, 1000 iterations per launch (ey_hmc_run): {dt * 1e6:.2f} u
 for dtype in (torch.float32, torch.float64):
     data = synthetic.binary_xor_like(256, dtype=dtype, device=dev)
     pl = Plan([2, 3, 2, 1], [1, 1, 1], [1, 1, 1], 0, dtype, dev)
+    pl.row_waves = "auto"   # the opt-in latency setting (the default, 'off', keeps a chain's bits independent of the chain count)
     pl.set_data(data.x, data.y)
     pl.set_prior(torch.zeros(20), torch.full((20,), float(np.sqrt(3.0))))
     for C in (256, 65536):

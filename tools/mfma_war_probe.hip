@@ -1,0 +1,244 @@
+// How long after an MFMA issues may a LOAD overwrite the registers it reads as SrcC?  (gfx950)
+//
+// Found with tools/f16_asm_bisect.py: the -O1 build of k_fused16<double, 32, 4, 3> is wrong because of
+//     v_mfma_f64_16x16x4_f64 a[16:23], v[26:27], v[34:35], a[24:31]
+//     ds_read_b64  v[16:17], ...
+//     ds_read_b128 a[24:27], ...          <- lands in the MFMA's SrcC before the MFMA has read it
+// The compiler's hazard recogniser knows VALU writes after MFMA reads (a few wait states) but no LOAD writes: a load's
+// latency used to be longer than any MFMA.  This probe issues one MFMA with SrcC != vDst, then K wait states, then a load
+// (LDS or global) into the SrcC registers, and checks D = A B + C_original.  One wave, and a second pass with the SIMD kept
+// busy by a partner wave.
+//   hipcc -O3 --offload-arch=gfx950 tools/mfma_war_probe.hip -o tools/mfma_war_probe && tools/mfma_war_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+
+enum { DGEMM16 = 0, DGEMM4 = 1, F32_32X32X2 = 2, BF16_32X32X16 = 3 };
+
+// K < 0: the load follows the MFMA directly; K >= 0: s_nop K (K + 1 wait states) between them.
+// GLOBAL: the overwriting load is a global_load instead of ds_read.
+template <int KIND, int K, bool GLOBAL>
+__global__ void k_war(const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ poison_g) {
+  __shared__ __attribute__((aligned(16))) double poison[64 * 8];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 64 * 8; i += blockDim.x) poison[i] = 1.0e6;
+  __syncthreads();
+  if (threadIdx.x >= 64) {  // partner waves: keep the LDS and the SIMD busy, touch nothing of wave 0
+    double s = 0;
+    for (int i = 0; i < 2000; ++i) s += poison[(lane * 7 + i) & 511];
+    if (s == 12345.0) out[4096 + threadIdx.x] = s;
+    return;
+  }
+  const double a = in[lane], b = in[64 + lane];
+  const unsigned lds_addr = (unsigned)(size_t)(poison + lane * 8);  // LDS byte address (low 32 bits of the flat address)
+  const double* gaddr = poison_g + lane * 8;
+  double d[8];
+  if constexpr (KIND == DGEMM16) {
+    // C = 1.0 in a[8:15]; D in a[0:7]
+    asm volatile(
+        "v_accvgpr_write_b32 a8, 0\n v_accvgpr_write_b32 a9, %[hi]\n"
+        "v_accvgpr_write_b32 a10, 0\n v_accvgpr_write_b32 a11, %[hi]\n"
+        "v_accvgpr_write_b32 a12, 0\n v_accvgpr_write_b32 a13, %[hi]\n"
+        "v_accvgpr_write_b32 a14, 0\n v_accvgpr_write_b32 a15, %[hi]\n"
+        "s_nop 7\n s_nop 7\n s_nop 7\n"
+        "v_mfma_f64_16x16x4_f64 a[0:7], %[a], %[b], a[8:15]\n"
+        ".if %[k] >= 0\n s_nop %[k]\n .endif\n"
+        ".if %[g]\n global_load_dwordx4 a[8:11], %[ga], off\n global_load_dwordx4 a[12:15], %[ga], off offset:16\n"
+        ".else\n ds_read_b128 a[8:11], %[la]\n ds_read_b128 a[12:15], %[la] offset:16\n .endif\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7\n s_nop 7\n"
+        "v_accvgpr_read_b32 %[d0], a0\n v_accvgpr_read_b32 %[d1], a1\n v_accvgpr_read_b32 %[d2], a2\n v_accvgpr_read_b32 %[d3], a3\n"
+        "v_accvgpr_read_b32 %[d4], a4\n v_accvgpr_read_b32 %[d5], a5\n v_accvgpr_read_b32 %[d6], a6\n v_accvgpr_read_b32 %[d7], a7\n"
+        : [d0] "=&v"(((int*)d)[0]), [d1] "=&v"(((int*)d)[1]), [d2] "=&v"(((int*)d)[2]), [d3] "=&v"(((int*)d)[3]),
+          [d4] "=&v"(((int*)d)[4]), [d5] "=&v"(((int*)d)[5]), [d6] "=&v"(((int*)d)[6]), [d7] "=&v"(((int*)d)[7])
+        : [a] "v"(a), [b] "v"(b), [la] "v"(lds_addr), [ga] "v"(gaddr), [k] "n"(K), [g] "n"(GLOBAL ? 1 : 0), [hi] "v"(0x3ff00000)
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "memory");
+    for (int r = 0; r < 4; ++r) out[r * 64 + lane] = d[r];
+  } else if constexpr (KIND == DGEMM4) {
+    asm volatile(
+        "v_accvgpr_write_b32 a8, 0\n v_accvgpr_write_b32 a9, %[hi]\n"
+        "s_nop 7\n s_nop 7\n"
+        "v_mfma_f64_4x4x4_4b_f64 a[0:1], %[a], %[b], a[8:9]\n"
+        ".if %[k] >= 0\n s_nop %[k]\n .endif\n"
+        ".if %[g]\n global_load_dwordx2 a[8:9], %[ga], off\n"
+        ".else\n ds_read_b64 a[8:9], %[la]\n .endif\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7\n"
+        "v_accvgpr_read_b32 %[d0], a0\n v_accvgpr_read_b32 %[d1], a1\n"
+        : [d0] "=&v"(((int*)d)[0]), [d1] "=&v"(((int*)d)[1])
+        : [a] "v"(a), [b] "v"(b), [la] "v"(lds_addr), [ga] "v"(gaddr), [k] "n"(K), [g] "n"(GLOBAL ? 1 : 0), [hi] "v"(0x3ff00000)
+        : "a0", "a1", "a8", "a9", "memory");
+    out[lane] = d[0];
+    for (int r = 1; r < 4; ++r) out[r * 64 + lane] = 0.0;
+  } else {
+    // f32 32x32x2 (16 passes) / bf16 32x32x16 (8 passes on gfx950): C = 1.0f in a[16:31], D in a[0:15]
+    const float af = (float)a, bf = (float)b;
+    float e[16];
+    typedef short bf8 __attribute__((ext_vector_type(8)));
+    bf8 av, bv;
+    for (int i = 0; i < 8; ++i) { av[i] = (short)0x3f80; bv[i] = (short)(i == 0 ? 0x3f80 : 0); }  // 1.0 bf16
+#define WR16(base)                                                                                                            \
+  "v_accvgpr_write_b32 a16, 1.0\n v_accvgpr_write_b32 a17, 1.0\n v_accvgpr_write_b32 a18, 1.0\n v_accvgpr_write_b32 a19, 1.0\n" \
+  "v_accvgpr_write_b32 a20, 1.0\n v_accvgpr_write_b32 a21, 1.0\n v_accvgpr_write_b32 a22, 1.0\n v_accvgpr_write_b32 a23, 1.0\n" \
+  "v_accvgpr_write_b32 a24, 1.0\n v_accvgpr_write_b32 a25, 1.0\n v_accvgpr_write_b32 a26, 1.0\n v_accvgpr_write_b32 a27, 1.0\n" \
+  "v_accvgpr_write_b32 a28, 1.0\n v_accvgpr_write_b32 a29, 1.0\n v_accvgpr_write_b32 a30, 1.0\n v_accvgpr_write_b32 a31, 1.0\n"
+#define TAIL                                                                                                                  \
+  ".if %[k] >= 0\n s_nop %[k]\n .endif\n"                                                                                     \
+  ".if %[g]\n global_load_dwordx4 a[16:19], %[ga], off\n global_load_dwordx4 a[20:23], %[ga], off offset:16\n"                 \
+  "global_load_dwordx4 a[24:27], %[ga], off offset:32\n global_load_dwordx4 a[28:31], %[ga], off offset:48\n"                  \
+  ".else\n ds_read_b128 a[16:19], %[la]\n ds_read_b128 a[20:23], %[la] offset:16\n"                                           \
+  "ds_read_b128 a[24:27], %[la] offset:32\n ds_read_b128 a[28:31], %[la] offset:48\n .endif\n"                                \
+  "s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7\n s_nop 7\n"                                                             \
+  "v_accvgpr_read_b32 %[d0], a0\n v_accvgpr_read_b32 %[d1], a1\n v_accvgpr_read_b32 %[d2], a2\n v_accvgpr_read_b32 %[d3], a3\n" \
+  "v_accvgpr_read_b32 %[d4], a4\n v_accvgpr_read_b32 %[d5], a5\n v_accvgpr_read_b32 %[d6], a6\n v_accvgpr_read_b32 %[d7], a7\n" \
+  "v_accvgpr_read_b32 %[d8], a8\n v_accvgpr_read_b32 %[d9], a9\n v_accvgpr_read_b32 %[d10], a10\n v_accvgpr_read_b32 %[d11], a11\n" \
+  "v_accvgpr_read_b32 %[d12], a12\n v_accvgpr_read_b32 %[d13], a13\n v_accvgpr_read_b32 %[d14], a14\n v_accvgpr_read_b32 %[d15], a15\n"
+#define OUTS                                                                                                                  \
+  [d0] "=&v"(e[0]), [d1] "=&v"(e[1]), [d2] "=&v"(e[2]), [d3] "=&v"(e[3]), [d4] "=&v"(e[4]), [d5] "=&v"(e[5]), [d6] "=&v"(e[6]), \
+      [d7] "=&v"(e[7]), [d8] "=&v"(e[8]), [d9] "=&v"(e[9]), [d10] "=&v"(e[10]), [d11] "=&v"(e[11]), [d12] "=&v"(e[12]),       \
+      [d13] "=&v"(e[13]), [d14] "=&v"(e[14]), [d15] "=&v"(e[15])
+#define CLOB                                                                                                                  \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18",  \
+      "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "memory"
+    if constexpr (KIND == F32_32X32X2) {
+      asm volatile(WR16() "s_nop 7\n s_nop 7\n s_nop 7\n"
+                   "v_mfma_f32_32x32x2_f32 a[0:15], %[a], %[b], a[16:31]\n" TAIL
+                   : OUTS
+                   : [a] "v"(af), [b] "v"(bf), [la] "v"(lds_addr), [ga] "v"(gaddr), [k] "n"(K), [g] "n"(GLOBAL ? 1 : 0)
+                   : CLOB);
+    } else {
+      asm volatile(WR16() "s_nop 7\n s_nop 7\n s_nop 7\n"
+                   "v_mfma_f32_32x32x16_bf16 a[0:15], %[a], %[b], a[16:31]\n" TAIL
+                   : OUTS
+                   : [a] "v"(av), [b] "v"(bv), [la] "v"(lds_addr), [ga] "v"(gaddr), [k] "n"(K), [g] "n"(GLOBAL ? 1 : 0)
+                   : CLOB);
+    }
+    // report: the largest |D - expected| over the lane's 16 results as a double in slot 0; expected is C + (A B): for f32
+    // A B = sum_k a b over the two k (lanes differ), so just look for the poison: any |D| > 1e5
+    double worst = 0;
+    for (int r = 0; r < 16; ++r) worst = fmax(worst, fabs((double)e[r]));
+    out[lane] = worst;
+    for (int r = 1; r < 4; ++r) out[r * 64 + lane] = 0.0;
+  }
+}
+
+template <int KIND, int K, bool GLOBAL>
+static bool run(int threads, const double* din, double* dout, const double* dpoison, int repeat) {
+  bool bad = false;
+  for (int rep = 0; rep < repeat && !bad; ++rep) {
+    k_war<KIND, K, GLOBAL><<<1, threads>>>(din, dout, dpoison);
+    std::vector<double> h(256);
+    (void)hipMemcpy(h.data(), dout, 256 * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 256; ++i)
+      if (std::fabs(h[i]) > 1e5) bad = true;  // the poison (1e6) entered the accumulation
+  }
+  return bad;
+}
+
+template <int KIND, bool GLOBAL>
+static void sweep(const char* name, const double* din, double* dout, const double* dpoison) {
+  for (int threads : {64, 256}) {
+    printf("%-22s %-6s load, %s: wait states between MFMA and load -> result ", name, GLOBAL ? "global" : "LDS",
+           threads == 64 ? "one wave        " : "four waves / CU ");
+    bool r[18];
+    r[0] = run<KIND, -1, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[1] = run<KIND, 0, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[2] = run<KIND, 1, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[3] = run<KIND, 2, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[4] = run<KIND, 3, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[5] = run<KIND, 4, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[6] = run<KIND, 5, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[7] = run<KIND, 6, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[8] = run<KIND, 7, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[9] = run<KIND, 8, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[10] = run<KIND, 9, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[11] = run<KIND, 10, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[12] = run<KIND, 11, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[13] = run<KIND, 12, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[14] = run<KIND, 13, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[15] = run<KIND, 14, GLOBAL>(threads, din, dout, dpoison, 20);
+    r[16] = run<KIND, 15, GLOBAL>(threads, din, dout, dpoison, 20);
+    for (int k = 0; k <= 16; ++k) printf("%d:%s ", k, r[k] ? "WRONG" : "ok");
+    printf("\n");
+  }
+}
+
+// Second question: WHAT between the MFMA and the load gives the MFMA the time it needs?  FILL = 0: s_nop; 1: LDS reads of
+// unrelated registers (as in the failing build); 2: VALU moves; 3: SALU moves.  COUNT instructions of that kind.
+template <int FILL, int COUNT>
+__global__ void k_fill(const double* __restrict__ in, double* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) double poison[64 * 8];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 64 * 8; i += blockDim.x) poison[i] = 1.0e6;
+  __syncthreads();
+  const double a = in[lane], b = in[64 + lane];
+  const unsigned lds_addr = (unsigned)(size_t)(poison + lane * 8);
+  double d[4];
+  int scratch_v;
+  asm volatile(
+      "v_accvgpr_write_b32 a8, 0\n v_accvgpr_write_b32 a9, %[hi]\n v_accvgpr_write_b32 a10, 0\n v_accvgpr_write_b32 a11, %[hi]\n"
+      "v_accvgpr_write_b32 a12, 0\n v_accvgpr_write_b32 a13, %[hi]\n v_accvgpr_write_b32 a14, 0\n v_accvgpr_write_b32 a15, %[hi]\n"
+      "s_nop 7\n s_nop 7\n s_nop 7\n"
+      "v_mfma_f64_16x16x4_f64 a[0:7], %[a], %[b], a[8:15]\n"
+      ".rept %[n]\n"
+      ".if %[f] == 0\n s_nop 0\n .endif\n"
+      ".if %[f] == 1\n ds_read_b32 %[t], %[la] offset:32\n .endif\n"
+      ".if %[f] == 2\n v_mov_b32 %[t], %[la]\n .endif\n"
+      ".if %[f] == 3\n s_mov_b32 s20, 0\n .endif\n"
+      ".endr\n"
+      "ds_read_b128 a[8:11], %[la]\n ds_read_b128 a[12:15], %[la] offset:16\n"
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7\n s_nop 7\n"
+      "v_accvgpr_read_b32 %[d0], a0\n v_accvgpr_read_b32 %[d1], a1\n v_accvgpr_read_b32 %[d2], a2\n v_accvgpr_read_b32 %[d3], a3\n"
+      "v_accvgpr_read_b32 %[d4], a4\n v_accvgpr_read_b32 %[d5], a5\n v_accvgpr_read_b32 %[d6], a6\n v_accvgpr_read_b32 %[d7], a7\n"
+      : [d0] "=&v"(((int*)d)[0]), [d1] "=&v"(((int*)d)[1]), [d2] "=&v"(((int*)d)[2]), [d3] "=&v"(((int*)d)[3]),
+        [d4] "=&v"(((int*)d)[4]), [d5] "=&v"(((int*)d)[5]), [d6] "=&v"(((int*)d)[6]), [d7] "=&v"(((int*)d)[7]), [t] "=&v"(scratch_v)
+      : [a] "v"(a), [b] "v"(b), [la] "v"(lds_addr), [n] "n"(COUNT), [f] "n"(FILL), [hi] "v"(0x3ff00000)
+      : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "s20", "memory");
+  for (int r = 0; r < 4; ++r) out[r * 64 + lane] = d[r];
+  if (scratch_v == 0x7fffffff) out[1024] = 1.0;
+}
+template <int FILL, int COUNT>
+static bool run_fill(const double* din, double* dout) {
+  bool bad = false;
+  for (int rep = 0; rep < 20 && !bad; ++rep) {
+    k_fill<FILL, COUNT><<<1, 64>>>(din, dout);
+    std::vector<double> h(256);
+    (void)hipMemcpy(h.data(), dout, 256 * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 256; ++i)
+      if (std::fabs(h[i]) > 1e5) bad = true;
+  }
+  return bad;
+}
+template <int FILL>
+static void sweep_fill(const char* what, const double* din, double* dout) {
+  printf("v_mfma_f64_16x16x4, then n x %-26s then the LDS load into SrcC: ", what);
+  bool r[9] = {run_fill<FILL, 0>(din, dout), run_fill<FILL, 1>(din, dout), run_fill<FILL, 2>(din, dout),
+               run_fill<FILL, 3>(din, dout), run_fill<FILL, 4>(din, dout), run_fill<FILL, 6>(din, dout),
+               run_fill<FILL, 8>(din, dout), run_fill<FILL, 12>(din, dout), run_fill<FILL, 16>(din, dout)};
+  const int ns[9] = {0, 1, 2, 3, 4, 6, 8, 12, 16};
+  for (int k = 0; k < 9; ++k) printf("%d:%s ", ns[k], r[k] ? "WRONG" : "ok");
+  printf("\n");
+}
+
+int main() {
+  double *din, *dout, *dpoison;
+  (void)hipMalloc(&din, 128 * 8); (void)hipMalloc(&dout, 8192 * 8); (void)hipMalloc(&dpoison, 64 * 8 * 8);
+  std::vector<double> h(128), p(512, 1.0e6);
+  for (int i = 0; i < 128; ++i) h[i] = 0.5 + 0.01 * i;
+  (void)hipMemcpy(din, h.data(), 128 * 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dpoison, p.data(), 512 * 8, hipMemcpyHostToDevice);
+  printf("A load into the SrcC registers of an MFMA (SrcC != vDst), K wait states after the MFMA: does the loaded value (1e6) "
+         "enter the product?\n");
+  sweep<DGEMM16, false>("v_mfma_f64_16x16x4", din, dout, dpoison);
+  sweep<DGEMM16, true>("v_mfma_f64_16x16x4", din, dout, dpoison);
+  sweep<DGEMM4, false>("v_mfma_f64_4x4x4_4b", din, dout, dpoison);
+  sweep<DGEMM4, true>("v_mfma_f64_4x4x4_4b", din, dout, dpoison);
+  sweep<F32_32X32X2, false>("v_mfma_f32_32x32x2", din, dout, dpoison);
+  sweep<F32_32X32X2, true>("v_mfma_f32_32x32x2", din, dout, dpoison);
+  sweep<BF16_32X32X16, false>("v_mfma_f32_32x32x16_bf16", din, dout, dpoison);
+  sweep<BF16_32X32X16, true>("v_mfma_f32_32x32x16_bf16", din, dout, dpoison);
+  sweep_fill<0>("s_nop 0", din, dout);
+  sweep_fill<1>("ds_read_b32 (other register)", din, dout);
+  sweep_fill<2>("v_mov_b32", din, dout);
+  sweep_fill<3>("s_mov_b32", din, dout);
+  return 0;
+}
