@@ -5,11 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one HMC iteration of every chain of the rank (one launch of the fused trajectory kernel: momentum
-draw from the in-kernel Philox stream, L = 20 leapfrog steps, accept, state update), BASELINE.json configs[2]:
+A "step" is one HMC iteration of every chain of the rank (momentum draw from the in-kernel Philox stream, L = 20
+leapfrog steps, accept, state update, and the state of every chain RECORDED as the reference's run loop records it after
+burn-in, eeyore/samplers/serial_sampler.py:35-52, eeyore/chains/chain_list.py:64-67), BASELINE.json configs[2]:
 4096 chains per GPU, MLP(4-32-32-3; sigmoid, sigmoid, None), CE-sum, prior N(0, sqrt 3), N = 150 rows, fp32.
+Steps are issued as `HMC.run` issues them: whole launches of 25 iterations (ey_hmc_run writing samples / targets /
+accept flags into the chain buffer); --steps is rounded UP to whole launches and the line says so.
 Chains shard over ranks with no collective in the step (weak scaling: 4096 chains per GPU, configs[3] at N = 8);
-when N > 1 the per-parameter R-hat summary is all-reduced over RCCL once at the end of the timed region.
+when N > 1 the per-parameter R-hat and ESS summaries are combined over RCCL once at the end of the timed region.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -31,6 +34,7 @@ L_STEPS = 20
 CHAINS_PER_GPU = 4096
 STEP_SIZE = 0.024  # ~70 % acceptance after burn-in on this target (tools/step_sweep.py: 0.02 -> 0.87, 0.03 -> 0.40)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_FLOPS = 2.5e15  # dense bf16 matrix peak (MI355X_MICROARCH.md; the 2:1-sparsity headline is twice that)
 MEASURED_F32_MFMA_TFLOPS = 145.9  # tools/peak_probe.hip on the box (profiles/r01_peak_probe.txt): the sustained clock
 
 
@@ -139,6 +143,49 @@ def cpu_baseline(x, y, sigma, cores, budget_s=9.0):
                       f"threads), {t:.1f} s"}
 
 
+def through_sampler_run(xs, ys, sigma, theta0, dev, n_iters, block, seed, chain_offset, world, gloo):
+    """The same workload through the plugin surface a reference script uses: eeyore_amd.samplers.HMC(model, theta0 [C, P],
+    ...).run(num_epochs, num_burnin_epochs=0) recording every iteration into its ChainBuffer [iters, C, P]
+    (eeyore/samplers/serial_sampler.py:35-52, eeyore/chains/chain_list.py:64-67).  One untimed run of a block first (the
+    buffer is allocated then), the same barrier / synchronize bracket and MAX over ranks as the headline.  -> seconds."""
+    from torch.distributions import Normal
+    from torch.utils.data import DataLoader
+    from eeyore_amd.chains import ChainBuffer
+    from eeyore_amd.constants import loss_functions
+    from eeyore_amd.datasets import XYDataset
+    from eeyore_amd.models import mlp
+    from eeyore_amd.samplers import HMC
+    data = XYDataset(torch.tensor(xs, dtype=torch.float32, device=dev), torch.tensor(ys, dtype=torch.float32, device=dev))
+    loader = DataLoader(data, batch_size=len(data), shuffle=False)
+    model = mlp.MLP(loss=loss_functions['multiclass_classification'],
+                    hparams=mlp.Hyperparameters(dims=DIMS, bias=3 * [True], activations=[torch.sigmoid, torch.sigmoid, None]),
+                    dtype=torch.float32, device=dev)
+    P = model.num_params()
+    model.prior = Normal(torch.zeros(P, device=dev), torch.full((P,), sigma, device=dev))
+    sampler = HMC(model, theta0=theta0, dataloader=loader, step=STEP_SIZE, num_steps=L_STEPS, seed=seed,
+                  chain_offset=chain_offset, chain=ChainBuffer(capacity=n_iters))
+    sampler.fused_block = block
+    sampler.run(num_epochs=block, num_burnin_epochs=0)   # untimed: allocates the chain buffer, warms the path
+    sampler.counter.reset()
+    sampler.get_chain().rewind()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    sampler.run(num_epochs=n_iters, num_burnin_epochs=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    chain = sampler.get_chain()
+    assert len(chain) == n_iters and chain.get_samples().shape == (n_iters, theta0.shape[0], P)
+    return elapsed, float(chain.acceptance_rate().mean().item())
+
+
 def self_launch(n_ranks, argv):
     """`bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process -- which has not
     touched the GPU: no HIP call, no torch.cuda call before this point -- starts N fresh rank processes with
@@ -199,6 +246,9 @@ def main():
     ap.add_argument("--iters-per-launch", type=int, default=25,
                     help="HMC iterations (bench steps) per kernel launch: ey_hmc_run, as HMC.run issues them; 1 = ey_hmc_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-record", action="store_true",
+                    help="do not record the chains in the timed region (round 3's figure: the kernel without the sample store)")
+    ap.add_argument("--no-sampler-run", action="store_true", help="skip the same workload timed through samplers.HMC.run")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed launches before the timed region, on top of --warmup, until the clocks have settled")
     ap.add_argument("--force-generic", action="store_true", help="time the generic VALU kernel instead of the MFMA one")
@@ -213,7 +263,7 @@ def main():
 
     from eeyore_amd import _lib as L
     from eeyore_amd.datasets import synthetic
-    from eeyore_amd.distributed import ChainStats, init_from_env
+    from eeyore_amd.distributed import ChainStats, init_from_env, reduce_ess
     from eeyore_amd.plan import Plan
 
     rank, world, local = init_from_env()
@@ -247,18 +297,33 @@ def main():
     if args.force_generic:
         ipl = 1  # the generic family replays attached moments from recorded samples; keep its one-step form
 
-    def steps(it, n):
+    # --steps rounded up to whole launches: the timed region is what HMC.run issues after burn-in
+    steps_timed = ((args.steps + ipl - 1) // ipl) * ipl
+    # the chain buffer of the timed region, [iterations, C, P] + targets + accept flags, as ChainBuffer holds a run
+    # (200 steps x 4096 x 1315 floats = 4.3 GB), and one launch's worth for the untimed launches around it
+    record = not args.no_record and not args.force_generic
+    n_rec = steps_timed if record else 0
+    rec = dict(s=plan.empty(max(n_rec, ipl), C, P), t=plan.empty(max(n_rec, ipl), C),
+               a=plan.empty(max(n_rec, ipl), C, dtype=torch.uint8)) if record else None
+
+    def steps(it, n, rec_at=None):
         """n bench steps = n HMC iterations of every chain, starting at iteration number `it`: whole launches of `ipl`
-        iterations (what HMC.run does after burn-in), then the remainder."""
+        iterations (what HMC.run does after burn-in), then the remainder.  Every launch records the chains' states,
+        log-targets and accept flags: the timed region into consecutive blocks of the chain buffer starting at `rec_at`,
+        the untimed launches into its first block."""
         done = 0
         while done < n:
             k = min(ipl, n - done)
-            if k == 1:
+            kw = {}
+            if record:
+                r0 = 0 if rec_at is None else rec_at + done
+                kw = dict(samples=rec["s"][r0:r0 + k], targets=rec["t"][r0:r0 + k], accepted_rec=rec["a"][r0:r0 + k])
+            if k == 1 and not record:
                 plan.hmc_step(theta, target, grad, STEP_SIZE, L_STEPS, seed=seed, it=it + done,
                               chain_offset=chain_offset, flags=flags, out=out)
             else:
                 plan.hmc_run(theta, target, grad, STEP_SIZE, L_STEPS, k, seed=seed, it=it + done,
-                             chain_offset=chain_offset, flags=flags, out=out)
+                             chain_offset=chain_offset, flags=flags, out=out, **kw)
             done += k
 
     # the running chain moments behind the R-hat summary are accumulated by the step kernel itself (attached moments)
@@ -295,7 +360,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps(it, args.steps); it += args.steps
+    steps(it, steps_timed, rec_at=0); it += steps_timed
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -304,9 +369,19 @@ def main():
     # the gather of chain statistics (R-hat summary; one RCCL all-reduce of [3, P] partial sums when world > 1) happens
     # once per run, not per step: timed on its own and reported in config
     t1 = time.perf_counter()
-    summ = stats.summary() if args.steps > 1 else None
+    summ = stats.summary() if steps_timed > 1 else None
     torch.cuda.synchronize()
     summary_ms = 1e3 * (time.perf_counter() - t1)
+    # ... and the effective sample sizes (configs[3]: "gather of R-hat/ESS"): every (chain, parameter) series of the
+    # recorded buffer through ey_inse_univariate on this rank, then min / mean / total per parameter over all ranks
+    # (two small all-reduces, distributed.reduce_ess); also outside the step clock, timed on its own
+    ess = None
+    if record and steps_timed >= 50:
+        from eeyore_amd.stats import batched
+        t2 = time.perf_counter()
+        ess = reduce_ess(batched.ess(rec["s"][:steps_timed]))
+        torch.cuda.synchronize()
+        ess_ms = 1e3 * (time.perf_counter() - t2)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -331,19 +406,26 @@ def main():
         other = (plan.f32_products, launch_ms())
         plan.f32_products = products
 
+    # the same workload through samplers.HMC.run -> ChainBuffer (the path a reference script takes), same start, own clock
+    via_sampler = None
+    if record and not args.no_sampler_run:
+        theta0 = 0.1 * plan.philox_normal(C, seed=0, it=0, chain_offset=chain_offset)
+        s_elapsed, s_acc = through_sampler_run(xs, ys, sigma, theta0, dev, steps_timed, ipl, seed, chain_offset, world, gloo)
+        via_sampler = (s_elapsed, s_acc)
+
     if rank == 0:
         f_step = flops_per_leapfrog_step(DIMS, N_ROWS)
         total_chains = C * world
-        value = total_chains * L_STEPS * args.steps / elapsed
+        value = total_chains * L_STEPS * steps_timed / elapsed
         achieved_tflops = f_step * L_STEPS * C * ipl / (kern_ms * 1e-3) / 1e12
         line = {
             "metric": "leapfrog-steps/sec x chains, HMC MLP(4-32-32-3)",
             "value": value,
             "unit": "leapfrog-steps/sec x chains",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps_timed,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / steps_timed,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -357,9 +439,15 @@ def main():
                 "kernel": "generic" if args.force_generic else plan.kernel,
                 "f32_products": None if args.force_generic else products,
                 "gradient_evaluations_per_iteration": L_STEPS, "iterations_per_launch": ipl,
+                "steps_requested": args.steps,
+                "steps_note": f"--steps {args.steps} rounded up to {steps_timed} = {steps_timed // ipl} whole launch(es) of {ipl} "
+                              f"iterations, as HMC.run issues them" if steps_timed != args.steps else "whole launches",
+                "recorded_in_timed_region": ("samples [steps, C, P], targets [steps, C], accepted [steps, C] (the chain buffer "
+                                             "HMC.run fills after burn-in)") if record else None,
                 "stats_summary_ms": round(summary_ms, 3),
-                "value_including_stats_summary": total_chains * L_STEPS * args.steps / (elapsed + 1e-3 * summary_ms),
+                "value_including_stats_summary": total_chains * L_STEPS * steps_timed / (elapsed + 1e-3 * summary_ms),
                 "acceptance": None if summ is None else round(summ["acceptance"], 4),
+                "rhat_max": None if summ is None else float(summ["rhat"].max().item()),
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -369,6 +457,18 @@ def main():
                 "peak_measured": MEASURED_F32_MFMA_TFLOPS, "frac_of_measured": achieved_tflops / MEASURED_F32_MFMA_TFLOPS,
             },
         }
+        if ess is not None:
+            line["config"]["ess"] = {"summary_ms": round(ess_ms, 3), "min_over_chains_and_parameters": float(ess["min"].min().item()),
+                                     "mean": float(ess["mean"].mean().item()), "total_per_parameter_mean": float(ess["total"].mean().item()),
+                                     "num_chains": ess["num_chains"], "series_without_enough_samples": ess["not_enough"],
+                                     "from": f"{steps_timed} recorded iterations of every chain (ey_inse_univariate), combined "
+                                             f"over ranks by distributed.reduce_ess"}
+        if via_sampler is not None:
+            s_value = total_chains * L_STEPS * steps_timed / via_sampler[0]
+            line["config"]["through_sampler_run"] = {
+                "value": s_value, "unit": "leapfrog-steps/sec x chains", "seconds": via_sampler[0], "iterations": steps_timed,
+                "ratio_to_headline": s_value / value, "acceptance": round(via_sampler[1], 4),
+                "path": "eeyore_amd.samplers.HMC(model, theta0 [C, P], ...).run(num_epochs, 0) -> ChainBuffer [iters, C, P]"}
         if other is not None:
             o_tflops = f_step * L_STEPS * C * ipl / (other[1] * 1e-3) / 1e12
             line["config"]["kernels"] = {
@@ -385,6 +485,13 @@ def main():
             simd_cycles = 1024 * 2.4e9 * kern_ms * 1e-3
             per = C * L_STEPS * ipl * tiles
             line["roofline"]["f32_equivalent"] = True
+            line["roofline"]["frac_is"] = ("f32-equivalent: algorithmic f32 flops / f32 MFMA peak, measured on the default kernel, "
+                                           "whose three 32x32x32 products per tile issue on the bf16 pipe (exact 3-piece split of "
+                                           "each f32 operand, f32 accumulate); frac_exact_f32_products is the like-for-like figure")
+            if other is not None:
+                line["roofline"]["frac_exact_f32_products"] = o_tflops / PEAK_F32_MFMA_TFLOPS
+            # what the bf16 pipe itself is asked for: 36 MFMAs of 2 x 32 x 32 x 16 flop per tile against the dense bf16 peak
+            line["roofline"]["bf16_pipe_flops_frac"] = per * 36 * 32768 / (kern_ms * 1e-3) / PEAK_BF16_MFMA_FLOPS
             line["roofline"]["bf16_mfma_issue_frac"] = per * 36 * 32 / simd_cycles
             line["roofline"]["f32_mfma_issue_frac"] = per * (2 * 64 + 60 * 8.4) / simd_cycles
 

@@ -34,6 +34,11 @@ class ChainBuffer(Chain):
         self.n = 0
         self.bufs = {}
 
+    def rewind(self):
+        """Forget the stored iterations but keep the device buffers (a second run of the same length records into the same
+        memory: no allocation inside it)."""
+        self.n = 0
+
     @property
     def vals(self):
         return {k: None for k in self.keys}

@@ -164,7 +164,7 @@ static void sweep(const char* name, const double* din, double* dout, const doubl
 
 // Second question: WHAT between the MFMA and the load gives the MFMA the time it needs?  FILL = 0: s_nop; 1: LDS reads of
 // unrelated registers (as in the failing build); 2: VALU moves; 3: SALU moves.  COUNT instructions of that kind.
-template <int FILL, int COUNT>
+template <int FILL, int COUNT, int PRE = 0>
 __global__ void k_fill(const double* __restrict__ in, double* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) double poison[64 * 8];
   const int lane = threadIdx.x & 63;
@@ -178,6 +178,7 @@ __global__ void k_fill(const double* __restrict__ in, double* __restrict__ out) 
       "v_accvgpr_write_b32 a8, 0\n v_accvgpr_write_b32 a9, %[hi]\n v_accvgpr_write_b32 a10, 0\n v_accvgpr_write_b32 a11, %[hi]\n"
       "v_accvgpr_write_b32 a12, 0\n v_accvgpr_write_b32 a13, %[hi]\n v_accvgpr_write_b32 a14, 0\n v_accvgpr_write_b32 a15, %[hi]\n"
       "s_nop 7\n s_nop 7\n s_nop 7\n"
+      ".rept %[pre]\n v_mfma_f64_16x16x4_f64 a[16:23], %[a], %[b], a[24:31]\n .endr\n"   // independent MFMAs already in the pipe
       "v_mfma_f64_16x16x4_f64 a[0:7], %[a], %[b], a[8:15]\n"
       ".rept %[n]\n"
       ".if %[f] == 0\n s_nop 0\n .endif\n"
@@ -191,16 +192,17 @@ __global__ void k_fill(const double* __restrict__ in, double* __restrict__ out) 
       "v_accvgpr_read_b32 %[d4], a4\n v_accvgpr_read_b32 %[d5], a5\n v_accvgpr_read_b32 %[d6], a6\n v_accvgpr_read_b32 %[d7], a7\n"
       : [d0] "=&v"(((int*)d)[0]), [d1] "=&v"(((int*)d)[1]), [d2] "=&v"(((int*)d)[2]), [d3] "=&v"(((int*)d)[3]),
         [d4] "=&v"(((int*)d)[4]), [d5] "=&v"(((int*)d)[5]), [d6] "=&v"(((int*)d)[6]), [d7] "=&v"(((int*)d)[7]), [t] "=&v"(scratch_v)
-      : [a] "v"(a), [b] "v"(b), [la] "v"(lds_addr), [n] "n"(COUNT), [f] "n"(FILL), [hi] "v"(0x3ff00000)
-      : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "s20", "memory");
+      : [a] "v"(a), [b] "v"(b), [la] "v"(lds_addr), [n] "n"(COUNT), [f] "n"(FILL), [hi] "v"(0x3ff00000), [pre] "n"(PRE)
+      : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18",
+        "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "s20", "memory");
   for (int r = 0; r < 4; ++r) out[r * 64 + lane] = d[r];
   if (scratch_v == 0x7fffffff) out[1024] = 1.0;
 }
-template <int FILL, int COUNT>
+template <int FILL, int COUNT, int PRE = 0>
 static bool run_fill(const double* din, double* dout) {
   bool bad = false;
   for (int rep = 0; rep < 20 && !bad; ++rep) {
-    k_fill<FILL, COUNT><<<1, 64>>>(din, dout);
+    k_fill<FILL, COUNT, PRE><<<1, 64>>>(din, dout);
     std::vector<double> h(256);
     (void)hipMemcpy(h.data(), dout, 256 * 8, hipMemcpyDeviceToHost);
     for (int i = 0; i < 256; ++i)
@@ -216,6 +218,17 @@ static void sweep_fill(const char* what, const double* din, double* dout) {
                run_fill<FILL, 8>(din, dout), run_fill<FILL, 12>(din, dout), run_fill<FILL, 16>(din, dout)};
   const int ns[9] = {0, 1, 2, 3, 4, 6, 8, 12, 16};
   for (int k = 0; k < 9; ++k) printf("%d:%s ", ns[k], r[k] ? "WRONG" : "ok");
+  printf("\n");
+}
+template <int PRE>
+static void sweep_pre(const double* din, double* dout) {
+  printf("%d independent v_mfma_f64_16x16x4 in the pipe, then the MFMA, n x s_nop 0, the LDS load into its SrcC: ", PRE);
+  bool r[12] = {run_fill<0, 0, PRE>(din, dout), run_fill<0, 1, PRE>(din, dout), run_fill<0, 2, PRE>(din, dout),
+                run_fill<0, 4, PRE>(din, dout), run_fill<0, 8, PRE>(din, dout), run_fill<0, 12, PRE>(din, dout),
+                run_fill<0, 16, PRE>(din, dout), run_fill<0, 20, PRE>(din, dout), run_fill<0, 24, PRE>(din, dout),
+                run_fill<0, 32, PRE>(din, dout), run_fill<0, 40, PRE>(din, dout), run_fill<0, 48, PRE>(din, dout)};
+  const int ns[12] = {0, 1, 2, 4, 8, 12, 16, 20, 24, 32, 40, 48};
+  for (int k = 0; k < 12; ++k) printf("%d:%s ", ns[k], r[k] ? "WRONG" : "ok");
   printf("\n");
 }
 
@@ -240,5 +253,8 @@ int main() {
   sweep_fill<1>("ds_read_b32 (other register)", din, dout);
   sweep_fill<2>("v_mov_b32", din, dout);
   sweep_fill<3>("s_mov_b32", din, dout);
+  sweep_pre<1>(din, dout);
+  sweep_pre<2>(din, dout);
+  sweep_pre<4>(din, dout);
   return 0;
 }
