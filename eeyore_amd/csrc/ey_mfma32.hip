@@ -1060,19 +1060,25 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     wave_lds_fence();  // the staged normals have been read; the evaluations reuse that LDS
     kin = wsum(kin);
     t_cur = A.target[chain];
-    if (!A.recompute) for_each(g, c, h, lane, [&](float& v, int idx, bool) { v = grg[idx]; });
   } else {
     const float* pin = A.pio + chain * NPAR;
     for_each(p, c, h, lane, [&](float& v, int idx, bool) { v = pin[idx]; });
   }
   const float h_cur = -t_cur + 0.5f * kin;  // hmc.py:91-98,137
   float t = t_cur;
+  // leapfrog, hmc.py:100-124 (grad_potential = -grad): the first half step of the momentum
   if (MODE == MODE_LEAPFROG || A.recompute) {  // hmc.py:104
     write_images<BF3, SH>(lw, th, c, h, lane, wl);
     t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc, wl);
+    for_each2(p, g, [&](float& pv, float& gv) { pv = __builtin_fmaf(0.5f * eps, gv, pv); });
+  } else {
+    // the cached gradient goes from memory straight into the momentum: loaded into a register vector of its own before
+    // the momentum existed it was spilled pair by pair, every pair behind its own s_waitcnt vmcnt(0) (15 serial round
+    // trips per draw)
+    // (one fused multiply-add per element, written out: left to the compiler the two forms of this update were contracted
+    // differently -- v_fmac_f32 there, v_pk_mul_f32 + v_pk_add_f32 here -- and a chain's bits depended on the flag)
+    for_each(p, c, h, lane, [&](float& pv, int idx, bool) { pv = __builtin_fmaf(0.5f * eps, grg[idx], pv); });
   }
-  // leapfrog, hmc.py:100-124 (grad_potential = -grad)
-  for_each2(p, g, [&](float& pv, float& gv) { pv = pv + 0.5f * eps * gv; });
 #pragma unroll 1
   KO(0);
   for (int k = 1; k <= A.L; ++k) {
@@ -1099,8 +1105,14 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   // the pointers the write-back uses are made opaque here: otherwise the per-lane addresses theta + idx, grad + idx are
   // computed before the trajectory, live across it and spilled (14 dwords per lane stored and reloaded per draw)
   asm volatile("" : "+s"(thg), "+s"(grg));
+  // ... and so are the lane coordinates everything below indexes with: the element offsets of the write-back, the moments and
+  // the record were otherwise computed at kernel entry (they depend on the lane alone), kept for the whole launch and spilled
+  // (22 dwords per lane written at entry and read back in every draw)
+  int le = lane;
+  asm volatile("" : "+v"(le));
+  const int ce = le & 31, he = le >> 5;
   kin = 0.0f;
-  for_each(p, c, h, lane, [&](float& v, int, bool counts) { if (counts) kin += v * v; });
+  for_each(p, ce, he, le, [&](float& v, int, bool counts) { if (counts) kin += v * v; });
   kin = wsum(kin);
   const float h_prop = -t + 0.5f * kin;
   float rate = __expf(h_cur - h_prop);  // hmc.py:143-146
@@ -1109,10 +1121,10 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   const float u = A.u ? A.u[chain] : ey_rng_uniform<float>(ru);
   const bool acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
   if (acc) {
-    for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) thg[idx] = v; });
-    for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
+    for_each(th, ce, he, le, [&](float& v, int idx, bool counts) { if (counts) thg[idx] = v; });
+    for_each(g, ce, he, le, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
   }
-  if (lane == 0) {
+  if (le == 0) {
     if (acc) A.target[chain] = t;
     A.accepted[chain] = acc ? 1 : 0;
     if (A.rate) A.rate[chain] = rate;
@@ -1128,14 +1140,14 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
                                                A.da_has_eub != 0, A.da_logeub, it == A.da_final_it);
     }
   }
-  if (A.mom_s1) add_moments(A, chain, th, thg, !acc, acc, c, h, lane);
+  if (A.mom_s1) add_moments(A, chain, th, thg, !acc, acc, ce, he, le);
   if (A.rec_samples) {  // the state this chain is left in (what ChainList.update stores, chain_list.py:64-67)
     float* so = A.rec_samples + ((int64_t)it * A.C + chain) * NPAR;
     const float* old = thg;
     asm volatile("" : "+s"(old));  // see add_moments
-    for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) so[idx] = acc ? v : old[idx]; });
+    for_each(th, ce, he, le, [&](float& v, int idx, bool counts) { if (counts) so[idx] = acc ? v : old[idx]; });
   }
-  if (lane == 0) {
+  if (le == 0) {
     if (A.rec_targets) A.rec_targets[(int64_t)it * A.C + chain] = acc ? t : t_cur;
     if (A.rec_accepted) A.rec_accepted[(int64_t)it * A.C + chain] = acc ? 1 : 0;
     if (A.accept_count && acc) A.accept_count[chain] += 1;

@@ -242,6 +242,13 @@ class TemperingExchange:
         ``self.labels`` is updated in place.  All pairs of the sweep go through ONE swap-decision call."""
         ell = self._gather(ell_local.detach().to(torch.float64))          # [world, R] by rank
         lab = self._gather(self.labels)                                   # [world, R]
+        new_lab, accepted = self._sweep(ell, lab)
+        self.labels = new_lab[self.rank].clone()
+        return accepted
+
+    def _sweep(self, ell, lab):
+        """The sweep on the gathered arrays: ``ell`` [world, R] log-targets and ``lab`` [world, R] ladder positions by
+        holder -> (new positions [world, R], accepted exchanges).  The same on every rank."""
         dev = ell.device
         # rank_of[k, r]: which rank holds ladder position k of replica r; ell_at[k, r] its log-target
         rank_of = torch.empty_like(lab)
@@ -267,7 +274,27 @@ class TemperingExchange:
         new_lab = lab.clone()
         new_lab[lo_rank[m], cols[m]] = (ks[:, None] + 1).expand(n, self.R)[m]
         new_lab[hi_rank[m], cols[m]] = ks[:, None].expand(n, self.R)[m]
-        self.labels = new_lab[self.rank].clone()
         accepted = m.sum()
         self._swaps = self._swaps + accepted.to(self._swaps.device)
+        return new_lab, accepted
+
+
+class LocalTemperingLadder(TemperingExchange):
+    """The same ladder held by ONE process: K positions x R replicas as one chain batch of K R chains on one GPU (row
+    k R + r starts at position k of replica r), exchanged by the same sweep -- same pair ids, same Philox accept variates,
+    same decisions as K ranks would take (tests/test_tempering_gpu.py holds the two against each other).  BASELINE config
+    5's algorithm on a single device: ``labels`` is [K, R], ``temperature_vector`` and ``exchange`` take / give [K R]."""
+
+    def __init__(self, temperatures, num_replicas, device, seed=0, decide=None):
+        K = len(temperatures)
+        super().__init__(temperatures, num_replicas, 0, K, device, seed=seed, decide=decide)
+        self.labels = torch.arange(K, dtype=torch.int64, device=device)[:, None].expand(K, num_replicas).contiguous()
+
+    def temperature_vector(self, dtype):
+        return self.temps.to(self.labels.device)[self.labels].to(dtype).reshape(-1)
+
+    def exchange(self, ell_all):
+        """``ell_all`` [K R] (or [K, R]): untempered log-targets of every chain, by holder."""
+        ell = ell_all.detach().to(torch.float64).reshape(self.world, self.R)
+        self.labels, accepted = self._sweep(ell, self.labels)
         return accepted

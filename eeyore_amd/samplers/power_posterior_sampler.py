@@ -9,7 +9,7 @@ from .hmc import HMC
 from .mala import MALA
 from .metropolis_hastings import MetropolisHastings
 from .base import SerialSampler
-from eeyore_amd.chains import ChainBuffer
+from eeyore_amd.chains import ChainBuffer, ChainFile
 from eeyore_amd.datasets import DataCounter
 
 
@@ -42,9 +42,9 @@ class PowerPosteriorSampler(SerialSampler):
         self.sampler_names = [samplers[i][0] for i in range(self.num_chains)]
         if len(set(self.sampler_names)) != 1:
             raise ValueError("all temperatures must use the same within-chain sampler to be advanced by one fused step")
-        if storage != 'list':
-            raise ValueError("only in-memory storage is built (ChainBuffer per temperature); use chain.get_chain(r)."
-                             "to_chainfile(...) to write a chain to disk")
+        if storage not in ('list', 'file'):
+            raise ValueError("storage must be 'list' or 'file'")
+        self.storage = storage
         self.keys = list(keys)
         self.dtype, self.device = model.dtype, model.device
         K = self.num_chains
@@ -78,10 +78,23 @@ class PowerPosteriorSampler(SerialSampler):
                 self.sampler.kernel = kw[0]['kernel']
         else:
             raise ValueError(f"unknown within-chain sampler {name!r}")
-        self.chains = [ChainBuffer(keys=self.keys) for _ in range(K)]
+        self.chains = [self.init_chain(i, storage, self.keys, Path(path), mode) for i in range(K)]
         self._tvec = tvec
         self._log_q = torch.tensor(np.log(self._partner_matrix()), dtype=self.dtype, device=self.device)
         self._probs = [torch.tensor(self.eval_categorical_probs(i), dtype=torch.float64) for i in range(K)]
+
+    def init_chain(self, i, storage, keys, path, mode):
+        """The chain of temperature i (power_posterior_sampler.py:57-66): in memory, or appended to
+        ``<path>/chain<i+1>/<key>.csv`` iteration by iteration.  In memory it is a device buffer [iters, R, ...] for the R
+        replicas of the ladder; on file a single ladder (R = 1) writes the reference's files, R > 1 one directory per
+        replica, ``chain<i+1>/replica<r+1>``."""
+        if storage == 'list':
+            return ChainBuffer(keys=keys)
+        folder = path / f"chain{i + 1:0{len(str(self.num_chains))}}"
+        if self.num_replicas == 1:
+            return ChainFile(keys=keys, path=folder, mode=mode)
+        width = len(str(self.num_replicas))
+        return [ChainFile(keys=keys, path=folder / f"replica{r + 1:0{width}}", mode=mode) for r in range(self.num_replicas)]
 
     # ---- ladder and partner distribution (power_posterior_sampler.py:84-125)
     def default_indicator(self):
@@ -164,12 +177,13 @@ class PowerPosteriorSampler(SerialSampler):
         plan = self.model._plan(x, y)
         ar = torch.arange(R, device=self.device)
         has_grad = hasattr(s, '_grad')
-        self.last_swaps = []
+        self.last_swaps, self.last_swap_inputs = [], []
         for i in range(K):
             j = self._sample_partners(i)
             ell_i, ell_j, t_i, t_j, dlogq = self.between_chain_move_log_rate(i, j)
             swap, log_rate = plan.pt_swap_decide(ell_i, ell_j, t_i, t_j, self._rand(R), dlogq=dlogq)
             self.last_swaps.append((j, swap, log_rate))
+            self.last_swap_inputs.append((ell_i, ell_j, t_i, t_j, dlogq))
             m = swap.bool()
             if not bool(m.any()):
                 continue
@@ -192,7 +206,13 @@ class PowerPosteriorSampler(SerialSampler):
             state['grad_val'] = s._grad[sl]
         if 'accepted' in self.keys:
             state['accepted'] = s.current['accepted'][sl]
-        self.chains[i].update(state)
+        chain = self.chains[i]
+        if self.storage == 'list':
+            chain.update(state)
+            return
+        # on file: one row per saved iteration and replica, as ChainFile.update writes a single chain's state
+        for r, handle in enumerate([chain] if R == 1 else chain):
+            handle.update({k: (int(v[r]) if k == 'accepted' else v[r]) for k, v in state.items()})
 
     def draw(self, x, y, savestate=False):
         """power_posterior_sampler.py:174-182."""
@@ -205,12 +225,66 @@ class PowerPosteriorSampler(SerialSampler):
             for i in range(self.num_chains):
                 self.save_state(i)
 
+    # ---- the multi-chain surface of the reference (eeyore/samplers/multi_chain_serial_sampler.py:10-46); `chain_idx` is
+    #      a temperature (default: the last one, the target itself, power_posterior_sampler.py:84-85)
+    def _memory_chain(self, idx):
+        chain = self.get_chain(idx)
+        if not isinstance(chain, ChainBuffer):
+            raise RuntimeError("this sampler stores its chains on file (storage='file'): read them back with "
+                               "ChainFile.to_chainlist()")
+        return chain
+
+    def get_param(self, param_idx, chain_idx=None):
+        """The history of one parameter at one temperature: [iters] for a single ladder, [iters, R] for R replicas."""
+        samples = self._memory_chain(chain_idx).get_samples()[:, :, param_idx]
+        return samples[:, 0] if self.num_replicas == 1 else samples
+
+    def get_sample(self, sample_idx, chain_idx=None):
+        """The state saved at one iteration at one temperature: [P] for a single ladder, [R, P] for R replicas."""
+        sample = self._memory_chain(chain_idx).get_samples()[sample_idx]
+        return sample[0] if self.num_replicas == 1 else sample
+
+    def set_current(self, theta, data=None):
+        """Put every temperature of every replica at ``theta`` ([P] or [R, P]) and evaluate it there
+        (multi_chain_serial_sampler.py:28-31)."""
+        th = theta.detach().to(device=self.device, dtype=self.dtype)
+        th = th[None] if th.dim() == 1 else th
+        if th.shape[0] != self.num_replicas:
+            th = th.expand(self.num_replicas, -1)
+        self.sampler.set_current(th.repeat(self.num_chains, 1).contiguous(), data=data)
+
+    def set_all(self, theta, data=None):
+        # (the reference's own method calls itself, multi_chain_serial_sampler.py:33-36; what it means is this)
+        self.set_current(theta, data=data)
+
+    def reset_chains(self):
+        for i, chain in enumerate(self.chains):
+            if self.storage == 'list':
+                chain.reset()
+            else:
+                for handle in ([chain] if self.num_replicas == 1 else chain):
+                    handle.reset(keys=self.keys)
+
+    def to_chainfile(self, path=Path.cwd(), mode='a'):
+        """One directory per temperature, ``sampler<i>`` zero-filled as the reference does (to the width of the number of
+        temperatures, multi_chain_serial_sampler.py:44-46), with ``<key>.csv`` inside; R replicas get ``replica<r>``
+        directories below it."""
+        path = Path(path)
+        for i in range(self.num_chains):
+            folder = path / ('sampler' + str(i).zfill(self.num_chains))
+            buf = self._memory_chain(i)
+            if self.num_replicas == 1:
+                buf.get_chain(0).to_chainfile(keys=self.keys, path=folder, mode=mode)
+            else:
+                width = len(str(self.num_replicas))
+                for r in range(self.num_replicas):
+                    buf.get_chain(r).to_chainfile(keys=self.keys, path=folder / f"replica{r + 1:0{width}}", mode=mode)
+
     def reset(self, theta, data=None, reset_counter=True, reset_chain=True):
         if reset_counter:
             self.counter.reset()
         if reset_chain:
-            for ch in self.chains:
-                ch.reset()
+            self.reset_chains()
         th = theta.detach().to(device=self.device, dtype=self.dtype)
         th = th[None] if th.dim() == 1 else th
         self.sampler.set_current(th.repeat(self.num_chains, 1).contiguous(), data=data)

@@ -5,7 +5,9 @@ P = 101 770 parameters per chain do not fit a CU's LDS: ``plan.kernel`` is ``bge
 tile job of a chain-batched GEMM, the leapfrog update rides in the epilogues of the gradient kernels.  One temperature per
 GPU (``torchrun --nproc-per-node K examples/mnist_shaped_tempering.py``; one process = one temperature = plain HMC),
 replicas exchange temperature LABELS between neighbouring ranks every few iterations (``distributed.TemperingExchange``),
-never their 100 k-float states.  EEYORE_EXAMPLE_CHAINS / EEYORE_EXAMPLE_EPOCHS / EEYORE_EXAMPLE_ROWS size the run.
+never their 100 k-float states.  On ONE GPU, EEYORE_EXAMPLE_LADDER=K runs the same algorithm with all K temperatures in this
+process (``distributed.LocalTemperingLadder``: K x chains as one chain batch with a per-chain temperature vector).
+EEYORE_EXAMPLE_CHAINS / EEYORE_EXAMPLE_EPOCHS / EEYORE_EXAMPLE_ROWS size the run.
 """
 import os
 import sys
@@ -19,7 +21,7 @@ from torch.utils.data import DataLoader
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
 from eeyore_amd.constants import loss_functions
 from eeyore_amd.datasets import XYDataset
-from eeyore_amd.distributed import TemperingExchange, init_from_env
+from eeyore_amd.distributed import LocalTemperingLadder, TemperingExchange, init_from_env
 from eeyore_amd.models import mlp
 from eeyore_amd.samplers import HMC
 
@@ -46,13 +48,19 @@ def main():
     P = model.num_params()
     model.prior = Normal(torch.zeros(P, device=device), torch.ones(P, device=device))
 
-    ladder = [(i / world) ** 4 for i in range(1, world + 1)]   # the reference's default power-posterior ladder
-    exchange = TemperingExchange(ladder, num_chains, rank, world, device, seed=11)
+    local_ladder = int(os.environ.get('EEYORE_EXAMPLE_LADDER', 1)) if world == 1 else 1
+    temps = max(world, local_ladder)
+    ladder = [(i / temps) ** 4 for i in range(1, temps + 1)]   # the reference's default power-posterior ladder
+    if local_ladder > 1:   # every temperature in this process: local_ladder x num_chains chains in one batch
+        exchange = LocalTemperingLadder(ladder, num_chains, device, seed=11)
+        num_chains *= local_ladder
+    else:
+        exchange = TemperingExchange(ladder, num_chains, rank, world, device, seed=11)
     sampler = HMC(model, theta0=0.05 * torch.randn(num_chains, P, device=device), dataloader=loader, step=STEP,
                   num_steps=NUM_STEPS, seed=1 + rank, temperature=exchange.temperature_vector(torch.float32))
     if rank == 0:
-        print(f"kernel family: {model._plan(*next(iter(loader))).kernel}; {world} temperature(s) x {num_chains} chains, "
-              f"P = {P}")
+        print(f"kernel family: {model._plan(*next(iter(loader))).kernel}; {temps} temperature(s) x "
+              f"{num_chains // local_ladder} chains, P = {P}")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     swaps, accepted, stored = 0, 0.0, 0
@@ -60,7 +68,7 @@ def main():
         sampler.run(num_epochs=min(EXCHANGE_EVERY, epochs - start), num_burnin_epochs=0)
         accepted += sampler.get_chain().get_accepted().float().mean(1).sum().item()
         stored += len(sampler.get_chain())
-        if world > 1:
+        if temps > 1:
             swaps += int(exchange.exchange(sampler.current['target_val'] / sampler.temperature))  # untempered log-target
             sampler.set_temperature(exchange.temperature_vector(torch.float32))   # a relabelled replica keeps its state
     torch.cuda.synchronize()

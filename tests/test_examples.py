@@ -19,6 +19,25 @@ def test_example_runs(script):
     assert "cceptance rate" in out.stdout
 
 
+@pytest.mark.parametrize("ladder", [1, 8])
+def test_config5_example_runs_on_one_gpu(ladder):
+    """examples/mnist_shaped_tempering.py (BASELINE config 5 through the sampler surface) as one process: plain HMC on the
+    layerwise path (world = 1), and with EEYORE_EXAMPLE_LADDER=8 the whole 8-temperature ladder in this process with
+    label exchanges every five iterations."""
+    env = dict(os.environ, EEYORE_EXAMPLE_EPOCHS="10", EEYORE_EXAMPLE_CHAINS="12", EEYORE_EXAMPLE_ROWS="128",
+               EEYORE_EXAMPLE_LADDER=str(ladder), PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "mnist_shaped_tempering.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "kernel family: bgemm" in out.stdout and f"{ladder} temperature(s) x 12 chains" in out.stdout
+    assert "Iterations per chain: 10" in out.stdout and "cceptance rate" in out.stdout
+    if ladder > 1:
+        swaps = int(out.stdout.rsplit("label exchanges accepted:", 1)[1].split()[0])
+        assert swaps > 0
+
+
 def test_bench_contract_small_run():
     """bench.py prints ONE JSON line with the driver's fields, roofline and cpu_baseline objects."""
     import json
@@ -32,7 +51,14 @@ def test_bench_contract_small_run():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["vs_baseline"] is None
+    # --steps is rounded up to whole launches of 25 iterations (what HMC.run issues); the line says what was asked for
+    assert d["n_gpus"] == 1 and d["steps"] == 25 and d["config"]["steps_requested"] == 3 and d["vs_baseline"] is None
+    assert d["config"]["iterations_per_launch"] == 25 and "rounded up" in d["config"]["steps_note"]
+    # the timed region records the chains as HMC.run does, and the same workload through the sampler surface is beside it
+    assert d["config"]["recorded_in_timed_region"].startswith("samples [steps, C, P]")
+    via = d["config"]["through_sampler_run"]
+    assert via["iterations"] == 25 and 0.5 < via["ratio_to_headline"] < 1.5 and 0 < via["acceptance"] <= 1
+    assert 0 < d["roofline"]["frac_exact_f32_products"] < d["roofline"]["frac"] and 0 < d["roofline"]["bf16_pipe_flops_frac"] < 1
     # the arithmetic type is f32; the default form of the kernel's products is named beside it, both forms' rates recorded
     assert d["dtype"] == "f32 (bf16x3 products, f32 accumulate)" and d["config"]["f32_products"] == "bf16x3"
     assert set(d["config"]["kernels"]) == {"bf16x3", "exact"} and d["roofline"]["f32_equivalent"] is True

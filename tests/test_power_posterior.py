@@ -104,3 +104,64 @@ def test_power_posterior_on_gpu_with_hip_decide_kernel():
     hot = s.get_chain(0).get_target_vals().mean().item()
     assert np.isfinite(cold) and np.isfinite(hot)
     assert s.get_chain().get_samples().shape == (30, R, 20)
+
+
+def test_multi_chain_surface_and_file_storage(tmp_path):
+    """The reference's multi-chain surface (multi_chain_serial_sampler.py:10-46) and storage='file'
+    (power_posterior_sampler.py:57-66): get_param / get_sample / reset_chains / to_chainfile / set_current / set_all, the
+    chain<i> directories a file-backed sampler appends to, and what they hold against the in-memory run of the same seed."""
+    from eeyore_amd.chains import ChainFile
+    z, m, ds, s = _setup(R=1, between_step=2)
+    torch.manual_seed(11)
+    s.run(num_epochs=9, num_burnin_epochs=3)
+    K, P = s.num_chains, 20
+    assert s.get_param(4).shape == (6,) and s.get_param(4, chain_idx=0).shape == (6,)
+    assert torch.equal(s.get_param(4), s.get_chain().get_samples()[:, 0, 4])
+    assert s.get_sample(2).shape == (P,) and torch.equal(s.get_sample(2, chain_idx=1), s.get_chain(1).get_samples()[2, 0])
+    s.to_chainfile(path=tmp_path / "dump", mode='w')
+    for i in range(K):   # the reference's folder names: 'sampler' + str(i).zfill(num_chains)
+        back = ChainFile(keys=['sample', 'target_val'], path=tmp_path / "dump" / ('sampler' + str(i).zfill(K)), mode='a')
+        cl = back.to_chainlist()
+        np.testing.assert_array_equal(torch.stack(cl.vals['sample']).numpy(), s.get_chain(i).get_samples()[:, 0].numpy())
+        np.testing.assert_array_equal(torch.stack(cl.vals['target_val']).numpy(), s.get_chain(i).get_target_vals()[:, 0].numpy())
+    mem = [s.get_chain(i).get_samples()[:, 0].clone() for i in range(K)]
+    s.reset_chains()
+    assert all(len(s.get_chain(i)) == 0 for i in range(K))
+    # set_current / set_all: every temperature at the given state, evaluated there
+    th = torch.linspace(-0.3, 0.3, P, dtype=torch.float64)
+    for setter in (s.set_current, s.set_all):
+        setter(th)
+        assert torch.equal(s.sampler._theta, th.expand(K, P))
+        plan = m._plan(ds.x, ds.y)
+        t, _ = plan.log_target_grad(s.sampler._theta.clone(), temp=s._tvec)
+        np.testing.assert_allclose(s.sampler._target.numpy(), t.numpy(), rtol=1e-12)
+    # the same run, stored on file: chain<i+1>/<key>.csv, appended iteration by iteration
+    z2, m2, ds2, f = _setup(R=1, between_step=2)
+    f2 = PowerPosteriorSampler(m2, f.dataloader, [['MALA', {'step': 0.1}] for _ in range(K)], theta0=f.sampler._theta[0].clone(),
+                               between_step=2, b=0.5, rng='torch', storage='file', path=tmp_path / "run", mode='a')
+    torch.manual_seed(11)
+    f2.run(num_epochs=9, num_burnin_epochs=3)
+    for i in range(K):
+        folder = tmp_path / "run" / f"chain{i + 1}"
+        assert sorted(p.name for p in folder.iterdir()) == ['sample.csv', 'target_val.csv']
+        got = ChainFile(keys=['sample', 'target_val'], path=folder, mode='a').to_chainlist()
+        np.testing.assert_array_equal(torch.stack(got.vals['sample']).numpy(), mem[i].numpy())   # '%.18e' round-trips f64
+    with pytest.raises(RuntimeError, match="on file"):
+        f2.get_param(0)
+    with pytest.raises(ValueError):
+        PowerPosteriorSampler(m2, f.dataloader, [['MALA', {'step': 0.1}]] * K, theta0=th, storage='tape')
+
+
+def test_file_storage_with_several_replicas(tmp_path):
+    z, m, ds, s0 = _setup(R=3)
+    K = s0.num_chains
+    s = PowerPosteriorSampler(m, s0.dataloader, [['MALA', {'step': 0.1}] for _ in range(K)], theta0=s0.sampler._theta[:3].clone(),
+                              between_step=1, b=0.5, rng='torch', storage='file', keys=['sample', 'target_val', 'accepted'],
+                              path=tmp_path, mode='a')   # ('w' would truncate at every update, as the reference's ChainFile does)
+    s.run(num_epochs=5, num_burnin_epochs=1)
+    from eeyore_amd.chains import ChainFile
+    for i in (0, K - 1):
+        for r in range(3):
+            folder = tmp_path / f"chain{i + 1}" / f"replica{r + 1}"
+            cl = ChainFile(keys=['sample', 'target_val', 'accepted'], path=folder, mode='a').to_chainlist()
+            assert len(cl.vals['sample']) == 4 and cl.vals['sample'][0].shape == (20,) and set(cl.vals['accepted']) <= {0, 1}
