@@ -656,9 +656,19 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_dma(BG g) {
 // Staging is through registers, either operand in either direction (AK / BK_: k contiguous, else rows contiguous): a
 // thread takes one (row, 8 consecutive k) task per operand and chunk -- two 16-byte loads when k is contiguous, eight
 // dword loads (lanes <-> consecutive rows) when the rows are -- and writes its three 16-byte granules into the image
-// [piece][row][2 granules], granule position g ^ ((row >> 3) & 1): lane (c, h) of an MFMA reads granule h of its row with
+// [piece][row][2 granules], granule position g ^ BF3_SWZ(row): lane (c, h) of an MFMA reads granule h of its row with
 // one conflict-free ds_read_b128 per piece.  Two LDS stages of 24 KB, one barrier per chunk.
 #define BK3 16
+// granule position of a row in the staging image: position = granule ^ BF3_SWZ(row), BF3_SWZ = parity of the row's bits 2
+// and 3.  Measured (tools/lds_b128_probe.hip, profiles/r04_lds_b128_probe.txt): a ds_write_b128 whose lanes take consecutive
+// rows (32 bytes apart: the row-contiguous staging) is conflict-free when rows 4 apart alternate the position (bit 2), a
+// ds_read_b128 of the fragment pattern when rows 8 apart do (bit 3), and the parity of both serves both: round 3's bit 3 alone
+// left the row-contiguous stores at 16.0 cycles instead of 13.6 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.33 on config 5's
+// weight-gradient product, now 0.000; profiles/r04_cfg5_swizzle.txt).
+#ifndef EY_BF3_SWZ_MASK
+#define EY_BF3_SWZ_MASK 0x0C
+#endif
+#define BF3_SWZ(row) (__builtin_popcount((row) & EY_BF3_SWZ_MASK) & 1)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -766,16 +776,17 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
   // take consecutive rows
   const int ar = AK ? (tid >> 1) : (tid & 127), ag = AK ? (tid & 1) : (tid >> 7);
   const int br = BK_ ? (tid >> 1) : (tid & 127), bg = BK_ ? (tid & 1) : (tid >> 7);
-  const int a_slot = ar * 2 + (ag ^ ((ar >> 3) & 1)), b_slot = br * 2 + (bg ^ ((br >> 3) & 1));
+  const int a_slot = ar * 2 + (ag ^ BF3_SWZ(ar)), b_slot = br * 2 + (bg ^ BF3_SWZ(br));
   // fragment slots of this lane: rows wm * 64 + 32 i + c (A) and wn * 64 + 32 j + c (B); 32 rows further = 64 slots
   const int ra = wm * 64 + c, rb = wn * 64 + c;
-  const int fa = ra * 2 + (h ^ ((ra >> 3) & 1)), fb = rb * 2 + (h ^ ((rb >> 3) & 1));
+  const int fa[2] = {ra * 2 + (h ^ BF3_SWZ(ra)), (ra + 32) * 2 + (h ^ BF3_SWZ(ra + 32))};
+  const int fb[2] = {rb * 2 + (h ^ BF3_SWZ(rb)), (rb + 32) * 2 + (h ^ BF3_SWZ(rb + 32))};
   const float* arow = A + (long)min(m0 + ar, g.M - 1) * g.sAm;
   const float* brow = B + (long)min(n0 + br, g.N - 1) * g.sBn;
   float va[8], vb[8];
   // the pre-split operand: thread (row tid >> 1, granule tid & 1), consecutive threads consecutive 16-byte units
   const int pr = tid >> 1, pg = tid & 1;
-  const int p_slot = pr * 2 + (pg ^ ((pr >> 3) & 1));
+  const int p_slot = pr * 2 + (pg ^ BF3_SWZ(pr));
   const long pre_chunk = (long)g.pre_rows * 2;  // 16-byte units per (k-chunk, piece)
   const u32x4_t* pre = !PRE ? nullptr : reinterpret_cast<const u32x4_t*>(g.pre) + (long)min(m0 + pr, g.M - 1) * 2 + pg;
   u32x4_t vp[3];
@@ -813,8 +824,8 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        pa[i][p] = As[cur][p * 256 + fa + 64 * i];
-        pb[i][p] = Bs[cur][p * 256 + fb + 64 * i];
+        pa[i][p] = As[cur][p * 256 + fa[i]];
+        pb[i][p] = Bs[cur][p * 256 + fb[i]];
       }
     // (hi, lo), (lo, hi), (mid, mid), (hi, mid), (mid, hi), (hi, hi): smallest terms first
     constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};

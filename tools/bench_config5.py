@@ -29,7 +29,10 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 if os.environ.get("EY_NO_DMA"):  # A/B: the register-staged GEMM instead of the LDS-DMA one
     from eeyore_amd import _lib as L
     L.lib().ey_debug_set_variant(32)
-N, L, eps, between = 1024, 20, 0.001, 10
+N, L, between = 1024, 20, 10
+# the step: EY_CFG5_STEP (default: the step tools/step_sweep_cfg5.py found for 0.6-0.9 acceptance after burn-in)
+eps = float(os.environ.get("EY_CFG5_STEP", "0.004"))
+burnin = int(os.environ.get("EY_CFG5_BURNIN", "0"))   # untimed iterations before the clock (acceptance is reported over the timed ones)
 DT = torch.float64 if os.environ.get("EY_F64") else torch.float32   # EY_F64=1: the f64 layerwise path (parity dtype)
 PEAK, PEAK_NAME = (78.6e12, "f64") if DT == torch.float64 else (157.3e12, "f32")
 
@@ -46,6 +49,8 @@ th = 0.05 * pl.philox_normal(C, seed=0, it=0)  # every rank starts its replicas 
 temps = pt.temperature_vector(DT)
 t, g = pl.log_target_grad(th, temp=temps)
 out = pl.hmc_step(th, t, g, eps, L, temp=temps, seed=1 + rank, it=1)
+for b_ in range(burnin):
+    out = pl.hmc_step(th, t, g, eps, L, temp=temps, seed=1 + rank, it=1000000 + b_)
 torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
@@ -70,7 +75,8 @@ if rank == 0:
     tot = C * world
     print(f"kernel {pl.kernel}: {world} temperature(s) x {C} chains, {dt * 1e3:.1f} ms per HMC iteration (L={L}) -> "
           f"{tot * L / dt:.3e} leapfrog-steps/s x chains, {f_step * C * L / dt / 1e12:.1f} TFLOP/s per GPU "
-          f"({100 * f_step * C * L / dt / PEAK:.1f}% of {PEAK_NAME} MFMA peak), acceptance {np.mean(accs):.2f}, "
+          f"({100 * f_step * C * L / dt / PEAK:.1f}% of {PEAK_NAME} MFMA peak), step {eps}, acceptance {np.mean(accs):.2f} "
+          f"(after {burnin} burn-in iterations), "
           f"label exchanges accepted {swaps}")
 if world > 1:
     dist.destroy_process_group()
