@@ -259,7 +259,7 @@ class TemperingExchange:
         self.attempts += 1
         ks = torch.arange(attempt % 2, self.world - 1, 2, device=dev)   # the lower positions of this sweep's pairs
         if ks.numel() == 0:
-            return torch.zeros((), dtype=torch.int64, device=dev)
+            return lab, torch.zeros((), dtype=torch.int64, device=dev)
         u = self._uniform(self.R * self.world, dev, attempt).view(self.world, self.R)
         temps = self.temps.to(dev)
         n = ks.numel()
