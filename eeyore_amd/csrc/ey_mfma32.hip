@@ -441,6 +441,7 @@ struct Pace {
   int left;
   int bias;     // added to what this wave publishes and compares: the wave then runs `bias` tiles ahead of its partner
   bool on;
+  bool hi;      // EY_PHASE_PRIO: this wave is the one behind (the low bit of its priority levels)
 };
 __device__ __forceinline__ int pace_post(Pace& pc, int lane) {
   if (!pc.on) return 0;
@@ -448,12 +449,52 @@ __device__ __forceinline__ int pace_post(Pace& pc, int lane) {
   if (lane == 0) __hip_atomic_store(&pc.prog[pc.wave], pc.left + pc.bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return __hip_atomic_load(&pc.prog[pc.partner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void pace_apply(const Pace& pc, int theirs_v) {
+// EY_PHASE_PRIO (diagnostic builds, default off): priority by phase, see chain_enter below
+#ifndef EY_PHASE_PRIO
+#define EY_PHASE_PRIO 0
+#endif
+__device__ __forceinline__ void pace_apply(Pace& pc, int theirs_v) {
   if (!pc.on) return;
   // (scalar comparison: a vector compare would be lowered to EXEC masking, under which both s_setprio would execute)
   const int theirs = __builtin_amdgcn_readfirstlane(theirs_v);
+  if (EY_PHASE_PRIO == 1 || EY_PHASE_PRIO == 2) {  // the levels are set where the phases change (chain_enter / chain_exit)
+    if (EY_PHASE_PRIO == 2) pc.hi = !(pc.left + pc.bias < theirs);
+    return;
+  }
   if (pc.left + pc.bias < theirs) __builtin_amdgcn_s_setprio(0);
   else __builtin_amdgcn_s_setprio(1);
+}
+
+// Priority by phase (EY_PHASE_PRIO = 1: levels 0 inside / 2 outside a chain of bf16 products, no pacing; 2: the pacing bit
+// as the low bit of both levels; 3: only the scheduling barriers).  MEASURED AND NOT KEPT (round 4).  The probe
+// (tools/coexec2_probe.hip, profiles/r04_coexec2_probe.txt) shows that a wave whose next instruction is a
+// v_mfma_f32_32x32x16_bf16 waiting for the matrix pipe holds the SIMD's vector issue port -- beside a wave inside a chain of
+// such products the partner's vector instructions do not issue at all, the two waves' times ADD -- unless the partner has
+// the higher priority: then its plain / transcendental / convert instructions run in the MFMAs' shadow (16 MFMAs + 128
+// v_fma_f32: 30.7 ns per MFMA slot at equal priority, 21.3 with the vector wave at priority 1; packed f32 instructions and
+// f32 MFMAs never overlap with a bf16 MFMA, in either wave).  In this kernel it does not pay: levels by phase without the
+// pacing 0.886 ms per draw against 0.800 (the older wave of each SIMD then finishes its chains in 396 us and the younger
+// in 599, the tail of the launch runs one wave per SIMD; tools/wave_timeline.py), with the pacing bit below the phase bit
+// 0.837, and 0.809 when the device code is also compiled without packed f32 instructions (profiles/r04_ab_phase_prio.txt).
+// The paired throughput is the same with and without (4.19 against 4.17 chains per ms and SIMD): the vector phases are
+// themselves 45 % f32 MFMA and packed instructions, which nothing overlaps.
+#ifndef EY_PHASE_SB
+#define EY_PHASE_SB 1
+#endif
+__device__ __forceinline__ void chain_enter(const Pace& pc) {
+  if (EY_PHASE_PRIO == 0) return;
+  if (EY_PHASE_SB) __builtin_amdgcn_sched_barrier(0);
+  if (EY_PHASE_PRIO == 3) return;
+  if (EY_PHASE_PRIO == 2 && pc.hi) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void chain_exit(const Pace& pc) {
+  if (EY_PHASE_PRIO == 0) return;
+  if (EY_PHASE_PRIO != 3) {
+    if (EY_PHASE_PRIO == 2 && pc.hi) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(2);
+  }
+  if (EY_PHASE_SB) __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---- the piece images of BF3 = 2: a tile X[feature][row] in the T layout, already split, goes to LDS as
@@ -588,7 +629,9 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       } else {
         A1p.lo[0] = pv[4 * 64]; A1p.lo[1] = pv[5 * 64];
       }
+      chain_enter(pc);
       acc = product_bf3(A1p, B1p, acc);
+      chain_exit(pc);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -700,7 +743,9 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       // B = delta1's pieces: the accumulator is a T tile like H0, so delta0 = dH0 * H0 (1 - H0) takes H0 from registers
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      chain_enter(pc);
       acc = product_bf3<true>(Bw, Ad, acc);
+      chain_exit(pc);
       const f32x16 D0 = times_dact<SH::ACT>(acc, H0);
       PH(7);
       // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in]: both operands from the piece images, transposed
@@ -708,7 +753,9 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
         Pieces AdU, BhU;
         load_pieces_transposed(lw + O_TB0, AdU, h, lane);
         load_pieces_transposed(lw + O_TB1, BhU, h, lane);
+        chain_enter(pc);
         dW1 = product_bf3(AdU, BhU, dW1);
+        chain_exit(pc);
       }
       // delta0 with lane <-> feature for the dW0 product, through H0's image (read by now)
       wave_lds_fence();
@@ -1201,6 +1248,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   pc.partner = wave;
   pc.left = 0;
   pc.bias = 0;
+  pc.hi = false;
+  if ((EY_PHASE_PRIO == 1 || EY_PHASE_PRIO == 2) && BF3 == 2) __builtin_amdgcn_s_setprio(2);  // the level of a wave outside a chain of bf16 products
   int mates = 0;
   for (int w = 0; w < MF_WAVES; ++w)
     if (w != wave && ctl[MF_WAVES + w] == simd) { pc.partner = w; ++mates; }
