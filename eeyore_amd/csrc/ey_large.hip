@@ -54,7 +54,12 @@ struct BGT {
   // (k_bf3_presplit), pre_rows rows
   const void* pre;
   int pre_rows;
+  // every parameter has the same prior (mu0, 1 / sigma0^2) (ey_plan_set_prior detects it): the fused update then reads no prior arrays
+  int pr_uniform;
+  T pr_mu0, pr_iv0;
+  int epi_nobatch;  // ey_debug_set_variant bit 12: the element-by-element form of the fused update (A/B runs, tests)
 };
+#define EY_DEV_NOBATCH(g) ((g).epi_nobatch != 0)
 using BG = BGT<float>;
 
 __device__ __forceinline__ float l_act(int code, float g) {
@@ -265,13 +270,86 @@ __device__ __forceinline__ void epi_loop(const BG& g, const f32x16 (&acc)[TM][TN
     }
   }
 }
+// The epilogue of a weight-gradient product on a FULL tile, batched: minus the prior gradient, times the temperature, and
+// (LF) the fused leapfrog update.  Written element by element (epi_loop) the compiler waited for every element's loads
+// before it stored that element and only then issued the next element's loads -- stores and loads share one in-order
+// counter (vmcnt) --: 64 serial HBM round trips per lane and tile, 58 us of a workgroup's 217 in config 5's first-layer
+// weight gradient, none of it hidden behind the other workgroups' products (the product alone 5.08 ms, with this epilogue
+// 6.94; tools/dw0_alone.py, tools/isa_mem_blocks.py).  Here the lane's 64 elements go in batches of BS whose loads are all
+// issued before the PREVIOUS batch is computed and stored: two batches in flight (32 registers: the accumulators leave no
+// more at three workgroups per CU), 64 / BS + 1 round trips.  Same arithmetic per element and the same order of the terms
+// of q: bit for bit the results of the loop (ey_debug_set_variant bit 12 switches back to it).
+// UNI: one (mu, 1 / sigma^2) for all parameters -- no prior loads, a batch is 8 elements (LF) / 16; otherwise 4 / 5.
+template <int TM, int TN, bool UNI, bool LF>
+__device__ __forceinline__ float epi_dw_full(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                             int c, int h, long b, float tscale, float ep, float et) {
+  constexpr int NE = TM * TN * 16;
+  constexpr int BS = UNI ? (LF ? 8 : 16) : 4, NB = NE / BS;
+  static_assert(NE % BS == 0, "whole batches");
+  const unsigned sCm = 4u * (unsigned)g.sCm, sCn = 4u * (unsigned)g.sCn;
+  float* __restrict__ th = const_cast<float*>(g.pr_theta) + b * g.bC;
+  float* __restrict__ pp = LF ? g.lf_p + b * g.bC : nullptr;
+  float* __restrict__ Cr = g.C + b * g.bC;
+  const float* __restrict__ mu = g.pr_mu;
+  const float* __restrict__ iv = g.pr_iv;
+  const bool store_g = !LF || g.lf_store_g != 0, move = LF && g.lf_wt != 0.0f;
+  const float mu0 = g.pr_mu0, iv0 = g.pr_iv0;
+  const unsigned base = (unsigned)(m0 + wm * (32 * TM) + 4 * h) * sCm + (unsigned)(n0 + wn * (32 * TN) + c) * sCn;
+  // element idx = (j TM + i) 16 + r, the order epi_loop visits them in
+  auto off = [&](int idx) -> unsigned {
+    const int j = idx / (TM * 16), i = (idx / 16) % TM, r = idx % 16;
+    return base + (unsigned)(32 * i + 8 * (r >> 2) + (r & 3)) * sCm + (unsigned)(32 * j) * sCn;
+  };
+  float tb[2][BS], pb[2][LF ? BS : 1], mb_[2][UNI ? 1 : BS], ib[2][UNI ? 1 : BS];
+  auto load = [&](int e, int buf) {
+#pragma unroll
+    for (int k = 0; k < BS; ++k) {
+      const unsigned ci = off(e * BS + k);
+      tb[buf][k] = EPI_AT(th, ci);
+      if constexpr (LF) pb[buf][k] = EPI_AT(pp, ci);
+      if constexpr (!UNI) { mb_[buf][k] = EPI_AT(mu, ci); ib[buf][k] = EPI_AT(iv, ci); }
+    }
+  };
+  float q = 0.0f;
+  load(0, 0);
+#pragma unroll
+  for (int e = 0; e < NB; ++e) {
+    if (e + 1 < NB) load(e + 1, (e + 1) & 1);
+    asm volatile("" ::: "memory");  // the next batch's loads stay above this batch's stores
+#pragma unroll
+    for (int k = 0; k < BS; ++k) {
+      const int idx = e * BS + k;
+      const unsigned ci = off(idx);
+      const float v = acc[(idx / 16) % TM][idx / (TM * 16)][idx % 16];
+      const float m_ = UNI ? mu0 : mb_[e & 1][UNI ? 0 : k], i_ = UNI ? iv0 : ib[e & 1][UNI ? 0 : k];
+      float tv = tb[e & 1][k];
+      const float gv = (v - (tv - m_) * i_) * tscale;
+      if (store_g) EPI_AT(Cr, ci) = gv;
+      if constexpr (LF) {
+        const float pv = pb[e & 1][k] + ep * gv;
+        EPI_AT(pp, ci) = pv;
+        if (move) { tv = tv + et * pv; EPI_AT(th, ci) = tv; }
+        const float d = tv - m_;
+        q += d * d * i_;
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+  return q;
+}
 // returns this lane's part of the prior quadratic form of the NEW position when the leapfrog update is fused in
 template <int TM, int TN, bool FULL>
 __device__ __forceinline__ float epi_kind(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
                                           int h, long b, float tscale, float ep, float et) {
   float* C = g.C + b * g.bC;
   float q = 0.0f;
-  if (g.pr_theta && g.lf_p) {  // weight gradient with the leapfrog update fused in
+  if (FULL && g.pr_theta && !EY_DEV_NOBATCH(g)) {
+    if (g.lf_p)
+      return g.pr_uniform ? epi_dw_full<TM, TN, true, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et)
+                          : epi_dw_full<TM, TN, false, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et);
+    return g.pr_uniform ? epi_dw_full<TM, TN, true, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et)
+                        : epi_dw_full<TM, TN, false, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et);
+  } else if (g.pr_theta && g.lf_p) {  // weight gradient with the leapfrog update fused in
     // the four arrays are distinct and every element is touched once: telling the compiler lets it issue the loads of
     // the following elements before the stores of this one (otherwise every element is a serialized HBM round trip)
     float* __restrict__ th = const_cast<float*>(g.pr_theta) + b * g.bC;
@@ -2032,6 +2110,8 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
         g.pr_iv_b = (const T*)m.inv_var + m.boff[l];
       }
       g.pr_temp = temp;
+      if (pl->prior_uniform) { g.pr_uniform = 1; g.pr_mu0 = (T)pl->prior_mu0; g.pr_iv0 = (T)pl->prior_iv0; }
+      g.epi_nobatch = EY_VBIT(12);
       if (lf) {
         g.lf_p = lf->p + m.woff[l]; g.lf_p_b = m.boff[l] >= 0 ? lf->p + m.boff[l] : nullptr; g.lf_q = lf->q_out;
         g.lf_step_vec = lf->step_vec; g.lf_step = lf->step; g.lf_wp = lf->wp; g.lf_wt = lf->wt;

@@ -29,6 +29,9 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 if os.environ.get("EY_NO_DMA"):  # A/B: the register-staged GEMM instead of the LDS-DMA one
     from eeyore_amd import _lib as L
     L.lib().ey_debug_set_variant(32)
+if os.environ.get("EY_VARIANT"):  # A/B: any ey_debug_set_variant bits (4096 = one chain per workgroup in the shared-operand product)
+    from eeyore_amd import _lib as L
+    L.lib().ey_debug_set_variant(int(os.environ["EY_VARIANT"]))
 N, L, between = 1024, 20, 10
 # the step: EY_CFG5_STEP (default: the step tools/step_sweep_cfg5.py found for 0.6-0.9 acceptance after burn-in)
 eps = float(os.environ.get("EY_CFG5_STEP", "0.004"))
