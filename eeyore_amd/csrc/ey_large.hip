@@ -270,47 +270,39 @@ __device__ __forceinline__ void epi_loop(const BG& g, const f32x16 (&acc)[TM][TN
     }
   }
 }
-// The epilogue of a weight-gradient product on a FULL tile, batched: minus the prior gradient, times the temperature, and
-// (LF) the fused leapfrog update.  Written element by element (epi_loop) the compiler waited for every element's loads
-// before it stored that element and only then issued the next element's loads -- stores and loads share one in-order
-// counter (vmcnt) --: 64 serial HBM round trips per lane and tile, 58 us of a workgroup's 217 in config 5's first-layer
-// weight gradient, none of it hidden behind the other workgroups' products (the product alone 5.08 ms, with this epilogue
-// 6.94; tools/dw0_alone.py, tools/isa_mem_blocks.py).  Here the lane's 64 elements go in batches of BS whose loads are all
-// issued before the PREVIOUS batch is computed and stored: two batches in flight (32 registers: the accumulators leave no
-// more at three workgroups per CU), 64 / BS + 1 round trips.  Same arithmetic per element and the same order of the terms
-// of q: bit for bit the results of the loop (ey_debug_set_variant bit 12 switches back to it).
-// UNI: one (mu, 1 / sigma^2) for all parameters -- no prior loads, a batch is 8 elements (LF) / 16; otherwise 4 / 5.
-template <int TM, int TN, bool UNI, bool LF>
-__device__ __forceinline__ float epi_dw_full(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                             int c, int h, long b, float tscale, float ep, float et) {
-  constexpr int NE = TM * TN * 16;
-  constexpr int BS = UNI ? (LF ? 8 : 16) : 4, NB = NE / BS;
+// Epilogues that READ per element (the prior gradient / fused leapfrog update of a weight-gradient product: theta, p, mu,
+// 1 / sigma^2; the input gradient: H), batched.  Written element by element (epi_loop) the compiler waited for every
+// element's loads before it stored that element and only then issued the next element's loads -- stores and loads share
+// one in-order counter (vmcnt) --: 64 serial memory round trips per lane and tile, 58 us of a workgroup's 217 in config 5's
+// first-layer weight gradient (the product alone 5.08 ms, with the update 6.94; tools/dw0_alone.py, tools/isa_mem_blocks.py),
+// and nearly ALL of a workgroup's 41 .. 64 us in the products of mid-size models (seven k-steps per tile).  Here the lane's
+// elements go in batches of BS (NL loaded values each) whose loads are all issued before the PREVIOUS batch is computed and
+// stored: two batches in flight (at most 32 registers: the accumulators leave no more at three workgroups per CU), NE / BS
+// + 1 round trips.  Elements beyond the matrix (tiles that are not FULL) load from offset 0 instead and are skipped by the
+// consumer -- no branch depends on the lane.  `ld(v, ci, m, n)` fills the NL values of the element at byte offset ci,
+// `cf(acc, v, ci, m, n)` consumes them; the elements are visited in epi_loop's order, so sums over them (the prior
+// quadratic form q) keep their order of terms: bit for bit the results of the loop (ey_debug_set_variant bit 12 = the loop).
+template <int TM, int TN, bool FULL, int BS, int NL, class LD, class CF>
+__device__ __forceinline__ void epi_batches(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
+                                            int h, LD ld, CF cf) {
+  constexpr int NE = TM * TN * 16, NB = NE / BS;
   static_assert(NE % BS == 0, "whole batches");
   const unsigned sCm = 4u * (unsigned)g.sCm, sCn = 4u * (unsigned)g.sCn;
-  float* __restrict__ th = const_cast<float*>(g.pr_theta) + b * g.bC;
-  float* __restrict__ pp = LF ? g.lf_p + b * g.bC : nullptr;
-  float* __restrict__ Cr = g.C + b * g.bC;
-  const float* __restrict__ mu = g.pr_mu;
-  const float* __restrict__ iv = g.pr_iv;
-  const bool store_g = !LF || g.lf_store_g != 0, move = LF && g.lf_wt != 0.0f;
-  const float mu0 = g.pr_mu0, iv0 = g.pr_iv0;
-  const unsigned base = (unsigned)(m0 + wm * (32 * TM) + 4 * h) * sCm + (unsigned)(n0 + wn * (32 * TN) + c) * sCn;
-  // element idx = (j TM + i) 16 + r, the order epi_loop visits them in
-  auto off = [&](int idx) -> unsigned {
-    const int j = idx / (TM * 16), i = (idx / 16) % TM, r = idx % 16;
-    return base + (unsigned)(32 * i + 8 * (r >> 2) + (r & 3)) * sCm + (unsigned)(32 * j) * sCn;
-  };
-  float tb[2][BS], pb[2][LF ? BS : 1], mb_[2][UNI ? 1 : BS], ib[2][UNI ? 1 : BS];
-  auto load = [&](int e, int buf) {
+  const int mb0 = m0 + wm * (32 * TM) + 4 * h, nb0 = n0 + wn * (32 * TN) + c;
+  const unsigned base = (unsigned)mb0 * sCm + (unsigned)nb0 * sCn;
+  float buf[2][BS][NL];
+  // element idx = (j TM + i) 16 + r: row mb0 + 32 i + 8 (r >> 2) + (r & 3), column nb0 + 32 j
+  auto dm = [](int idx) { return 32 * ((idx / 16) % TM) + 8 * ((idx % 16) >> 2) + (idx & 3); };
+  auto dn = [](int idx) { return 32 * (idx / (TM * 16)); };
+  auto load = [&](int e, int b) {
 #pragma unroll
     for (int k = 0; k < BS; ++k) {
-      const unsigned ci = off(e * BS + k);
-      tb[buf][k] = EPI_AT(th, ci);
-      if constexpr (LF) pb[buf][k] = EPI_AT(pp, ci);
-      if constexpr (!UNI) { mb_[buf][k] = EPI_AT(mu, ci); ib[buf][k] = EPI_AT(iv, ci); }
+      const int idx = e * BS + k, m = mb0 + dm(idx), n = nb0 + dn(idx);
+      const unsigned ci = base + (unsigned)dm(idx) * sCm + (unsigned)dn(idx) * sCn;
+      const bool in = FULL || (m < g.M && n < g.N);
+      ld(buf[b][k], in ? ci : 0u, in ? m : 0, in ? n : 0);
     }
   };
-  float q = 0.0f;
   load(0, 0);
 #pragma unroll
   for (int e = 0; e < NB; ++e) {
@@ -318,23 +310,47 @@ __device__ __forceinline__ float epi_dw_full(const BG& g, const f32x16 (&acc)[TM
     asm volatile("" ::: "memory");  // the next batch's loads stay above this batch's stores
 #pragma unroll
     for (int k = 0; k < BS; ++k) {
-      const int idx = e * BS + k;
-      const unsigned ci = off(idx);
-      const float v = acc[(idx / 16) % TM][idx / (TM * 16)][idx % 16];
-      const float m_ = UNI ? mu0 : mb_[e & 1][UNI ? 0 : k], i_ = UNI ? iv0 : ib[e & 1][UNI ? 0 : k];
-      float tv = tb[e & 1][k];
-      const float gv = (v - (tv - m_) * i_) * tscale;
-      if (store_g) EPI_AT(Cr, ci) = gv;
-      if constexpr (LF) {
-        const float pv = pb[e & 1][k] + ep * gv;
-        EPI_AT(pp, ci) = pv;
-        if (move) { tv = tv + et * pv; EPI_AT(th, ci) = tv; }
-        const float d = tv - m_;
-        q += d * d * i_;
-      }
+      const int idx = e * BS + k, m = mb0 + dm(idx), n = nb0 + dn(idx);
+      const unsigned ci = base + (unsigned)dm(idx) * sCm + (unsigned)dn(idx) * sCn;
+      if (FULL || (m < g.M && n < g.N)) cf(acc[(idx / 16) % TM][idx / (TM * 16)][idx % 16], buf[e & 1][k], ci, m, n);
     }
     asm volatile("" ::: "memory");
   }
+}
+// the weight-gradient epilogue on it: minus the prior gradient, times the temperature and (LF) the fused leapfrog update.
+// UNI: one (mu, 1 / sigma^2) for all parameters (ey_plan_set_prior detects it) -- no prior loads, twice the batch.
+template <int TM, int TN, bool FULL, bool UNI, bool LF>
+__device__ __forceinline__ float epi_dw(const BG& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int c,
+                                        int h, long b, float tscale, float ep, float et) {
+  constexpr int NL = (LF ? 2 : 1) + (UNI ? 0 : 2), BS = UNI ? (LF ? 8 : 16) : 4;
+  float* __restrict__ th = const_cast<float*>(g.pr_theta) + b * g.bC;
+  float* __restrict__ pp = LF ? g.lf_p + b * g.bC : nullptr;
+  float* __restrict__ Cr = g.C + b * g.bC;
+  const float* __restrict__ mu = g.pr_mu;
+  const float* __restrict__ iv = g.pr_iv;
+  const bool store_g = !LF || g.lf_store_g != 0, move = LF && g.lf_wt != 0.0f;
+  const float mu0 = g.pr_mu0, iv0 = g.pr_iv0;
+  float q = 0.0f;
+  epi_batches<TM, TN, FULL, BS, NL>(
+      g, acc, m0, n0, wm, wn, c, h,
+      [&](float (&v)[NL], unsigned ci, int, int) {
+        v[0] = EPI_AT(th, ci);
+        if constexpr (LF) v[1] = EPI_AT(pp, ci);
+        if constexpr (!UNI) { v[NL - 2] = EPI_AT(mu, ci); v[NL - 1] = EPI_AT(iv, ci); }
+      },
+      [&](float a, const float (&v)[NL], unsigned ci, int, int) {
+        const float m_ = UNI ? mu0 : v[NL - 2], i_ = UNI ? iv0 : v[NL - 1];
+        float tv = v[0];
+        const float gv = (a - (tv - m_) * i_) * tscale;
+        if (store_g) EPI_AT(Cr, ci) = gv;
+        if constexpr (LF) {
+          const float pv = v[1] + ep * gv;
+          EPI_AT(pp, ci) = pv;
+          if (move) { tv = tv + et * pv; EPI_AT(th, ci) = tv; }
+          const float d = tv - m_;
+          q += d * d * i_;
+        }
+      });
   return q;
 }
 // returns this lane's part of the prior quadratic form of the NEW position when the leapfrog update is fused in
@@ -343,12 +359,22 @@ __device__ __forceinline__ float epi_kind(const BG& g, const f32x16 (&acc)[TM][T
                                           int h, long b, float tscale, float ep, float et) {
   float* C = g.C + b * g.bC;
   float q = 0.0f;
-  if (FULL && g.pr_theta && !EY_DEV_NOBATCH(g)) {
+  if (g.pr_theta && !EY_DEV_NOBATCH(g)) {
     if (g.lf_p)
-      return g.pr_uniform ? epi_dw_full<TM, TN, true, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et)
-                          : epi_dw_full<TM, TN, false, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et);
-    return g.pr_uniform ? epi_dw_full<TM, TN, true, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et)
-                        : epi_dw_full<TM, TN, false, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et);
+      return g.pr_uniform ? epi_dw<TM, TN, FULL, true, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et)
+                          : epi_dw<TM, TN, FULL, false, true>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et);
+    return g.pr_uniform ? epi_dw<TM, TN, FULL, true, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et)
+                        : epi_dw<TM, TN, FULL, false, false>(g, acc, m0, n0, wm, wn, c, h, b, tscale, ep, et);
+  } else if (g.Hm && !EY_DEV_NOBATCH(g)) {  // input gradient: times act'(H), H read in batches of 16
+    float* __restrict__ Cr = C;
+    const float* __restrict__ Hm = g.Hm + b * g.bH;
+    const unsigned sHm = 4u * (unsigned)g.sHm, sHn = 4u * (unsigned)g.sHn;
+    const int act_h = g.act_h;
+    epi_batches<TM, TN, FULL, 16, 1>(
+        g, acc, m0, n0, wm, wn, c, h,
+        [&](float (&v)[1], unsigned, int m, int n) { v[0] = EPI_AT(Hm, (unsigned)m * sHm + (unsigned)n * sHn); },
+        [&](float a, const float (&v)[1], unsigned ci, int, int) { EPI_AT(Cr, ci) = a * l_dact(act_h, v[0]); });
+    return 0.0f;
   } else if (g.pr_theta && g.lf_p) {  // weight gradient with the leapfrog update fused in
     // the four arrays are distinct and every element is touched once: telling the compiler lets it issue the loads of
     // the following elements before the stores of this one (otherwise every element is a serialized HBM round trip)
@@ -1444,14 +1470,18 @@ __global__ void __launch_bounds__(256) k_prior(const T* __restrict__ theta, cons
 
 // ---- HMC elementwise pieces (one block per chain)
 template <class T>
-__global__ void __launch_bounds__(256) k_hmc_begin(const T* theta, const T* grad, const T* p0, T* thp,
-                                                   T* p, T* gp, int P, uint64_t seed, uint64_t iter,
+__global__ void __launch_bounds__(256) k_hmc_begin(const T* __restrict__ theta, const T* __restrict__ grad,
+                                                   const T* __restrict__ p0, T* __restrict__ thp, T* __restrict__ p,
+                                                   T* __restrict__ gp, int P, uint64_t seed, uint64_t iter,
                                                    uint64_t chain_offset, const T* target, T* hcur) {
   __shared__ T red[4];
   const long c = blockIdx.x;
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   T kin = T(0.0);
-  // momentum (hmc.py:134): one block of four stream elements per thread and round (one Philox call each)
+  // momentum (hmc.py:134): one block of four stream elements per thread and round (one Philox call each).  The arrays are
+  // distinct (__restrict__) and the rounds unrolled by four, so that the loads of four rounds are in flight together: as
+  // plain pointers every element's copy waited for the store before it (5.6 ms for config 5's share, 1.2 TB/s)
+#pragma unroll 4
   for (int b = threadIdx.x; 4 * b < P; b += blockDim.x) {
     T o[4];
     if (!p0) ey_rng_normal4<T>(rn, (uint32_t)b, o);
@@ -1537,8 +1567,9 @@ __global__ void __launch_bounds__(256) k_target(const T* __restrict__ qpart, int
 }
 
 template <class T>
-__global__ void __launch_bounds__(256) k_hmc_end(T* theta, T* grad, T* target, const T* thp,
-                                                 const T* p, const T* gp, const T* tprop, const T* hcur,
+__global__ void __launch_bounds__(256) k_hmc_end(T* __restrict__ theta, T* __restrict__ grad, T* target,
+                                                 const T* __restrict__ thp, const T* __restrict__ p,
+                                                 const T* __restrict__ gp, const T* tprop, const T* hcur,
                                                  const T* u_in, int P, uint64_t seed, uint64_t iter,
                                                  uint64_t chain_offset, unsigned char* accepted, T* rate_o,
                                                  T* hcur_o, T* hprop_o) {
@@ -1564,6 +1595,7 @@ __global__ void __launch_bounds__(256) k_hmc_end(T* theta, T* grad, T* target, c
   }
   __syncthreads();
   if (s_acc) {
+#pragma unroll 8
     for (int i = threadIdx.x; i < P; i += blockDim.x) {
       theta[c * P + i] = thp[c * P + i];
       grad[c * P + i] = gp[c * P + i];
@@ -1636,27 +1668,30 @@ __device__ __forceinline__ double row16_sum(double v) {
 __device__ __forceinline__ double l_act_fast(int code, double g) { return l_act(code, g); }
 // `room` = how many of this lane's F features exist (d - F q: the layer may be narrower than the 16 F the lanes span;
 // its width is a multiple of the vector piece -- 4, 2 or 1 floats -- so a piece is whole or absent)
+// No branch depends on the lane or the row: a piece that does not exist (features beyond d, rows beyond N) is loaded from
+// a piece that does -- `rowp` is a row inside the batch, the absent piece reads the row's first -- and dropped where the
+// values are USED (tail_mask).  Loads inside per-lane branches made the compiler wait for them where the branches merge:
+// with them (and the row's label fetched in the pass that used it) every pass of k_tail waited for its own prefetches,
+// 3 us per pass of 16 rows in config 5 (profiles/r04_cfg5_tail.txt).
 template <int F, class T>
-__device__ __forceinline__ void tail_load(const T* p, bool ok, int room, T (&h)[F]) {
-#pragma unroll
-  for (int f = 0; f < F; ++f) h[f] = T(0.0);
-  if (!ok) return;
+__device__ __forceinline__ void tail_load(const T* rowp, int q, int room, T (&h)[F]) {
   if constexpr (F >= 4) {
 #pragma unroll
     for (int f = 0; f < F; f += 4) {
-      if (f < room) {
-        const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(p + f);
-        h[f] = v.x; h[f + 1] = v.y; h[f + 2] = v.z; h[f + 3] = v.w;
-      }
+      const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(rowp + (f < room ? F * q + f : 0));
+      h[f] = v.x; h[f + 1] = v.y; h[f + 2] = v.z; h[f + 3] = v.w;
     }
   } else if constexpr (F == 2) {
-    if (room > 0) {
-      const Vec2<T> v = *reinterpret_cast<const Vec2<T>*>(p);
-      h[0] = v.x; h[1] = v.y;
-    }
+    const Vec2<T> v = *reinterpret_cast<const Vec2<T>*>(rowp + (room > 0 ? 2 * q : 0));
+    h[0] = v.x; h[1] = v.y;
   } else {
-    if (room > 0) h[0] = p[0];
+    h[0] = rowp[room > 0 ? q : 0];
   }
+}
+template <int F, class T>
+__device__ __forceinline__ void tail_mask(bool ok, int room, const T (&raw)[F], T (&h)[F]) {
+#pragma unroll
+  for (int f = 0; f < F; ++f) h[f] = (ok && (F >= 4 ? (f & ~3) : 0) < room) ? raw[f] : T(0.0);
 }
 template <int F, class T>
 __device__ __forceinline__ void tail_store(T* p, int room, const T (&h)[F]) {
@@ -1705,7 +1740,7 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
   const int tid = threadIdx.x, q = tid & (LPR - 1), rs = tid / LPR, wave = tid >> 6, lane = tid & 63;
   const long c = blockIdx.x;
   const int N = a.N, d = a.d, dK = a.dK;
-  const T* Hc = a.H + c * (long)N * d + F * q;
+  const T* Hc = a.H + c * (long)N * d;
   const int room = d - F * q;  // this lane's features that exist
   const T* th = a.theta + c * a.P;
   // W_{K-1} in LDS (rows beyond d_K zero), laid out so that the 16 lanes of a row read consecutive 16-byte pieces:
@@ -1743,10 +1778,12 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
   const T rowscale = a.rows_temp && a.temp ? a.temp[c] : T(1.0);
   const int passes = (N + RPP - 1) / RPP;
   T hb[TAIL_PF][F];
+  int lb[TAIL_PF];  // the rows' labels travel with them
 #pragma unroll
   for (int u = 0; u < TAIL_PF; ++u) {
-    const int n = RPP * u + rs;
-    tail_load<F>(Hc + (long)n * d, u < passes && n < N, room, hb[u]);
+    const int n = min(RPP * u + rs, N - 1);
+    tail_load<F>(Hc + (long)n * d, q, room, hb[u]);
+    lb[u] = a.labels[n];
   }
   for (int t0 = 0; t0 < passes; t0 += TAIL_PF) {
 #pragma unroll
@@ -1756,16 +1793,17 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
       const int n = RPP * t + rs;
       const bool live = n < N;
       T h[F];
-#pragma unroll
-      for (int f = 0; f < F; ++f) h[f] = hb[u][f];
+      tail_mask<F>(live, room, hb[u], h);
+      const int lab_pf = lb[u];
       // eight features per lane: q is made opaque per pass to keep the W reads below in the loop (hoisted they would
       // occupy 80 registers next to the 80 accumulators); with four or fewer the compiler hoists them, W lives in
       // registers and the loop has no LDS traffic
       int qv = q;
       if constexpr (F * sizeof(T) >= 32) asm volatile("" : "+v"(qv));
-      {  // refill this slot with the row TAIL_PF passes ahead
-        const int n2 = n + RPP * TAIL_PF;
-        tail_load<F>(Hc + (long)n2 * d, t + TAIL_PF < passes && n2 < N, room, hb[u]);
+      {  // refill this slot with the row TAIL_PF passes ahead (the last passes fetch row N - 1 again: never used)
+        const int n2 = min(n + RPP * TAIL_PF, N - 1);
+        tail_load<F>(Hc + (long)n2 * d, q, room, hb[u]);
+        lb[u] = a.labels[n2];
       }
       // logits: partial dot products over this lane's features, combined over the row's 16 lanes; rows of W beyond d_K
       // are zero.  The activation switches sit OUTSIDE the element loops (one uniform branch per pass, not per element).
@@ -1793,7 +1831,7 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
           }
         }
       } else {
-        const int lab = live ? a.labels[n] : 0;
+        const int lab = live ? lab_pf : 0;
         T mx = z[0];
 #pragma unroll
         for (int j = 1; j < TAIL_DK; ++j) mx = j < dK ? l_max(mx, z[j]) : mx;
@@ -2096,6 +2134,7 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
         d.C = D[l]; d.sCm = m.dims[l]; d.sCn = 1; d.bC = (long)N * m.dims[l];
         d.M = N; d.N = m.dims[l]; d.K = m.dims[l + 1];
         d.Hm = H[l]; d.sHm = m.dims[l]; d.sHn = 1; d.bH = (long)N * m.dims[l]; d.act_h = m.act[l - 1];
+        d.epi_nobatch = EY_VBIT(12);
         if ((rc = bgemm(d, C, s))) return rc;
       }
       BGT<T> g = {};  // dW_l = delta_{l+1}^T H_l, db_l = row sums of delta_{l+1}^T
