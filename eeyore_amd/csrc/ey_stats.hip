@@ -327,14 +327,263 @@ __global__ void __launch_bounds__(ST_THREADS) k_inse_multivariate(const T* __res
   }
 }
 
+// ---- the same estimator for wider chains, 16 < p <= 64 (and any n): config 2's MLP(2-3-2-1) already has 20 parameters.
+// One 256-thread workgroup per chain.  The centred samples do not fit LDS (n x p doubles), so the workgroup leaves them in
+// a global workspace (xc [C][n][64] doubles, columns beyond p zero) and streams them back through LDS in tiles of MW_TR
+// rows: thread (ta, tb) owns the 4 x 4 block of entries a = 4 ta .., b = 4 tb .. of BOTH lag matrices of a pair and sums
+// each entry over i in ascending order -- the order in which the reference adds its outer products (:24-31) -- so the sums
+// do not depend on the launch.  The p x p logic then runs on the whole workgroup instead of one thread: symmetrise and
+// accumulate through LDS, positive definiteness as a right-looking Cholesky attempt on an exactly symmetric matrix
+// (two barriers per column), the determinant by LU with partial pivoting (the first largest pivot, as LAPACK's getrf under
+// torch.det takes it; three barriers per column).  Matrices lie in LDS with a row stride of 65 doubles (columns are read
+// conflict-free).
+#define MW_P 64
+#define MW_LD 65
+#define MW_TR 16
+__device__ inline bool mw_chol_ok(double* w, int p, int tid, int* flag) {  // w is destroyed; uniform result
+  if (tid == 0) *flag = 1;
+  __syncthreads();
+  bool sym = true;
+  for (int e = tid; e < p * p; e += ST_THREADS) {
+    const int i = e / p, j = e - i * p;
+    if (w[i * MW_LD + j] != w[j * MW_LD + i]) sym = false;
+  }
+  if (!sym) *flag = 0;
+  __syncthreads();
+  if (!*flag) return false;
+  for (int j = 0; j < p; ++j) {
+    const double d = w[j * MW_LD + j];
+    if (!(d > 0.0)) return false;  // every thread reads the same value: uniform
+    const double dj = sqrt(d);
+    __syncthreads();               // everyone has read the diagonal element before the column is scaled
+    for (int i = j + 1 + tid; i < p; i += ST_THREADS) w[i * MW_LD + j] /= dj;
+    __syncthreads();
+    const int r = p - 1 - j;       // trailing square, lower triangle
+    for (int e = tid; e < r * r; e += ST_THREADS) {
+      const int i = j + 1 + e / r, k = j + 1 + e % r;
+      if (k <= i) w[i * MW_LD + k] -= w[i * MW_LD + j] * w[k * MW_LD + j];
+    }
+    __syncthreads();
+  }
+  return true;
+}
+__device__ inline double mw_det(double* w, int p, int tid, int* piv_s) {  // w is destroyed; uniform result
+  double det = 1.0;
+  for (int k = 0; k < p; ++k) {
+    if (tid < 64) {  // wave 0: lane i looks at row i; the first largest |w[i][k]|, i >= k
+      double v = (tid >= k && tid < p) ? fabs(w[tid * MW_LD + k]) : -1.0;
+      int idx = tid;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(v, o, 64);
+        const int i2 = __shfl_xor(idx, o, 64);
+        if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+      }
+      if (tid == 0) *piv_s = idx;
+    }
+    __syncthreads();
+    const int piv = *piv_s;
+    if (w[piv * MW_LD + k] == 0.0) return 0.0;  // uniform
+    if (piv != k) {
+      __syncthreads();  // everyone has read the pivot element
+      for (int j = tid; j < p; j += ST_THREADS) {
+        const double t = w[k * MW_LD + j];
+        w[k * MW_LD + j] = w[piv * MW_LD + j];
+        w[piv * MW_LD + j] = t;
+      }
+      det = -det;
+      __syncthreads();
+    }
+    const double pv = w[k * MW_LD + k];
+    det *= pv;
+    const int r = p - 1 - k;
+    for (int e = tid; e < r * r; e += ST_THREADS) {
+      const int i = k + 1 + e / r, j = k + 1 + e % r;
+      const double f = w[i * MW_LD + k] / pv;
+      w[i * MW_LD + j] -= f * w[k * MW_LD + j];
+    }
+    __syncthreads();
+  }
+  return det;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(ST_THREADS) k_inse_mv_wide(const T* __restrict__ x, int64_t n, int64_t C, int p, int64_t sn,
+                                                             int64_t sc, double* __restrict__ xcw, double* __restrict__ sig,
+                                                             double* __restrict__ cov, double* __restrict__ mean_o,
+                                                             int* __restrict__ pairs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Sig = reinterpret_cast<double*>(smem_raw);  // [64][65] each
+  double* Cand = Sig + MW_P * MW_LD;
+  double* Wk = Cand + MW_P * MW_LD;
+  double* sa = Wk + MW_P * MW_LD;                      // [MW_TR][64]     rows i0 ..
+  double* sb = sa + MW_TR * MW_P;                      // [MW_TR + 1][64] rows i0 + l0 ..
+  __shared__ double mean_s[MW_P];
+  __shared__ double part[4][MW_P];
+  __shared__ int flag_s, piv_s;
+  const int tid = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const int ni = (int)n;
+  const T* xc = x + c * sc;
+  double* xw = xcw + c * (int64_t)ni * MW_P;
+  // ---- mean (inse_mc_cov.py:10): column j by four threads over interleaved rows, combined in a fixed order; centre
+  {
+    const int j = tid & 63, q = tid >> 6;
+    double s = 0.0;
+    if (j < p)
+      for (int i = q; i < ni; i += 4) s += (double)xc[(int64_t)i * sn + j];
+    part[q][j] = s;
+    __syncthreads();
+    if (tid < MW_P) {
+      const double m = tid < p ? (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]) / (double)ni : 0.0;
+      mean_s[tid] = m;
+      if (mean_o && tid < p) mean_o[c * p + tid] = m;
+    }
+    __syncthreads();
+    for (int e = tid; e < ni * MW_P; e += ST_THREADS) {
+      const int i = e >> 6, jj = e & 63;
+      xw[e] = jj < p ? (double)xc[(int64_t)i * sn + jj] - mean_s[jj] : 0.0;
+    }
+    __syncthreads();  // (this workgroup's own global writes are read back below: same CU, in order)
+  }
+  const int ta = tid >> 4, tb = tid & 15;
+  double g0[4][4], g1[4][4];
+  // gam(l0) and gam(l0 + 1), the entries of this thread, summed over i ascending
+  auto lag_pair = [&](int l0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { g0[u][v] = 0.0; g1[u][v] = 0.0; }
+    const int cnt = ni - l0;  // rows i = 0 .. cnt - 1 enter gam(l0); gam(l0 + 1) ends one earlier (its partner row is zero)
+    for (int i0 = 0; i0 < cnt; i0 += MW_TR) {
+      __syncthreads();
+      for (int e = tid; e < MW_TR * MW_P; e += ST_THREADS) {
+        const int i = i0 + (e >> 6);
+        sa[e] = i < cnt ? xw[(int64_t)i * MW_P + (e & 63)] : 0.0;
+      }
+      for (int e = tid; e < (MW_TR + 1) * MW_P; e += ST_THREADS) {
+        const int i = i0 + l0 + (e >> 6);
+        sb[e] = i < ni ? xw[(int64_t)i * MW_P + (e & 63)] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int ii = 0; ii < MW_TR; ++ii) {
+        double xa[4], xb0[4], xb1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xa[u] = sa[ii * MW_P + 4 * ta + u];
+          xb0[u] = sb[ii * MW_P + 4 * tb + u];
+          xb1[u] = sb[(ii + 1) * MW_P + 4 * tb + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            g0[u][v] += xa[u] * xb0[v];
+            g1[u][v] += xa[u] * xb1[v];
+          }
+      }
+    }
+  };
+  const int ub = ni / 2;
+  double last = 0.0;
+  int state = 0, used = 0;  // 0: looking for the first positive definite Sig, 1: extending, 2: stopped (uniform)
+  for (int m = 0; m < ub && state != 2; ++m) {
+    lag_pair(2 * m);
+    // gam0 -> Cand, gam1 -> Wk (divided by n, :28, :31), then the candidate of every entry from both triangles
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int a = 4 * ta + u, b = 4 * tb + v;
+        Cand[a * MW_LD + b] = g0[u][v] / (double)ni;
+        Wk[a * MW_LD + b] = g1[u][v] / (double)ni;
+      }
+    __syncthreads();
+    double cnd[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int a = 4 * ta + u, b = 4 * tb + v;
+        const double G0ab = Cand[a * MW_LD + b];
+        const double Gab = G0ab + Wk[a * MW_LD + b], Gba = Cand[b * MW_LD + a] + Wk[b * MW_LD + a];
+        const double G = (Gab + Gba) / 2.0;                                              // :33-34
+        cnd[u][v] = (m == 0) ? (-G0ab + 2.0 * G) : (Sig[a * MW_LD + b] + 2.0 * G);       // :36-39 / :62
+        if (m == 0 && cov && a < p && b < p) cov[c * p * p + a * p + b] = G0ab * (double)ni / (double)(ni - 1);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int a = 4 * ta + u, b = 4 * tb + v;
+        Cand[a * MW_LD + b] = cnd[u][v];
+        Wk[a * MW_LD + b] = cnd[u][v];
+        if (state == 0) Sig[a * MW_LD + b] = cnd[u][v];
+      }
+    __syncthreads();
+    if (state == 0) {
+      if (mw_chol_ok(Wk, p, tid, &flag_s)) {  // :41-43
+        __syncthreads();
+        for (int e = tid; e < MW_P * MW_LD; e += ST_THREADS) Wk[e] = Sig[e];
+        __syncthreads();
+        last = mw_det(Wk, p, tid, &piv_s);    // :48
+        state = 1;
+        used = m + 1;
+      }
+    } else {
+      const double dtm = mw_det(Wk, p, tid, &piv_s);  // :63
+      if (dtm <= last) {                              // :64-65
+        state = 2;
+      } else {
+        __syncthreads();
+        for (int e = tid; e < MW_P * MW_LD; e += ST_THREADS) Sig[e] = Cand[e];
+        last = dtm;
+        used = m + 1;
+      }
+    }
+    __syncthreads();
+  }
+  const bool enough = state != 0;  // 'Not enough samples' (:45-46)
+  for (int e = tid; e < p * p; e += ST_THREADS) {
+    const int a = e / p, b = e - a * p;
+    sig[c * p * p + e] = enough ? Sig[a * MW_LD + b] : __builtin_nan("");
+  }
+  if (pairs && tid == 0) pairs[c] = enough ? used : -1;
+}
+#define MW_LDS_BYTES ((3 * MW_P * MW_LD + (2 * MW_TR + 1) * MW_P) * sizeof(double))
+
 extern "C" int ey_inse_multivariate(const void* x, int64_t n, int64_t C, int64_t p, int64_t stride_n, int64_t stride_c,
                                     int dtype, void* sig, void* cov, void* mean, void* num_pairs, void* stream) {
   if (!x || !sig) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: null argument");
   if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: bad dtype");
   if (n < 2) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: at least two iterations are needed");
-  if (p < 1 || p > MV_PMAX) EY_FAIL(EY_ERR_UNSUPPORTED, "ey_inse_multivariate: 1 <= p <= 16 (use ey_inse_univariate per parameter beyond)");
+  if (p < 1 || p > MW_P) EY_FAIL(EY_ERR_UNSUPPORTED, "ey_inse_multivariate: 1 <= p <= 64 (use ey_inse_univariate per parameter beyond)");
+  if (n > 0x7fffffff / MW_P) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: too many iterations");
   const size_t bytes = (size_t)n * (size_t)p * sizeof(double);
-  if (bytes > ST_LDS_BYTES) EY_FAIL(EY_ERR_UNSUPPORTED, "ey_inse_multivariate: a chain of n x p doubles must fit 144 KiB of LDS");
+  if (p > MV_PMAX || bytes > ST_LDS_BYTES) {  // the wide form: the centred chains in a workspace, matrices in LDS
+    if (C <= 0) return EY_OK;
+    hipStream_t s = (hipStream_t)stream;
+    double* xcw = nullptr;
+    EY_HIP(hipMallocAsync((void**)&xcw, (size_t)C * (size_t)n * MW_P * sizeof(double), s));
+    if (dtype == EY_F32) {
+      EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inse_mv_wide<float>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)MW_LDS_BYTES));
+      hipLaunchKernelGGL(k_inse_mv_wide<float>, dim3((unsigned)C), dim3(ST_THREADS), MW_LDS_BYTES, s, (const float*)x, n, C,
+                         (int)p, stride_n, stride_c, xcw, (double*)sig, (double*)cov, (double*)mean, (int*)num_pairs);
+    } else {
+      EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inse_mv_wide<double>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)MW_LDS_BYTES));
+      hipLaunchKernelGGL(k_inse_mv_wide<double>, dim3((unsigned)C), dim3(ST_THREADS), MW_LDS_BYTES, s, (const double*)x, n, C,
+                         (int)p, stride_n, stride_c, xcw, (double*)sig, (double*)cov, (double*)mean, (int*)num_pairs);
+    }
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(xcw, s);
+    EY_HIP(le);
+    return EY_OK;
+  }
   if (C <= 0) return EY_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EY_F32) {

@@ -11,7 +11,7 @@ import torch
 from eeyore_amd import _lib as L
 
 _DT = {torch.float32: L.EY_F32, torch.float64: L.EY_F64}
-MV_WIDTH_MAX = 16   # parameters per chain ey_inse_multivariate takes (MV_PMAX in csrc/ey_stats.hip)
+MV_WIDTH_MAX = 64   # parameters per chain ey_inse_multivariate takes (MW_P in csrc/ey_stats.hip)
 
 
 def inse_univariate(samples):
@@ -53,7 +53,7 @@ def mc_se(samples):
 # ---------------------------------------------------------------------------------------------- multivariate, many chains
 def inse_multivariate(samples, layout="ncp"):
     """The reference's multivariate initial-sequence estimator (eeyore/stats/inse_mc_cov.py:9-83, adjust=False) for
-    every chain at once on the device (``ey_inse_multivariate``: one workgroup per chain, p <= 16 parameters).
+    every chain at once on the device (``ey_inse_multivariate``: one workgroup per chain, p <= 64 parameters).
     ``samples``: [n, C, p] as a chain buffer stores a run (``layout="ncp"``) or [C, n, p] (``layout="cnp"``).
     Returns dict(sig [C,p,p], cov [C,p,p], mean [C,p], pairs [C]): the MC covariance (NaN where the reference raises
     'Not enough samples'), the unbiased sample covariance (cov.py:5-15), the chain means and the lag pairs used."""

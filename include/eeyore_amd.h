@@ -210,7 +210,8 @@ int ey_inse_univariate(const void* x, int64_t n, int64_t S, int dtype, void* sig
                        void* stream);
 
 /* The reference's MULTIVARIATE initial-sequence estimator (eeyore/stats/inse_mc_cov.py:9-83, adjust=False) for C
- * chains of p <= 16 parameters at once: x is addressed as x[i * stride_n + c * stride_c + j] (elements; a chain buffer
+ * chains of p <= 64 parameters at once (up to 16, with n p doubles inside 144 KiB, the chain lies in LDS; beyond that the
+ * centred chains go through a workspace the call allocates and frees on the stream): x is addressed as x[i * stride_n + c * stride_c + j] (elements; a chain buffer
  * [iterations, C, P] has stride_n = C*P, stride_c = P; [C, n, p] has stride_n = p, stride_c = n*p).  sig [C,p,p]
  * double: the estimate (NaN where the reference raises 'Not enough samples'); cov [C,p,p] double or NULL: the unbiased
  * sample covariance (eeyore/stats/cov.py:5-15); mean [C,p] double or NULL; num_pairs [C] int32 or NULL.  With these,

@@ -2279,7 +2279,54 @@ def test_multivariate_inse_ess_rhat_on_the_device_match_the_reference():
     ok = ~np.isnan(sig).any(axis=(1, 2))
     np.testing.assert_allclose(r32["cov"].cpu().numpy()[ok], r["cov"].cpu().numpy()[ok], rtol=1e-4, atol=1e-6)
     with pytest.raises(RuntimeError):
-        batched.inse_multivariate(_t(rng.standard_normal((2, 50, 17))), "cnp")  # p > 16
+        batched.inse_multivariate(_t(rng.standard_normal((2, 50, 65))), "cnp")  # p > 64
+
+
+@pytest.mark.parametrize("p,n,C", [(17, 30, 3), (20, 240, 5), (33, 121, 2), (40, 700, 2), (64, 300, 3), (64, 40, 2),
+                                   (16, 2000, 2), (5, 5000, 1)])
+def test_multivariate_inse_beyond_sixteen_parameters(p, n, C):
+    """ey_inse_multivariate's wide form (16 < p <= 64, or a chain too long for LDS: the centred chains in a workspace, the
+    p x p logic on the whole workgroup -- Cholesky attempt and LU determinant in LDS) against the per-chain port of the
+    reference's estimator (eeyore/stats/inse_mc_cov.py:9-83, pinned by G7), both layouts, f64 and f32 storage; config 2's
+    MLP(2-3-2-1) has 20 parameters.  multi_ess and multi_rhat follow from its outputs."""
+    import eeyore_amd.stats as st
+    from eeyore_amd.stats import batched
+    rng = np.random.default_rng(1000 * p + n)
+    phi = rng.uniform(0.0, 0.9, size=(C, 1, p))
+    e = rng.standard_normal((C, n, p))
+    y = np.empty_like(e)
+    y[:, 0] = e[:, 0]
+    for t in range(1, n):
+        y[:, t] = phi[:, 0] * y[:, t - 1] + e[:, t]
+    y = y @ (np.eye(p) + 0.2 * rng.standard_normal((p, p))) + rng.standard_normal((C, 1, p))
+    if C > 2:
+        y[C - 1] = 0.25  # a constant chain: 'Not enough samples'
+    checked = 0
+    for layout, xs in (("cnp", _t(y)), ("ncp", _t(y).permute(1, 0, 2).contiguous())):
+        r = batched.inse_multivariate(xs, layout)
+        sig = r["sig"].cpu().numpy()
+        np.testing.assert_allclose(r["mean"].cpu().numpy(), y.mean(1), rtol=1e-11, atol=1e-13)
+        for i in range(C):
+            try:
+                want = st.inse_mc_cov(torch.tensor(y[i])).numpy()
+            except RuntimeError:  # 'Not enough samples' (inse_mc_cov.py:45-46): also what n <= 2 p gives
+                assert np.isnan(sig[i]).all() and int(r["pairs"][i]) == -1, (i, p, n)
+                continue
+            cv = st.cov(torch.tensor(y[i]), rowvar=False).numpy()
+            scale = max(np.abs(want).max(), np.abs(cv).max())
+            np.testing.assert_allclose(sig[i], want, rtol=1e-8, atol=1e-11 * scale, err_msg=str((i, p, n, layout)))
+            np.testing.assert_allclose(r["cov"][i].cpu().numpy(), cv, rtol=1e-10, atol=1e-13 * scale)
+            assert np.array_equal(sig[i], sig[i].T)
+            checked += 1
+    r32 = batched.inse_multivariate(_t(y, torch.float32), "cnp")
+    ok = ~np.isnan(r32["sig"].cpu().numpy()).any(axis=(1, 2))
+    np.testing.assert_allclose(r32["cov"].cpu().numpy()[ok], np.stack([st.cov(torch.tensor(y[i]), rowvar=False).numpy()
+                                                                       for i in range(C)])[ok], rtol=2e-4, atol=1e-5)
+    if n >= 4 * p:
+        assert checked > 0
+        good = [i for i in range(C) if not np.isnan(sig[i]).any()]
+        ess = batched.multi_ess_device(_t(y[good]), "cnp").cpu().numpy()
+        np.testing.assert_allclose(ess, [float(st.multi_ess(torch.tensor(y[i]))) for i in good], rtol=1e-6)
 
 
 # --------------------------------------------------------------------------------------------- dual averaging in the kernels
