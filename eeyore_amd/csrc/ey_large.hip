@@ -14,6 +14,7 @@
 // update in the epilogues of the gradient kernels.  f64: k_bgemm_f64 on v_mfma_f64_16x16x4_f64.  The elementwise
 // kernels and the host logic are written once for both types.
 #include <atomic>
+#include <type_traits>
 #include <vector>
 
 #include "ey_common.h"
@@ -797,17 +798,24 @@ __device__ __forceinline__ void l_split8(const float (&v)[8], u32x4_t& hi, u32x4
 __device__ __forceinline__ f32x16 l_mfma_bf16(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
-// this thread's eight elements of k-chunk kt: k = 16 kt + 8 tg + j of the row `rowp` points at.  No branch depends on the
-// lane: a chunk that lies inside K (wave-uniform test) is loaded straight -- two 16-byte loads when k is contiguous, eight
-// dword loads otherwise --, only the last chunk of a K that is not a multiple of 16 clamps its addresses and zeroes what
-// lies beyond K.  (With per-lane bounds branches the compiler waited for every load where the branches merge, which
-// serialised the fetch of chunk kt + 1 with the products of chunk kt.)  Rows beyond the matrix are clamped by the
-// caller: their products land in outputs the epilogue drops.
+// this thread's eight elements of k-chunk kt: k = 16 kt + 8 tg + j of the row `rowp` points at.  No branch at all: with
+// any (even a wave-uniform one) the compiler can no longer count the younger loads that may stay in flight when it waits
+// for an older chunk and waits for everything -- which serialised the fetch of chunk kt + 2 with the products of chunk kt.
+// KTAIL = 0 (K a multiple of 16, decided on the host): two 16-byte loads when k is contiguous, eight dword loads
+// otherwise.  KTAIL = 1: eight dword loads whose k is clamped to K - 1.  KTAIL = 2 (K a multiple of 4): a k-contiguous
+// operand keeps its 16-byte loads, a group of four that lies beyond K is read from the row's last group instead.
+// bf3_zero_tail drops what lies beyond K where the values are used.  Rows beyond the matrix are clamped by the caller:
+// their products land in outputs the epilogue drops.
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-template <bool KF>
+template <bool KF, int KTAIL>
 __device__ __forceinline__ void bf3_fetch(const float* rowp, long sK, int K, int kt, int tg, float (&v)[8]) {
   const int k0 = kt * BK3 + 8 * tg;
-  if ((kt + 1) * BK3 <= K) {
+  if constexpr (KTAIL == 2 && KF) {
+    const f32x4_u lo = *reinterpret_cast<const f32x4_u*>(rowp + min(k0, K - 4));
+    const f32x4_u hi = *reinterpret_cast<const f32x4_u*>(rowp + min(k0 + 4, K - 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+  } else if constexpr (!KTAIL) {
     const float* src = rowp + (long)k0 * sK;
     if (KF) {
       const f32x4_u lo = *reinterpret_cast<const f32x4_u*>(src), hi = *reinterpret_cast<const f32x4_u*>(src + 4);
@@ -819,11 +827,15 @@ __device__ __forceinline__ void bf3_fetch(const float* rowp, long sK, int K, int
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = k0 + j;
-      const float x = rowp[(long)(k < K ? k : K - 1) * sK];
-      v[j] = k < K ? x : 0.0f;
-    }
+    for (int j = 0; j < 8; ++j) v[j] = rowp[(long)min(k0 + j, K - 1) * sK];
+  }
+}
+template <int KTAIL>
+__device__ __forceinline__ void bf3_zero_tail(int K, int kt, int tg, float (&v)[8]) {
+  if constexpr (KTAIL) {
+    const int k0 = kt * BK3 + 8 * tg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = k0 + j < K ? v[j] : 0.0f;
   }
 }
 // The shared operand split once per batch: element (row r, k) = src[r sRow + k sK]; thread (k-chunk, row, granule).
@@ -852,7 +864,7 @@ __global__ void __launch_bounds__(256) k_bf3_presplit(const float* __restrict__ 
 // loads and the split, which every workgroup of every chain otherwise repeats on the same data: config 5's forward
 // product 4.54 -> 4.24 ms.  (The same for x as the B operand of the first layer's weight gradient measured 5 % SLOWER,
 // 6.97 -> 7.35 ms: 48 bytes per task instead of 32 through an L2 that product already saturates.  Not kept.)
-template <bool AK, bool BK_, bool PRE = false>
+template <bool AK, bool BK_, bool PRE = false, int KTAIL = 0>
 __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
   __shared__ __attribute__((aligned(16))) u32x4_t As[2][3 * 128 * 2];
   __shared__ __attribute__((aligned(16))) u32x4_t Bs[2][3 * 128 * 2];
@@ -887,42 +899,52 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
   const int fb[2] = {rb * 2 + (h ^ BF3_SWZ(rb)), (rb + 32) * 2 + (h ^ BF3_SWZ(rb + 32))};
   const float* arow = A + (long)min(m0 + ar, g.M - 1) * g.sAm;
   const float* brow = B + (long)min(n0 + br, g.N - 1) * g.sBn;
-  float va[8], vb[8];
+  // Two chunks of fetches are in flight: chunk kt + 2 is requested at the top of iteration kt, chunk kt + 1 (requested an
+  // iteration earlier) is split and staged at its end.  With one chunk ahead every iteration waited for the fetch it had just
+  // issued (s_waitcnt vmcnt(0) behind 24 MFMAs = 0.3 us of cover for a 1 - 2 us round trip): the matrix pipe was busy 36 - 47 %
+  // of config 5's two big products.  The chunks alternate between two register sets (the loop is unrolled by two).
+  float va[2][8], vb[2][8];
   // the pre-split operand: thread (row tid >> 1, granule tid & 1), consecutive threads consecutive 16-byte units
   const int pr = tid >> 1, pg = tid & 1;
   const int p_slot = pr * 2 + (pg ^ BF3_SWZ(pr));
   const long pre_chunk = (long)g.pre_rows * 2;  // 16-byte units per (k-chunk, piece)
   const u32x4_t* pre = !PRE ? nullptr : reinterpret_cast<const u32x4_t*>(g.pre) + (long)min(m0 + pr, g.M - 1) * 2 + pg;
-  u32x4_t vp[3];
-  auto fetch_pre = [&](int kt) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) vp[p] = pre[(long)(kt * 3 + p) * pre_chunk];
-  };
-  auto stage = [&](int st) {
-    u32x4_t hi, mid, lo;
+  u32x4_t vp[2][3];
+  auto fetch = [&](int kt, auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
     if constexpr (PRE) {
-      As[st][0 * 256 + p_slot] = vp[0]; As[st][1 * 256 + p_slot] = vp[1]; As[st][2 * 256 + p_slot] = vp[2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) vp[S][p] = pre[(long)(kt * 3 + p) * pre_chunk];
     } else {
-      l_split8(va, hi, mid, lo);
+      bf3_fetch<AK, KTAIL>(arow, g.sAk, g.K, kt, ag, va[S]);
+    }
+    bf3_fetch<BK_, KTAIL>(brow, g.sBk, g.K, kt, bg, vb[S]);
+  };
+  auto stage = [&](int st, int kt, auto set_tag) {  // chunk kt from register set S into LDS stage st
+    constexpr int S = decltype(set_tag)::value;
+    u32x4_t hi, mid, lo;
+    if constexpr (!PRE) bf3_zero_tail<KTAIL>(g.K, kt, ag, va[S]);
+    bf3_zero_tail<KTAIL>(g.K, kt, bg, vb[S]);
+    if constexpr (PRE) {
+      As[st][0 * 256 + p_slot] = vp[S][0]; As[st][1 * 256 + p_slot] = vp[S][1]; As[st][2 * 256 + p_slot] = vp[S][2];
+    } else {
+      if (want_rowsum && kt < ktiles)  // (the iteration behind the last chunk stages that chunk once more: not summed twice)
+        rsum += ((va[S][0] + va[S][1]) + (va[S][2] + va[S][3])) + ((va[S][4] + va[S][5]) + (va[S][6] + va[S][7]));
+      l_split8(va[S], hi, mid, lo);
       As[st][0 * 256 + a_slot] = hi; As[st][1 * 256 + a_slot] = mid; As[st][2 * 256 + a_slot] = lo;
     }
-    l_split8(vb, hi, mid, lo);
+    l_split8(vb[S], hi, mid, lo);
     Bs[st][0 * 256 + b_slot] = hi; Bs[st][1 * 256 + b_slot] = mid; Bs[st][2 * 256 + b_slot] = lo;
   };
-  if constexpr (PRE) fetch_pre(0);
-  else bf3_fetch<AK>(arow, g.sAk, g.K, 0, ag, va);
-  bf3_fetch<BK_>(brow, g.sBk, g.K, 0, bg, vb);
-  if (want_rowsum) rsum += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
-  stage(0);
-  __syncthreads();
-  for (int kt = 0; kt < ktiles; ++kt) {
+  typedef std::integral_constant<int, 0> Set0;
+  typedef std::integral_constant<int, 1> Set1;
+  // one iteration: chunk kt is multiplied out of LDS stage kt & 1; chunk kt + 2 goes into the register set chunk kt had,
+  // chunk kt + 1 leaves the other one for LDS stage (kt + 1) & 1
+  auto iteration = [&](int kt, auto mine, auto other) {
     const int cur = kt & 1;
-    const bool more = kt + 1 < ktiles;
-    if (more) {
-      if constexpr (PRE) fetch_pre(kt + 1);
-      else bf3_fetch<AK>(arow, g.sAk, g.K, kt + 1, ag, va);
-      bf3_fetch<BK_>(brow, g.sBk, g.K, kt + 1, bg, vb);
-    }
+    // (unconditional: behind a branch the compiler can no longer count how many younger loads may stay in flight when it
+    // waits for chunk kt + 1 and waits for all of them; the last two iterations fetch the last chunk again, unused)
+    fetch(min(kt + 2, ktiles - 1), mine);
     u32x4_t pa[2][3], pb[2][3];  // [tile][piece: hi, mid, lo]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -939,12 +961,21 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = l_mfma_bf16(pa[i][TA[t]], pb[j][TB[t]], acc[i][j]);
-    if (more) {
-      if (want_rowsum) rsum += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
-      stage(cur ^ 1);
-    }
+    // (unconditional as well: the last iteration stages the re-fetched last chunk into the stage nobody reads any more;
+    // behind a branch the loop header waited for every load, see fetch)
+    stage(cur ^ 1, kt + 1, other);
     __syncthreads();
+  };
+  fetch(0, Set0());
+  stage(0, 0, Set0());
+  __syncthreads();
+  fetch(min(1, ktiles - 1), Set1());
+  int kt = 0;
+  for (; kt + 1 < ktiles; kt += 2) {
+    iteration(kt, Set0(), Set1());
+    iteration(kt + 1, Set1(), Set0());
   }
+  if (kt < ktiles) iteration(kt, Set0(), Set1());
   bool do_rowsum = false;
   if (want_rowsum) {  // the two granule columns of a row, in a fixed order
     rs_red[ag][ar] = rsum;
@@ -1238,11 +1269,20 @@ static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry) {
     bool kfast = false;
     const bool a_k = g.sAk == 1, b_k = g.sBk == 1;
     if (t_ey_products == EY_PRODUCTS_BF16X3 && (a_k || g.sAm == 1) && (b_k || g.sBn == 1)) {
-      if (g.pre && a_k && b_k && !g.rowsum) hipLaunchKernelGGL((k_bgemm_bf3<true, true, true>), grid, dim3(256), 0, s, g);
-      else if (a_k && b_k) hipLaunchKernelGGL((k_bgemm_bf3<true, true>), grid, dim3(256), 0, s, g);
-      else if (a_k) hipLaunchKernelGGL((k_bgemm_bf3<true, false>), grid, dim3(256), 0, s, g);
-      else if (b_k) hipLaunchKernelGGL((k_bgemm_bf3<false, true>), grid, dim3(256), 0, s, g);
-      else hipLaunchKernelGGL((k_bgemm_bf3<false, false>), grid, dim3(256), 0, s, g);
+      // the tail of K (a pre-split operand is zero-padded to whole chunks: its own fetch has none)
+      const int ktail = g.K % BK3 == 0 ? 0 : ((a_k || b_k) && g.K % 4 == 0 && g.K >= 4 ? 2 : 1);
+#define EY_BF3_LAUNCH(A_, B_, P_)                                                                      \
+  do {                                                                                                 \
+    if (ktail == 2) hipLaunchKernelGGL((k_bgemm_bf3<A_, B_, P_, 2>), grid, dim3(256), 0, s, g);        \
+    else if (ktail == 1) hipLaunchKernelGGL((k_bgemm_bf3<A_, B_, P_, 1>), grid, dim3(256), 0, s, g);   \
+    else hipLaunchKernelGGL((k_bgemm_bf3<A_, B_, P_, 0>), grid, dim3(256), 0, s, g);                   \
+  } while (0)
+      if (g.pre && a_k && b_k && !g.rowsum) EY_BF3_LAUNCH(true, true, true);
+      else if (a_k && b_k) EY_BF3_LAUNCH(true, true, false);
+      else if (a_k) EY_BF3_LAUNCH(true, false, false);
+      else if (b_k) EY_BF3_LAUNCH(false, true, false);
+      else EY_BF3_LAUNCH(false, false, false);
+#undef EY_BF3_LAUNCH
     } else if (g_bgemm_dma && dma_ok(g, kfast)) {
       if (kfast) hipLaunchKernelGGL(k_bgemm_dma<true>, grid, dim3(256), 0, s, g);
       else hipLaunchKernelGGL(k_bgemm_dma<false>, grid, dim3(256), 0, s, g);

@@ -33,9 +33,9 @@ if os.environ.get("EY_VARIANT"):  # A/B: any ey_debug_set_variant bits (4096 = o
     from eeyore_amd import _lib as L
     L.lib().ey_debug_set_variant(int(os.environ["EY_VARIANT"]))
 N, L, between = 1024, 20, 10
-# the step: EY_CFG5_STEP (default: the step tools/step_sweep_cfg5.py found for 0.6-0.9 acceptance after burn-in)
-eps = float(os.environ.get("EY_CFG5_STEP", "0.004"))
-burnin = int(os.environ.get("EY_CFG5_BURNIN", "0"))   # untimed iterations before the clock (acceptance is reported over the timed ones)
+# the step: EY_CFG5_STEP (default 0.024: acceptance 0.74 after burn-in, tools/step_sweep_cfg5.sh -> profiles/r04_cfg5_step_sweep.txt; 0.016: 0.89, 0.032: 0.00)
+eps = float(os.environ.get("EY_CFG5_STEP", "0.024"))
+burnin = int(os.environ.get("EY_CFG5_BURNIN", "20"))   # untimed iterations before the clock (acceptance is reported over the timed ones)
 DT = torch.float64 if os.environ.get("EY_F64") else torch.float32   # EY_F64=1: the f64 layerwise path (parity dtype)
 PEAK, PEAK_NAME = (78.6e12, "f64") if DT == torch.float64 else (157.3e12, "f32")
 
