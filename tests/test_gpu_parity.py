@@ -1626,6 +1626,55 @@ def test_bgemm_path_f64_vs_oracle(dims, acts, bias, lik, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,N,uniform_prior,products", [
+    ([784, 128, 10], 160, True, "bf16x3"),     # config 5's shape: full 128 x 128 tiles and the 16-column remainder
+    ([784, 128, 10], 96, False, "bf16x3"),     # edge tiles in M, a prior that differs per parameter
+    ([20, 100, 100, 5], 70, True, "bf16x3"),   # K = 100 (the clamped K tail), the input gradient's read of H
+    ([30, 140, 36, 4], 130, False, "exact"),   # the exact-product kernels share the epilogue
+])
+def test_bgemm_batched_epilogue_is_the_element_loop_bit_for_bit(dims, N, uniform_prior, products):
+    """The layerwise path's batched epilogues (prior gradient / fused leapfrog update of the weight-gradient products, the
+    input gradient's read of H: loads in batches, two batches in flight) against the element-by-element loop they replace
+    (ey_debug_set_variant bit 12): the same arithmetic per element and the same order of the prior sums, so value, gradient
+    and whole HMC draws are bit-identical."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(sum(dims) + N)
+    x = rng.standard_normal((N, dims[0])) * (rng.random((N, dims[0])) < 0.4)
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)]
+    f32 = torch.float32
+    C, K = 5, len(dims) - 1
+    P = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(K))
+    sig = torch.full((P,), 1.5) if uniform_prior else torch.tensor(rng.uniform(0.5, 2.0, P), dtype=f32)
+    mu = torch.zeros(P) if uniform_prior else torch.tensor(0.1 * rng.standard_normal(P), dtype=f32)
+    res = []
+    for variant in (16, 16 | 4096):
+        L.lib().ey_debug_set_variant(variant)
+        try:
+            pl = Plan(dims, [1] * K, [1] * (K - 1) + [0], 1, f32, DEV)
+            pl.f32_products = products
+            pl.set_data(_t(x, f32), _t(y, f32))
+            assert pl.P == P
+            pl.set_prior(mu, sig)
+            assert pl.kernel == "bgemm"
+            th = 0.05 * pl.philox_normal(C, seed=5, it=0)
+            temps = torch.tensor([1.0, 0.5, 1.0, 0.3, 2.0])
+            t, g = pl.log_target_grad(th, temp=temps)
+            t0, g0 = t.clone(), g.clone()
+            outs = [pl.hmc_step(th, t, g, 0.004, 6, temp=temps, seed=8, it=1 + it) for it in range(2)]
+            res.append((t0, g0, th.clone(), t.clone(), g.clone(), [o["accepted"].clone() for o in outs],
+                        [o["h_prop"].clone() for o in outs]))
+        finally:
+            L.lib().ey_debug_set_variant(0)
+    a, b = res
+    for i in range(5):
+        assert torch.equal(a[i], b[i]), i
+    for u, v in zip(a[5] + a[6], b[5] + b[6]):
+        assert torch.equal(u, v)
+    assert sum(int(o.sum()) for o in a[5]) > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dims,acts,bias,N", [
     ([4, 3, 3], [1, 0], [1, 1], 150),            # no fused tail (d = 3)
     ([3, 5, 4, 2], [2, 3, 0], [1, 0, 1], 77),    # a layer without bias
