@@ -1665,7 +1665,9 @@ bool ey_large_needed(const ey_plan* pl, int nvec) {
 // all of them hold the row's logits and compute the (cheap) loss redundantly.  Sums over rows are combined in a fixed
 // order (slots inside a wave, then waves): reproducible.
 #define TAIL_DK 10
+#ifndef TAIL_PF
 #define TAIL_PF 3
+#endif
 template <class T>
 struct TailArgsT {
   const T* H; T* Dout; const T* theta; T* grad; const T* mu; const T* iv;
@@ -1733,16 +1735,23 @@ __device__ __forceinline__ void tail_mask(bool ok, int room, const T (&raw)[F], 
 #pragma unroll
   for (int f = 0; f < F; ++f) h[f] = (ok && (F >= 4 ? (f & ~3) : 0) < room) ? raw[f] : T(0.0);
 }
+// Unconditional: a piece that must not be written (rows beyond N, features beyond d) goes to the lane's own slot of a junk
+// buffer instead.  Behind a per-lane branch the stores made the compiler merge two paths' counts of outstanding memory
+// operations conservatively, and every pass of k_tail waited for most of its prefetch ring.
+__device__ double g_tail_junk[256 * 8];
 template <int F, class T>
-__device__ __forceinline__ void tail_store(T* p, int room, const T (&h)[F]) {
+__device__ __forceinline__ void tail_store(T* p, bool ok, int room, const T (&h)[F]) {
+  T* junk = reinterpret_cast<T*>(g_tail_junk) + threadIdx.x * F;
   if constexpr (F >= 4) {
 #pragma unroll
-    for (int f = 0; f < F; f += 4)
-      if (f < room) *reinterpret_cast<Vec4<T>*>(p + f) = Vec4<T>{h[f], h[f + 1], h[f + 2], h[f + 3]};
+    for (int f = 0; f < F; f += 4) {
+      T* dst = (ok && f < room) ? p + f : junk + f;
+      *reinterpret_cast<Vec4<T>*>(dst) = Vec4<T>{h[f], h[f + 1], h[f + 2], h[f + 3]};
+    }
   } else if constexpr (F == 2) {
-    if (room > 0) *reinterpret_cast<Vec2<T>*>(p) = Vec2<T>{h[0], h[1]};
+    *reinterpret_cast<Vec2<T>*>((ok && room > 0) ? p : junk) = Vec2<T>{h[0], h[1]};
   } else {
-    if (room > 0) p[0] = h[0];
+    *((ok && room > 0) ? p : junk) = h[0];
   }
 }
 template <int F, int WS, class T>
@@ -1887,9 +1896,9 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
 #pragma unroll
         for (int j = 0; j < TAIL_DK; ++j) dl[j] = ((j == lab && live ? T(1.0) : T(0.0)) - e[j] * rsum) * da[j];
       }
-      if (live) {
-        lik += row;
-        if (a.rows_o && q == 0) a.rows_o[c * (long)N + n] = row * rowscale;
+      lik += live ? row : T(0.0);
+      if (a.rows_o) {  // (uniform: ey_log_lik_rows only)
+        if (live && q == 0) a.rows_o[c * (long)N + n] = row * rowscale;
       }
       if (GRAD) {
         T dh[F];
@@ -1906,12 +1915,12 @@ __global__ void __launch_bounds__(256, (F * sizeof(T) >= 32) ? 2 : 3) k_tail(Tai
             dh[f] += dl[j] * wj[f];
           }
         }
-        if (a.Dout && live) {
+        if (a.Dout) {  // (uniform)
           T dp[F];
           dact_vec<F>(a.act_prev, h, dp);
 #pragma unroll
           for (int f = 0; f < F; ++f) dh[f] *= dp[f];
-          tail_store<F>(a.Dout + c * (long)N * d + (long)n * d + F * q, room, dh);
+          tail_store<F>(a.Dout + c * (long)N * d + (long)n * d + F * q, live, room, dh);
         }
       }
     }
