@@ -1191,6 +1191,16 @@ static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   }
 }
 
+// EY_F16_W16: waves per CU of the f32 H = 16 instantiations.  16 (four per SIMD, 128 registers) is 13 - 16 % faster on the small
+// shapes (MLP(4-16-16-3) 34.4 -> 39.0 TFLOP/s, same bits in HMC) and is NOT shipped: at that register budget the padded
+// instantiation's MALA log-rate comes out wrong (MLP(4-10-7-3): the position's registers do not survive the evaluation --
+// value, gradient, proposal and every other mode are right; re-reading theta from memory behind the evaluation repairs it).
+// Not a timing hazard (no s_nop padding of any instruction class repairs it, tools/f16_asm_bisect.py) and not the DPP
+// reductions; -O1, twelve waves, and most flags that perturb the pre-RA scheduler or the allocator repair it
+// (profiles/r04_f16_w16_flags.txt).  Unresolved, taken to be the compiler's spilling at 128 registers; DESIGN.md 4.4.
+#ifndef EY_F16_W16
+#define EY_F16_W16 8
+#endif
 template <typename T>
 static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
   const EyModel& m = pl->m;
@@ -1213,7 +1223,7 @@ static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
   const int H = std::max(a.h1, a.h2);
   // waves per CU by what the per-wave LDS region and the register file allow
   if constexpr (sizeof(T) == 4) {
-    if (H <= 16) return f16_launch_w<float, 16, 8>(a, pl->n_cu, s);
+    if (H <= 16) return f16_launch_w<float, 16, EY_F16_W16>(a, pl->n_cu, s);
     if (H <= 32) return f16_launch_w<float, 32, 8>(a, pl->n_cu, s);
     return f16_launch_w<float, 64, 4>(a, pl->n_cu, s);
   } else {

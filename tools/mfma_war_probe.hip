@@ -14,7 +14,7 @@
 #include <cmath>
 #include <vector>
 
-enum { DGEMM16 = 0, DGEMM4 = 1, F32_32X32X2 = 2, BF16_32X32X16 = 3 };
+enum { DGEMM16 = 0, DGEMM4 = 1, F32_32X32X2 = 2, BF16_32X32X16 = 3, F32_16X16X4_V = 4, F32_4X4X1_V = 5, F64_16X16X4_V = 6 };
 
 // K < 0: the load follows the MFMA directly; K >= 0: s_nop K (K + 1 wait states) between them.
 // GLOBAL: the overwriting load is a global_load instead of ds_read.
@@ -68,6 +68,35 @@ __global__ void k_war(const double* __restrict__ in, double* __restrict__ out, c
         : [a] "v"(a), [b] "v"(b), [la] "v"(lds_addr), [ga] "v"(gaddr), [k] "n"(K), [g] "n"(GLOBAL ? 1 : 0), [hi] "v"(0x3ff00000)
         : "a0", "a1", "a8", "a9", "memory");
     out[lane] = d[0];
+    for (int r = 1; r < 4; ++r) out[r * 64 + lane] = 0.0;
+  } else if constexpr (KIND == F32_16X16X4_V || KIND == F32_4X4X1_V) {
+    // the f32 shapes of ey_fused16.hip / ey_mfma32.hip with SrcC and vDst in ARCHITECTURAL registers (those kernels use no
+    // accumulation registers): C = 1.0f, the load overwrites C's own registers
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const float af = (float)a, bf = (float)b;
+    f4 c4 = {1.0f, 1.0f, 1.0f, 1.0f}, d4;
+    if constexpr (KIND == F32_16X16X4_V) {
+      asm volatile("s_nop 7\n s_nop 7\n"
+                   "v_mfma_f32_16x16x4_f32 %[d], %[a], %[b], %[c]\n"
+                   ".if %[k] >= 0\n s_nop %[k]\n .endif\n"
+                   ".if %[g]\n global_load_dwordx4 %[c], %[ga], off\n .else\n ds_read_b128 %[c], %[la]\n .endif\n"
+                   "s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7\n"
+                   : [d] "=&v"(d4), [c] "+v"(c4)
+                   : [a] "v"(af), [b] "v"(bf), [la] "v"(lds_addr), [ga] "v"(gaddr), [k] "n"(K), [g] "n"(GLOBAL ? 1 : 0)
+                   : "memory");
+    } else {
+      asm volatile("s_nop 7\n s_nop 7\n"
+                   "v_mfma_f32_4x4x1_16b_f32 %[d], %[a], %[b], %[c]\n"
+                   ".if %[k] >= 0\n s_nop %[k]\n .endif\n"
+                   ".if %[g]\n global_load_dwordx4 %[c], %[ga], off\n .else\n ds_read_b128 %[c], %[la]\n .endif\n"
+                   "s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7\n"
+                   : [d] "=&v"(d4), [c] "+v"(c4)
+                   : [a] "v"(af), [b] "v"(bf), [la] "v"(lds_addr), [ga] "v"(gaddr), [k] "n"(K), [g] "n"(GLOBAL ? 1 : 0)
+                   : "memory");
+    }
+    double worst = 0;
+    for (int r = 0; r < 4; ++r) worst = fmax(worst, fabs((double)d4[r]));
+    out[lane] = worst;
     for (int r = 1; r < 4; ++r) out[r * 64 + lane] = 0.0;
   } else {
     // f32 32x32x2 (16 passes) / bf16 32x32x16 (8 passes on gfx950): C = 1.0f in a[16:31], D in a[0:15]
@@ -249,6 +278,11 @@ int main() {
   sweep<F32_32X32X2, true>("v_mfma_f32_32x32x2", din, dout, dpoison);
   sweep<BF16_32X32X16, false>("v_mfma_f32_32x32x16_bf16", din, dout, dpoison);
   sweep<BF16_32X32X16, true>("v_mfma_f32_32x32x16_bf16", din, dout, dpoison);
+  printf("SrcC and vDst in architectural registers (the f32 kernels use no accumulation registers):\n");
+  sweep<F32_16X16X4_V, false>("v_mfma_f32_16x16x4 (v)", din, dout, dpoison);
+  sweep<F32_16X16X4_V, true>("v_mfma_f32_16x16x4 (v)", din, dout, dpoison);
+  sweep<F32_4X4X1_V, false>("v_mfma_f32_4x4x1_16b (v)", din, dout, dpoison);
+  sweep<F32_4X4X1_V, true>("v_mfma_f32_4x4x1_16b (v)", din, dout, dpoison);
   sweep_fill<0>("s_nop 0", din, dout);
   sweep_fill<1>("ds_read_b32 (other register)", din, dout);
   sweep_fill<2>("v_mov_b32", din, dout);
