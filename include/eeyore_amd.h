@@ -252,7 +252,9 @@ int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* ta
  * 5, 6, 7: that path without LDS-DMA staging / fused last layer / fused leapfrog update; 8, 9: tiny models never / always
  * through the register-resident evaluation of the generic kernels; 10 (ey_debug_set_variant only): new plans, and
  * ey_debug_bgemm, start with EY_PRODUCTS_EXACT; 11: the layerwise path's bf16x3 products split the data matrix in every
- * workgroup instead of taking it pre-split.  Results agree to rounding across them (bit for bit across bit 11). */
+ * workgroup instead of taking it pre-split; 12: the layerwise path's epilogues that read per element (prior gradient, fused
+ * leapfrog update, act'(H)) element by element instead of in batches of loads.  Results agree to rounding across them (bit
+ * for bit across bits 11 and 12). */
 int ey_plan_set_variant(ey_plan* plan, int variant);
 int ey_debug_set_variant(int variant);
 
