@@ -237,6 +237,47 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def config5_share(dev, chains=4096, iters=3, burnin=20, step=0.024):
+    """BASELINE configs[4]'s share of ONE GPU, beside the headline (rank 0, N = 1 only; not the metric): HMC L = 20 on
+    MLP(784-128-10), MNIST-shaped synthetic data (N = 1024 rows, ~19 % non-zero, 10 balanced classes), `chains` chains at
+    one temperature, the layerwise path (tools/bench_config5.py is the stand-alone form with the tempering ladder).  Freed
+    again before it returns."""
+    import numpy as np
+    import torch
+    from eeyore_amd.plan import Plan
+    N, L = 1024, 20
+    rng = np.random.default_rng(0)
+    x = (rng.random((N, 784)) * (rng.random((N, 784)) < 0.19)).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[np.arange(N) % 10]
+    pl = Plan([784, 128, 10], [1, 1], [1, 0], 1, torch.float32, dev)
+    pl.set_data(torch.tensor(x, device=dev), torch.tensor(y, device=dev))
+    pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
+    th = 0.05 * pl.philox_normal(chains, seed=0, it=0)
+    t, g = pl.log_target_grad(th)
+    for b in range(burnin):
+        pl.hmc_step(th, t, g, step, L, seed=1, it=1 + b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    accs = []
+    e0.record()
+    for it in range(iters):
+        accs.append(pl.hmc_step(th, t, g, step, L, seed=1, it=1000 + it)["accepted"])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    f_step = 2 * N * (2 * (784 * 128 + 128 * 10) + 128 * 10) + 6 * pl.P
+    tflops = f_step * chains * L / (ms * 1e-3) / 1e12
+    out = {"workload": f"HMC L=20, {chains} chains, MLP(784-128-10) sigmoid-linear, CE-sum, prior N(0,1), MNIST-shaped synthetic "
+                       f"N={N} (BASELINE configs[4], one GPU's temperature)", "kernel": pl.kernel, "ms_per_hmc_iteration": ms,
+           "leapfrog_steps_per_sec_x_chains": chains * L / (ms * 1e-3), "flops_per_leapfrog_step_per_chain": f_step,
+           "tflops": tflops, "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS, "f32_products": pl.f32_products,
+           "step_size": step, "burnin_iterations": burnin, "timed_iterations": iters,
+           "acceptance": round(float(torch.stack(accs).float().mean().item()), 4)}
+    del pl, th, t, g
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +290,8 @@ def main():
     ap.add_argument("--no-record", action="store_true",
                     help="do not record the chains in the timed region (round 3's figure: the kernel without the sample store)")
     ap.add_argument("--no-sampler-run", action="store_true", help="skip the same workload timed through samplers.HMC.run")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the secondary measurement of BASELINE configs[4]'s per-GPU share (N = 1 only, ~10 s)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed launches before the timed region, on top of --warmup, until the clocks have settled")
     ap.add_argument("--force-generic", action="store_true", help="time the generic VALU kernel instead of the MFMA one")
@@ -463,6 +506,11 @@ def main():
                                      "num_chains": ess["num_chains"], "series_without_enough_samples": ess["not_enough"],
                                      "from": f"{steps_timed} recorded iterations of every chain (ey_inse_univariate), combined "
                                              f"over ranks by distributed.reduce_ess"}
+        if world == 1 and not args.no_config5 and not args.force_generic and not args.no_compare:
+            try:  # a secondary figure: never in the way of the headline line
+                line["config"]["secondary"] = {"config5_share_one_gpu": config5_share(dev)}
+            except Exception as e:  # noqa: BLE001
+                line["config"]["secondary"] = {"config5_share_one_gpu": {"error": repr(e)[:200]}}
         if via_sampler is not None:
             s_value = total_chains * L_STEPS * steps_timed / via_sampler[0]
             line["config"]["through_sampler_run"] = {
