@@ -419,7 +419,7 @@ def main():
     # recorded buffer through ey_inse_univariate on this rank, then min / mean / total per parameter over all ranks
     # (two small all-reduces, distributed.reduce_ess); also outside the step clock, timed on its own
     ess = None
-    if record and steps_timed >= 50:
+    if record and steps_timed >= 20:  # (the driver's --steps 20 becomes one launch of 25: a short series, but the gather runs)
         from eeyore_amd.stats import batched
         t2 = time.perf_counter()
         ess = reduce_ess(batched.ess(rec["s"][:steps_timed]))
