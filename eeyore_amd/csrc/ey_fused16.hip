@@ -334,7 +334,12 @@ struct F16Cfg {
   static constexpr int O_B0 = O_W2T + MT * 64 * (KSM == 4 ? 4 : 1);  // [H]
   static constexpr int O_B1 = O_B0 + H;                 // [H]
   static constexpr int O_D2 = O_B1 + H;                 // [4][16] delta2[o][row]  ([16][TS] transpose buffer of the delta2 tile)
-  static constexpr int WAVE_ELEMS = O_D2 + (KSM == 4 ? 16 * F16_TS : 64);
+  // O_JUNK: one element per lane that nothing reads.  A store that a lane must not make (a feature, an output or a bias slot
+  // the lane does not own) goes there instead of sitting behind a per-lane branch: inside such a branch only some lanes are
+  // active, and a register the allocator spills and reloads there -- theta, the momentum, a gradient: everything is live
+  // across these stores -- comes back with the inactive lanes' values lost.
+  static constexpr int O_JUNK = O_D2 + (KSM == 4 ? 16 * F16_TS : 64);
+  static constexpr int WAVE_ELEMS = O_JUNK + 64;
   // the N(0,1) stream of a draw is staged in [O_W1A, O_W0A) between evaluations: P <= H^2 + 14 H + 4 <= H^2 + 40 H
   static_assert(H * H + 14 * H + 4 <= O_W0A, "the staging area must hold P normals");
 };
@@ -408,34 +413,37 @@ __device__ __forceinline__ void f16_write_images(T* lw, const T (&th)[F16Cfg<H>:
     const int r = k & 3, n = (k >> 2) % K::MT, mo = (k >> 2) / K::MT;
     lw[K::O_W1A + ((mo * K::MT + n) * 4 + rk) * 64 + L::fi(g, r) + 16 * gk] = th[k];
   }
-  if (c < a.d0) {
+  const int junk = K::O_JUNK + (int)(threadIdx.x & 63);
+  {
+    const bool own = c < a.d0;
 #pragma unroll
     for (int k = 0; k < K::NW0; ++k) {  // W0[16m + fi(g, r)][c]: A operand of F0, k-step c >> 2, k-slot c & 3 (as k_f16_pack lays x out)
       const int r = k & 3, m = k >> 2;
-      lw[K::O_W0A + (m * KSM + (c >> 2)) * 64 + L::fi(g, r) + 16 * (c & 3)] = th[K::S_W0 + k];
+      lw[own ? K::O_W0A + (m * KSM + (c >> 2)) * 64 + L::fi(g, r) + 16 * (c & 3) : junk] = th[K::S_W0 + k];
     }
   }
 #pragma unroll
   for (int k = 0; k < K::NW2; ++k) {  // W2[o = fi(g, r)][16n + c]
     const int r = k & 3, n = k >> 2, o = L::fi(g, r);
-    if (o < a.dK) {
-      if (sizeof(T) == 8 && !(KSM == 4 && a.dK > 4)) {
-        // f64, at most four outputs: the logits are a 4x4x4 product (mfma44): row o of W2 in every block of four lanes
+    const bool own = o < a.dK;
+    if (sizeof(T) == 8 && !(KSM == 4 && a.dK > 4)) {
+      // f64, at most four outputs: the logits are a 4x4x4 product (mfma44): row o of W2 in every block of four lanes
 #pragma unroll
-        for (int b4 = 0; b4 < 4; ++b4) lw[K::O_W2A + (n * 4 + rk) * 64 + 4 * b4 + o + 16 * gk] = th[K::S_W2 + k];
-      } else
-      lw[K::O_W2A + (n * 4 + rk) * 64 + o + 16 * gk] = th[K::S_W2 + k];  // logits: A lane (o, gk), k-step (n, rk)
-      if (KSM == 4 && a.dK > 4)  // dH1 over four k-steps: k-step s, k-slot g' <-> output fi(g', s), which is (r, g) here
-        lw[K::O_W2T + (n * 4 + r) * 64 + c + 16 * g] = th[K::S_W2 + k];
-      else
-        lw[K::O_W2T + n * 64 + c + 16 * o] = th[K::S_W2 + k];            // dH1: A lane (f & 15, k-slot o)
+      for (int b4 = 0; b4 < 4; ++b4) lw[own ? K::O_W2A + (n * 4 + rk) * 64 + 4 * b4 + o + 16 * gk : junk] = th[K::S_W2 + k];
+    } else {
+      lw[own ? K::O_W2A + (n * 4 + rk) * 64 + o + 16 * gk : junk] = th[K::S_W2 + k];  // logits: A lane (o, gk), k-step (n, rk)
     }
+    if (KSM == 4 && a.dK > 4)  // dH1 over four k-steps: k-step s, k-slot g' <-> output fi(g', s), which is (r, g) here
+      lw[own ? K::O_W2T + (n * 4 + r) * 64 + c + 16 * g : junk] = th[K::S_W2 + k];
+    else
+      lw[own ? K::O_W2T + n * 64 + c + 16 * o : junk] = th[K::S_W2 + k];            // dH1: A lane (f & 15, k-slot o)
   }
-  if (g == 0) {  // bias images in the order a vector read at 4g hands out the features fi(g, 0..3)
+  {  // bias images in the order a vector read at 4g hands out the features fi(g, 0..3): lane group 0 writes them
+    const bool own = g == 0;
 #pragma unroll
     for (int m = 0; m < K::MT; ++m) {
-      lw[K::O_B1 + 16 * m + pc] = th[K::S_B1 + m];
-      lw[K::O_B0 + 16 * m + pc] = th[K::S_B0 + m];
+      lw[own ? K::O_B1 + 16 * m + pc : junk] = th[K::S_B1 + m];
+      lw[own ? K::O_B0 + 16 * m + pc : junk] = th[K::S_B0 + m];
     }
   }
   f16_fence();
@@ -661,11 +669,12 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
         for (int r = 0; r < 4; ++r) dW2[n] = mfma16s<T>(d2u[r], h1u[r], dW2[n]);
       }
     } else {
-    if (g == 0) {
+    {  // (lane group 0 holds the row's delta2: the others add zeros and store to their junk slots -- no per-lane branch)
+      const bool own = g == 0;
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
-        db2[o] += d2[o];
-        lw[K::O_D2 + o * 16 + pc] = d2[o];
+        db2[o] += own ? d2[o] : T(0);
+        lw[own ? K::O_D2 + o * 16 + pc : K::O_JUNK + lane] = d2[o];
       }
     }
     f16_fence();
@@ -786,32 +795,25 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
     const T mu0 = a.mu0, iv0 = a.iv0;
     F16_EACH(k) {
       const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-      if (s.valid) {
-        const T d = th[k] - mu0;
-        if (s.counts) qsum += d * d * iv0;
-        if (GRAD) {
-          T gn = gr[k] - d * iv0;
-          if (has_temp) gn *= temp;
-          gr[k] = gn;
-        }
-      } else if (GRAD) {
-        gr[k] = T(0);
+      const T d = th[k] - mu0;
+      qsum += s.counts ? d * d * iv0 : T(0);
+      if (GRAD) {
+        T gn = gr[k] - d * iv0;
+        if (has_temp) gn *= temp;
+        gr[k] = s.valid ? gn : T(0);
       }
     }
   } else {
-    F16_EACH(k) {
+    F16_EACH(k) {  // (a slot that holds nothing reads element 0 and drops it: no load behind a per-lane branch)
       const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-      if (s.valid) {
-        const T d = th[k] - a.mu[s.idx];
-        const T iv = a.inv_var[s.idx];
-        if (s.counts) qsum += d * d * iv;
-        if (GRAD) {
-          T gn = gr[k] - d * iv;
-          if (has_temp) gn *= temp;
-          gr[k] = gn;
-        }
-      } else if (GRAD) {
-        gr[k] = T(0);
+      const int si = s.valid ? s.idx : 0;
+      const T d = th[k] - a.mu[si];
+      const T iv = a.inv_var[si];
+      qsum += s.counts ? d * d * iv : T(0);
+      if (GRAD) {
+        T gn = gr[k] - d * iv;
+        if (has_temp) gn *= temp;
+        gr[k] = s.valid ? gn : T(0);
       }
     }
   }
@@ -849,7 +851,8 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   T th[K::NREG], gr[K::NREG];
   F16_EACH(k) {
     const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-    th[k] = s.valid ? thg[s.idx] : T(0);
+    const T v = thg[s.valid ? s.idx : 0];
+    th[k] = s.valid ? v : T(0);
     gr[k] = T(0);
   }
 
@@ -901,19 +904,20 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     T qf = T(0);
     F16_EACH(k) {
       const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-      p[k] = T(0);
+      const int si = s.valid ? s.idx : 0;
       gp[k] = T(0);
-      if (s.valid) {
-        const T zi = st[s.idx];
-        if (mode == F16_MALA) {
-          gr[k] = grg[s.idx];
-          const T loc = th[k] + T(0.5) * eps * gr[k];  // kernel_mean, mala.py:35-36
-          p[k] = loc + sc * zi;
-          const T d = p[k] - loc;
-          if (s.counts) qf += d * d;
-        } else {
-          p[k] = th[k] + a.scale[s.idx] * zi;  // NormalKernel(theta, scale).sample()
-        }
+      const T zi = st[si];
+      if (mode == F16_MALA) {
+        const T gk = grg[si];
+        gr[k] = s.valid ? gk : gr[k];
+        const T loc = th[k] + T(0.5) * eps * gk;  // kernel_mean, mala.py:35-36
+        const T pk = loc + sc * zi;
+        const T d = pk - loc;
+        p[k] = s.valid ? pk : T(0);
+        qf += s.counts ? d * d : T(0);
+      } else {
+        const T pk = th[k] + a.scale[si] * zi;  // NormalKernel(theta, scale).sample()
+        p[k] = s.valid ? pk : T(0);
       }
     }
     f16_fence();  // the staged normals have been read; the evaluation reuses that LDS
@@ -925,10 +929,8 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
       T qb = T(0);
       F16_EACH(k) {
         const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-        if (s.counts) {
-          const T d = th[k] - (p[k] + T(0.5) * eps * gp[k]);
-          qb += d * d;
-        }
+        const T d = th[k] - (p[k] + T(0.5) * eps * gp[k]);
+        qb += s.counts ? d * d : T(0);
       }
       const T inv2v = T(1) / (T(2) * sc * sc);
       log_rate += (f16_wsum(qf) - f16_wsum(qb)) * inv2v;  // the -P log s - P/2 log 2pi terms cancel (mala.py:58-64)
@@ -964,9 +966,11 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   if (mode == F16_HMC) {
     F16_EACH(k) {
       const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-      p[k] = s.valid ? st[s.idx] : T(0);   // hmc.py:134
-      if (s.counts) kin += p[k] * p[k];
-      if (s.valid && !a.recompute) gr[k] = grg[s.idx];
+      const int si = s.valid ? s.idx : 0;
+      const T zv = st[si], gv = grg[si];
+      p[k] = s.valid ? zv : T(0);   // hmc.py:134
+      kin += s.counts ? p[k] * p[k] : T(0);
+      gr[k] = (s.valid && !a.recompute) ? gv : gr[k];
     }
     f16_fence();  // the staged normals have been read; the evaluations reuse that LDS
     kin = f16_wsum(kin);
@@ -975,7 +979,8 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     const T* pin = a.pio + chain * P;
     F16_EACH(k) {
       const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-      p[k] = s.valid ? pin[s.idx] : T(0);
+      const T pv = pin[s.valid ? s.idx : 0];
+      p[k] = s.valid ? pv : T(0);
     }
   }
   const T h_cur = -t_cur + T(0.5) * kin;  // hmc.py:91-98,137
@@ -1016,7 +1021,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   kin = T(0);
   F16_EACH(k) {
     const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-    if (s.counts) kin += p[k] * p[k];
+    kin += s.counts ? p[k] * p[k] : T(0);
   }
   kin = f16_wsum(kin);
   const T h_prop = -t + T(0.5) * kin;
@@ -1191,15 +1196,12 @@ static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   }
 }
 
-// EY_F16_W16: waves per CU of the f32 H = 16 instantiations.  16 (four per SIMD, 128 registers) is 13 - 16 % faster on the small
-// shapes (MLP(4-16-16-3) 34.4 -> 39.0 TFLOP/s, same bits in HMC) and is NOT shipped: at that register budget the padded
-// instantiation's MALA log-rate comes out wrong (MLP(4-10-7-3): the position's registers do not survive the evaluation --
-// value, gradient, proposal and every other mode are right; re-reading theta from memory behind the evaluation repairs it).
-// Not a timing hazard (no s_nop padding of any instruction class repairs it, tools/f16_asm_bisect.py) and not the DPP
-// reductions; -O1, twelve waves, and most flags that perturb the pre-RA scheduler or the allocator repair it
-// (profiles/r04_f16_w16_flags.txt).  Unresolved, taken to be the compiler's spilling at 128 registers; DESIGN.md 4.4.
+// EY_F16_W16: waves per CU of the f32 H = 16 instantiations: sixteen (four per SIMD, 128 registers) are 13 - 16 % faster
+// than eight on the small shapes (MLP(4-16-16-3) 34.4 -> 39.0 TFLOP/s, same bits).  At that register budget the kernel
+// spills, and that is what exposed the family's per-lane branches (see O_JUNK): until they were removed the padded
+// instantiation's MALA log-rate came out wrong there (profiles/r04_f16_w16_flags.txt).
 #ifndef EY_F16_W16
-#define EY_F16_W16 8
+#define EY_F16_W16 16
 #endif
 template <typename T>
 static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {

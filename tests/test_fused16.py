@@ -427,3 +427,4 @@ def test_fused16_built_at_O1_passes_the_oracle_suite():
                            env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert suite.returncode == 0, suite.stdout[-3000:]
     assert " passed" in suite.stdout and "failed" not in suite.stdout
+
