@@ -68,3 +68,7 @@ def test_bench_contract_small_run():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 100 * cb["value"]
+    # the ESS gather runs on the driver-sized run too, and the secondary figure (config 5's share of one GPU) is beside the metric
+    assert d["config"]["ess"]["num_chains"] == 512 and d["config"]["ess"]["mean"] > 0
+    sec = d["config"]["secondary"]["config5_share_one_gpu"]
+    assert "error" not in sec and sec["kernel"] == "bgemm" and 0.2 < sec["frac_of_f32_mfma_peak"] < 1.5 and 0 <= sec["acceptance"] <= 1
