@@ -73,7 +73,7 @@ def build(force=False, verbose=False):
 
 
 O1_LIB_PATH = os.path.join(HERE, "lib", "libeeyore_amd_f16o1.so")
-SPILL_LIB_PATH = os.path.join(HERE, "lib", "libeeyore_amd_f16spill.so")  # `make spill`: a diagnostic build
+SPILL_LIB_DIR = os.path.join(HERE, "lib")  # `make spill`: diagnostic builds libeeyore_amd_spill_<unit>.so
 
 
 _lib = None

@@ -79,6 +79,19 @@ struct F16Args {
 // F16_ABLATE (diagnostic builds only, tools/ablate_fused16.sh): 1 = no transcendental in the activations, 2 = the
 // skinny products (logits, dH1, dW2, dW0) replaced by one add each, 4 = no global loads of the data tile, 8 = no
 // transpose stores.  Results are wrong in such a build; only its timing is read.
+// EY_F16_PART: the family is built as two translation units.  0 (this file as it stands) = the host side and every
+// instantiation except k_fused16<double, 32, 4, *>; 1 (ey_fused16_d32.hip, which includes this file) = those four and their
+// launcher only.  The split exists for one compiler flag: at one wave per SIMD (512 registers) the compiler selects the
+// MFMAs in their AGPR form and then keeps the loop-carried accumulators in architectural registers all the same, copying
+// them in and out around every product (a third of the vector instructions of the f64 tile loop); -mllvm
+// -amdgpu-mfma-vgpr-form on that unit removes the copies (+7 % on the f64 headline model, same bits), and cannot be given
+// to the whole file because the same compiler crashes with it on k_fused16<float, 64, 4, 2>.
+#ifndef EY_F16_PART
+#define EY_F16_PART 0
+#endif
+#ifndef EY_F16_TANH_EM1
+#define EY_F16_TANH_EM1 1  // the f64 tanh on expm1 (0: round 3's form, kept for A/B)
+#endif
 #ifndef F16_ABLATE
 #define F16_ABLATE 0
 #endif
@@ -193,6 +206,41 @@ template <typename T>
 __device__ __forceinline__ T f16_tanh(T g) {
   if constexpr (sizeof(T) == 4) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * g)) - 1.0f;
   else {
+#if EY_F16_TANH_EM1
+    // tanh |g| = -m / (2 + m) with m = expm1(-2 |g|), so that nothing cancels near 0: exp(t) = 2^n (1 + r q(r)) with
+    // n = rint(t log2 e), |r| <= 0.3466 and q the Taylor polynomial of (e^r - 1) / r to r^12 (remainder 4e-18); for n = 0
+    // (|g| < 0.173) m = r q exactly as computed, otherwise m = 2^n (1 + r q) - 1 with 2^n <= 1/2.  2 + m lies in (1, 2], so
+    // the reciprocal is v_rcp_f64 and two Newton steps without a range guard.  36 instructions per element (the form it
+    // replaces -- the exp, 2 / (1 + e) - 1, and a separate odd polynomial below |g| = 0.125 -- took 48), at most 3 ulp from
+    // the library's tanh over [-45, 45] and down to 2^-60 (checked on the host with the same fma sequence); a NaN stays a
+    // NaN (the clamp is a compare-and-select, which keeps it; v_max would return the bound), +-inf give +-1.
+    T t = T(-2) * __builtin_fabs(g);
+    t = t < T(-80) ? T(-80) : t;  // exp(-80) = 1.8e-35: tanh is 1 to the last bit long before
+    const T n = __builtin_rint(t * T(1.4426950408889634));
+    T r = __builtin_fma(-n, T(6.93147180369123816490e-01), t);
+    r = __builtin_fma(-n, T(1.90821492927058770002e-10), r);
+    T q = T(1.0 / 6227020800.0);
+    q = __builtin_fma(q, r, T(1.0 / 479001600.0));
+    q = __builtin_fma(q, r, T(1.0 / 39916800.0));
+    q = __builtin_fma(q, r, T(1.0 / 3628800.0));
+    q = __builtin_fma(q, r, T(1.0 / 362880.0));
+    q = __builtin_fma(q, r, T(1.0 / 40320.0));
+    q = __builtin_fma(q, r, T(1.0 / 5040.0));
+    q = __builtin_fma(q, r, T(1.0 / 720.0));
+    q = __builtin_fma(q, r, T(1.0 / 120.0));
+    q = __builtin_fma(q, r, T(1.0 / 24.0));
+    q = __builtin_fma(q, r, T(1.0 / 6.0));
+    q = __builtin_fma(q, r, T(0.5));
+    q = __builtin_fma(q, r, T(1.0));
+    const T rq = r * q;
+    const T e = __builtin_amdgcn_ldexp(__builtin_fma(r, q, T(1)), (int)n);
+    const T m = n == T(0) ? rq : e - T(1);
+    const T d = T(2) + m;
+    T y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(y, __builtin_fma(-d, y, T(1)), y);
+    y = __builtin_fma(y, __builtin_fma(-d, y, T(1)), y);
+    return __builtin_copysign(-m * y, g);
+#else
     // tanh |g| = 2 / (1 + exp(-2 |g|)) - 1 on the 19-instruction exp (the library's tanh is 139 f64 instructions per
     // element); below |g| = 0.125, where that form cancels, the odd Taylor polynomial to g^15 (remainder 2e-18 relative)
     const T big = T(2) * f16_recip_ge1<false>(T(1) + Nm<T>::exp_fast(-T(2) * __builtin_fabs(g))) - T(1);
@@ -206,6 +254,7 @@ __device__ __forceinline__ T f16_tanh(T g) {
     p = __builtin_fma(p, g2, T(-1.0 / 3.0));
     const T small = __builtin_fma(p * g2, g, g);
     return __builtin_fabs(g) < T(0.125) ? small : __builtin_copysign(big, g);
+#endif
   }
 }
 template <typename T>
@@ -1085,6 +1134,7 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4) k_fused16(F16Args
     }
 }
 
+#if EY_F16_PART == 0
 // ----------------------------------------------------------------------------------------------- host side
 // Operand-order data image, per 16-row tile: [ks0][64] x as the B operand of F0 (lane (row, in & 3), k-step in >> 2),
 // [4][64] x as the B operand of dW0 (lane (in, row >> 2), step row & 3), [64] labels (-1 = padding row), [4][16] y.
@@ -1161,6 +1211,8 @@ int ey_fused16_set_data(ey_plan* pl, hipStream_t s) {
   return EY_OK;
 }
 
+#endif  // EY_F16_PART == 0
+
 template <typename T, int H, int WAVES, int V>
 static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
 #ifdef F16_ONLY_H  // diagnostic builds (tools/f16_bisect.sh): one instantiation only, the others refuse
@@ -1196,6 +1248,12 @@ static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   }
 }
 
+// the four k_fused16<double, 32, 4, *> live in ey_fused16_d32.hip (EY_F16_PART above)
+int ey_f16_launch_d32(F16Args<double>& a, int n_cu, hipStream_t s);
+#if EY_F16_PART == 1
+int ey_f16_launch_d32(F16Args<double>& a, int n_cu, hipStream_t s) { return f16_launch_w<double, 32, 4>(a, n_cu, s); }
+#else
+
 // EY_F16_W16: waves per CU of the f32 H = 16 instantiations: sixteen (four per SIMD, 128 registers) are 13 - 16 % faster
 // than eight on the small shapes (MLP(4-16-16-3) 34.4 -> 39.0 TFLOP/s, same bits).  At that register budget the kernel
 // spills, and that is what exposed the family's per-lane branches (see O_JUNK): until they were removed the padded
@@ -1230,7 +1288,7 @@ static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
     return f16_launch_w<float, 64, 4>(a, pl->n_cu, s);
   } else {
     if (H <= 16) return f16_launch_w<double, 16, 8>(a, pl->n_cu, s);
-    return f16_launch_w<double, 32, 4>(a, pl->n_cu, s);
+    return ey_f16_launch_d32(a, pl->n_cu, s);
   }
 }
 
@@ -1340,3 +1398,4 @@ int ey_fused16_leapfrog(ey_plan* pl, void* theta, void* p, double step, const vo
   if (pl->dtype == EY_F32) return f16_leapfrog_t<float>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
   return f16_leapfrog_t<double>(pl, theta, p, step, step_vec, L, temp, C, target, grad, s);
 }
+#endif  // EY_F16_PART == 0

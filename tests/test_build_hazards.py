@@ -99,14 +99,15 @@ def test_the_assembly_the_library_was_built_from_has_no_such_load_left():
     files = sorted(f for f in (os.listdir(obj) if os.path.isdir(obj) else []) if f.endswith(".fixed.s"))
     if not files:
         pytest.skip("library not built in this tree yet (python -c 'import __graft_entry__ as g; g.build()')")
-    assert {"ey_fused16.fixed.s", "ey_large.fixed.s", "ey_mfma32.fixed.s"} <= set(files)
+    assert {"ey_fused16.fixed.s", "ey_fused16_d32.fixed.s", "ey_large.fixed.s", "ey_mfma32.fixed.s"} <= set(files)
     for f in files:
         _, _, found = hz.find(open(os.path.join(obj, f)).read().split("\n"))
         assert found == [], (f, found[:3])
     # the pass had work to do on the f64 kernels of the fused16 family (if a later compiler stops producing the pattern
     # this number goes to zero and the pass is idle, which is fine -- reported, not asserted)
-    _, _, before = hz.find(open(os.path.join(obj, "ey_fused16.dev.s")).read().split("\n"))
-    print(f"ey_fused16: {len(before)} load(s) padded by the build")
+    for unit in ("ey_fused16", "ey_fused16_d32"):
+        _, _, before = hz.find(open(os.path.join(obj, unit + ".dev.s")).read().split("\n"))
+        print(f"{unit}: {len(before)} load(s) padded by the build")
 
 
 def test_the_o1_reproducer_shows_the_pattern_before_the_pass_and_none_after(tmp_path):
@@ -116,7 +117,7 @@ def test_the_o1_reproducer_shows_the_pattern_before_the_pass_and_none_after(tmp_
         pytest.skip("no hipcc")
     dev = tmp_path / "dev.s"
     cmd = ["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-w",
-           "-DF16_ONLY_SIZE=8", "-DF16_ONLY_H=32", "-DF16_ONLY_V=3", "-DF16_ONLY_MODE=1", "--offload-device-only", "-S",
+           "-DF16_ONLY_SIZE=8", "-DF16_ONLY_H=32", "-DF16_ONLY_V=3", "-DF16_ONLY_MODE=1", "-DEY_F16_PART=1", "--offload-device-only", "-S",
            os.path.join(CSRC, "ey_fused16.hip"), "-o", str(dev)]
     subprocess.check_call(cmd)
     lines = dev.read_text().split("\n")
