@@ -89,6 +89,9 @@ struct F16Args {
 #ifndef EY_F16_PART
 #define EY_F16_PART 0
 #endif
+#ifndef EY_F16_HMC_OWN
+#define EY_F16_HMC_OWN 1  // (see f16_launch_t)
+#endif
 #ifndef EY_F16_TANH_EM1
 #define EY_F16_TANH_EM1 1  // the f64 tanh on expm1 (0: round 3's form, kept for A/B)
 #endif
@@ -878,7 +881,7 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
 }
 
 // One chain of one launch: everything between reading theta and writing the accepted state back.
-template <typename T, int H, int V, typename A>
+template <typename T, int H, int V, int MODE, typename A>
 __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t chain, const int it, const int c,
                                               const int g, const int lane) {
   typedef F16Cfg<H, (V & 2) ? 4 : 2> K;
@@ -894,7 +897,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
 #ifdef F16_ONLY_MODE  // diagnostic builds: one mode compiled in (a kernel a fifth of the size)
   const int mode = F16_ONLY_MODE;
 #else
-  const int mode = a.mode;
+  const int mode = MODE >= 0 ? MODE : a.mode;  // MODE: the mode compiled in (EY_F16_HMC_OWN below), -1 = the argument's
 #endif
 
   T th[K::NREG], gr[K::NREG];
@@ -1108,7 +1111,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
 
 // Persistent launch: one WAVES-wave workgroup per CU, every wave walks over chains blockIdx + gridDim * wave, ... and
 // takes each through all iterations of the launch (chain-major, as ey_mfma32.hip).
-template <typename T, int H, int WAVES, int V>
+template <typename T, int H, int WAVES, int V, int MODE = -1>
 __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4) k_fused16(F16Args<T> a) {
   typedef F16Cfg<H, (V & 2) ? 4 : 2> K;
   extern __shared__ __attribute__((aligned(32))) unsigned char smem_raw[];
@@ -1130,7 +1133,7 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES + 3) / 4) k_fused16(F16Args
       // all stay live in scalar registers for the whole kernel and spill into vector registers
       KA* ap = (KA*)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ap));
-      f16_run_chain<T, H, V>(*ap, lw, chain, it, c, g, lane);
+      f16_run_chain<T, H, V, MODE>(*ap, lw, chain, it, c, g, lane);
     }
 }
 
@@ -1223,9 +1226,19 @@ static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
 #endif
   {
   const size_t bytes = sizeof(T) * (size_t)WAVES * F16Cfg<H, (V & 2) ? 4 : 2>::WAVE_ELEMS;
+  const unsigned grid = (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256);
+  // the HMC draw of the one-wave-per-SIMD kernels as an instantiation of its own: with the other modes' code and live
+  // ranges out of the way the kernel spills a third less (scratch 1804 -> 1252 bytes per lane on the f64 headline model's
+  // instantiation, +3.7 %, same bits)
+  if constexpr (EY_F16_HMC_OWN && WAVES == 4) if (a.mode == F16_HMC) {
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, V, F16_HMC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL((k_fused16<T, H, WAVES, V, F16_HMC>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+    EY_HIP(hipGetLastError());
+    return EY_OK;
+  }
   EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, V>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  const unsigned grid = (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256);
   hipLaunchKernelGGL((k_fused16<T, H, WAVES, V>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
   EY_HIP(hipGetLastError());
   return EY_OK;

@@ -7,11 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eeyore_amd.datasets import synthetic
 from eeyore_amd.plan import Plan
 dev = torch.device('cuda', 0)
-dims = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [4, 32, 32, 3]
-tdt = torch.float64
+dims = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4, 32, 32, 3]
+tdt = torch.float32 if len(sys.argv) > 2 and sys.argv[2] == "f32" else torch.float64
 xs, ys = synthetic.iris_shaped_arrays(seed=0)
 pl = Plan(dims, [1] * (len(dims) - 1), [1] * (len(dims) - 2) + [0], 1, tdt, dev)
 pl.set_data(torch.tensor(xs, dtype=tdt, device=dev), torch.tensor(ys, dtype=tdt, device=dev))
+if tdt == torch.float32: pl.f32_products = "exact"
 pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), float(np.sqrt(3.0))))
 C = 4096
 th = 0.1 * pl.philox_normal(C, seed=0, it=0)
@@ -26,5 +27,5 @@ for rep in range(3):
     best = max(best, C * 20 * 20 / (time.perf_counter() - t0))
 prods = [dims[i] * dims[i + 1] for i in range(len(dims) - 1)]
 fl = 2 * 150 * (2 * sum(prods) + sum(prods[1:])) + 6 * pl.P
-print(f"{os.environ.get('EEYORE_AMD_LIB', 'shipped'):40s} MLP({'-'.join(map(str, dims))}) f64 kernel {pl.kernel}: {best:.3e} leapfrog-steps/s x chains = "
+print(f"{os.environ.get('EEYORE_AMD_LIB', 'shipped'):40s} MLP({'-'.join(map(str, dims))}) {str(tdt)[6:]} kernel {pl.kernel}: {best:.3e} leapfrog-steps/s x chains = "
       f"{fl * best / 1e12:.2f} TFLOP/s; checksum theta {th.double().sum().item():.15e} target {t.double().sum().item():.15e}")
