@@ -80,17 +80,19 @@ struct F16Args {
 // skinny products (logits, dH1, dW2, dW0) replaced by one add each, 4 = no global loads of the data tile, 8 = no
 // transpose stores.  Results are wrong in such a build; only its timing is read.
 // EY_F16_PART: the family is built as two translation units.  0 (this file as it stands) = the host side and every
-// instantiation except k_fused16<double, 32, 4, *>; 1 (ey_fused16_d32.hip, which includes this file) = those four and their
-// launcher only.  The split exists for one compiler flag: at one wave per SIMD (512 registers) the compiler selects the
+// instantiation except the one-wave-per-SIMD ones named next; 1 (ey_fused16_d32.hip, which includes this file) =
+// k_fused16<double, 32, 4, *> and the HMC kernels of the f32 H = 64 shapes, k_fused16<float, 64, 4, 2 | 3, F16_HMC>, with
+// their launchers only.  The split exists for one compiler flag: at one wave per SIMD (512 registers) the compiler selects the
 // MFMAs in their AGPR form and then keeps the loop-carried accumulators in architectural registers all the same, copying
 // them in and out around every product (a third of the vector instructions of the f64 tile loop); -mllvm
 // -amdgpu-mfma-vgpr-form on that unit removes the copies (+7 % on the f64 headline model, same bits), and cannot be given
-// to the whole file because the same compiler crashes with it on k_fused16<float, 64, 4, 2>.
+// to the whole file because the same compiler crashes with it on k_fused16<float, 64, 4, 2> with the mode a run-time
+// argument.
 #ifndef EY_F16_PART
 #define EY_F16_PART 0
 #endif
 #ifndef EY_F16_HMC_OWN
-#define EY_F16_HMC_OWN 1  // (see f16_launch_t)
+#define EY_F16_HMC_OWN 4  // the instantiations of up to this many waves per CU get an HMC kernel of their own (f16_launch_t)
 #endif
 #ifndef EY_F16_TANH_EM1
 #define EY_F16_TANH_EM1 1  // the f64 tanh on expm1 (0: round 3's form, kept for A/B)
@@ -1216,6 +1218,18 @@ int ey_fused16_set_data(ey_plan* pl, hipStream_t s) {
 
 #endif  // EY_F16_PART == 0
 
+template <typename T, int H, int WAVES, int V, int MODE>
+static int f16_launch_kernel(F16Args<T>& a, unsigned grid, size_t bytes, hipStream_t s) {
+  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, V, MODE>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL((k_fused16<T, H, WAVES, V, MODE>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+// (defined in ey_fused16_d32.hip, EY_F16_PART)
+int ey_f16_launch_d32(F16Args<double>& a, int n_cu, hipStream_t s);
+int ey_f16_launch_f32h64_hmc(F16Args<float>& a, int v, unsigned grid, size_t bytes, hipStream_t s);
+
 template <typename T, int H, int WAVES, int V>
 static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
 #ifdef F16_ONLY_H  // diagnostic builds (tools/f16_bisect.sh): one instantiation only, the others refuse
@@ -1229,19 +1243,15 @@ static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
   const unsigned grid = (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256);
   // the HMC draw of the one-wave-per-SIMD kernels as an instantiation of its own: with the other modes' code and live
   // ranges out of the way the kernel spills a third less (scratch 1804 -> 1252 bytes per lane on the f64 headline model's
-  // instantiation, +3.7 %, same bits)
-  if constexpr (EY_F16_HMC_OWN && WAVES == 4) if (a.mode == F16_HMC) {
-    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, V, F16_HMC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((k_fused16<T, H, WAVES, V, F16_HMC>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
-    EY_HIP(hipGetLastError());
-    return EY_OK;
+  // instantiation, +3.7 %, same bits).  Those of the f32 H = 64 shapes live in ey_fused16_d32.hip as well (EY_F16_PART).
+  if constexpr (WAVES <= EY_F16_HMC_OWN) if (a.mode == F16_HMC) {
+#if EY_F16_PART == 0
+    if constexpr (sizeof(T) == 4 && H == 64 && WAVES == 4) return ey_f16_launch_f32h64_hmc(a, V, grid, bytes, s);
+    else
+#endif
+    return f16_launch_kernel<T, H, WAVES, V, F16_HMC>(a, grid, bytes, s);
   }
-  EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused16<T, H, WAVES, V>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  hipLaunchKernelGGL((k_fused16<T, H, WAVES, V>), dim3(grid), dim3(WAVES * 64), bytes, s, a);
-  EY_HIP(hipGetLastError());
-  return EY_OK;
+  return f16_launch_kernel<T, H, WAVES, V, -1>(a, grid, bytes, s);
   }
 }
 // The variant V = TWO | 2 PAD is a template parameter: one hidden layer (the middle layer skipped) and hidden widths
@@ -1253,7 +1263,8 @@ static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   // 8.7e6 against 7.3e6 leapfrog-steps/s x chains on MLP(4-64-64-3), same session)
   // (more than 8 inputs: the padded forms' four k-steps; a layer without a bias: its slots are padding slots)
   const bool pad = a.h1 != H || a.h2 != H || H == 64 || a.d0 > 8 || a.iB0 < 0 || a.iB2 < 0 || (!a.two && a.iB1 < 0) || a.dK > 4;
-  switch ((a.two ? 1 : 0) | (pad ? 2 : 0)) {
+  if constexpr (H == 64) return a.two ? f16_launch_t<T, H, WAVES, 3>(a, n_cu, s) : f16_launch_t<T, H, WAVES, 2>(a, n_cu, s);
+  else switch ((a.two ? 1 : 0) | (pad ? 2 : 0)) {
     case 0: return f16_launch_t<T, H, WAVES, 0>(a, n_cu, s);
     case 1: return f16_launch_t<T, H, WAVES, 1>(a, n_cu, s);
     case 2: return f16_launch_t<T, H, WAVES, 2>(a, n_cu, s);
@@ -1261,10 +1272,13 @@ static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   }
 }
 
-// the four k_fused16<double, 32, 4, *> live in ey_fused16_d32.hip (EY_F16_PART above)
-int ey_f16_launch_d32(F16Args<double>& a, int n_cu, hipStream_t s);
 #if EY_F16_PART == 1
 int ey_f16_launch_d32(F16Args<double>& a, int n_cu, hipStream_t s) { return f16_launch_w<double, 32, 4>(a, n_cu, s); }
+int ey_f16_launch_f32h64_hmc(F16Args<float>& a, int v, unsigned grid, size_t bytes, hipStream_t s) {
+  // (H = 64 only ever takes the padded instantiations, f16_launch_w)
+  return v == 3 ? f16_launch_kernel<float, 64, 4, 3, F16_HMC>(a, grid, bytes, s)
+                : f16_launch_kernel<float, 64, 4, 2, F16_HMC>(a, grid, bytes, s);
+}
 #else
 
 // EY_F16_W16: waves per CU of the f32 H = 16 instantiations: sixteen (four per SIMD, 128 registers) are 13 - 16 % faster
