@@ -882,6 +882,13 @@ __device__ __forceinline__ T f16_eval(const A& a, T* lw, const T (&th)[F16Cfg<H>
   return lik + prior;
 }
 
+// Where a lane that holds no counted copy of an element sends its store of the final state (the rule of O_JUNK, for global
+// memory: no store behind a per-lane branch while theta / momentum / gradient are live; every wave's lane l writes the same
+// 8 bytes, nobody reads them).
+static __device__ double g_f16_junk[64];
+template <typename T>
+__device__ __forceinline__ T* f16_junk(int lane) { return reinterpret_cast<T*>(g_f16_junk + lane); }
+
 // One chain of one launch: everything between reading theta and writing the accepted state back.
 template <typename T, int H, int V, int MODE, typename A>
 __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t chain, const int it, const int c,
@@ -917,7 +924,7 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     if (a.grad) {
       F16_EACH(k) {
         const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-        if (s.counts) grg[s.idx] = gr[k];
+        *(s.counts ? grg + s.idx : f16_junk<T>(lane)) = gr[k];
       }
     }
     if (lane == 0) {
@@ -993,15 +1000,14 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     const T u = a.u ? a.u[chain] : ey_rng_uniform<T>(ru);
     const bool acc = Nm<T>::log(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
     T* so = a.rec_samples ? a.rec_samples + ((int64_t)it * a.C + chain) * P : nullptr;
+    const bool acc_u = __builtin_amdgcn_readfirstlane((int)acc) != 0;  // (the same in every lane: a scalar branch)
     F16_EACH(k) {
       const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-      if (s.counts) {
-        if (acc) {
-          thg[s.idx] = p[k];
-          if (mode == F16_MALA) grg[s.idx] = gp[k];
-        }
-        if (so) so[s.idx] = acc ? p[k] : th[k];
+      if (acc_u) {
+        *(s.counts ? thg + s.idx : f16_junk<T>(lane)) = p[k];
+        if (mode == F16_MALA) *(s.counts ? grg + s.idx : f16_junk<T>(lane)) = gp[k];
       }
+      if (so) *(s.counts ? so + s.idx : f16_junk<T>(lane)) = acc ? p[k] : th[k];
     }
     if (lane == 0) {
       if (acc) a.target[chain] = tv;
@@ -1062,11 +1068,9 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
     T* pout = a.pio + chain * P;
     F16_EACH(k) {
       const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-      if (s.counts) {
-        thg[s.idx] = th[k];
-        pout[s.idx] = -p[k];  // hmc.py:122
-        grg[s.idx] = gr[k];
-      }
+      *(s.counts ? thg + s.idx : f16_junk<T>(lane)) = th[k];
+      *(s.counts ? pout + s.idx : f16_junk<T>(lane)) = -p[k];  // hmc.py:122
+      *(s.counts ? grg + s.idx : f16_junk<T>(lane)) = gr[k];
     }
     if (lane == 0) a.target[chain] = t;
     return;
@@ -1085,14 +1089,16 @@ __device__ __forceinline__ void f16_run_chain(const A& a, T* lw, const int64_t c
   const T u = a.u ? a.u[chain] : ey_rng_uniform<T>(ru);
   const bool acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
   T* so = a.rec_samples ? a.rec_samples + ((int64_t)it * a.C + chain) * P : nullptr;
+  const bool acc_u = __builtin_amdgcn_readfirstlane((int)acc) != 0;  // (the same in every lane: a scalar branch)
   F16_EACH(k) {
     const F16Slot s = f16_slot<H, T, V>(k, a, c, g, lane);
-    if (s.counts) {
-      if (so) so[s.idx] = acc ? th[k] : thg[s.idx];  // the state this chain is left in (chain_list.py:64-67)
-      if (acc) {
-        thg[s.idx] = th[k];
-        grg[s.idx] = gr[k];
-      }
+    if (so) {  // the state this chain is left in (chain_list.py:64-67)
+      const T cur = thg[s.counts ? s.idx : 0];
+      *(s.counts ? so + s.idx : f16_junk<T>(lane)) = acc ? th[k] : cur;
+    }
+    if (acc_u) {
+      *(s.counts ? thg + s.idx : f16_junk<T>(lane)) = th[k];
+      *(s.counts ? grg + s.idx : f16_junk<T>(lane)) = gr[k];
     }
   }
   if (lane == 0) {

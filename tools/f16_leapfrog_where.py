@@ -26,10 +26,17 @@ for c in range(C):
     to, go, _, _ = co.log_target_grad(th0[c].astype(np.float64))
     bad = np.nonzero(np.abs(g[c].cpu().numpy() - go) > 2e-2 * max(1, np.abs(go).max()))[0]
     print(f"gradient chain {c}: target err {abs(t[c].item() - to):.2e}, wrong indices {bad.tolist()[:24]}")
-th, p = t_(th0).clone(), t_(p0).clone()
-pl.leapfrog(th, p, 0.02, 4)
-for c in range(C):
-    tho, po_, to_, go_ = co.leapfrog(th0[c].astype(np.float64), p0[c].astype(np.float64), 0.02, 4)
-    bad = np.nonzero(np.abs(th[c].cpu().numpy() - tho) > 2e-3)[0]
-    print(f"leapfrog chain {c}: wrong theta indices {bad.tolist()[:24]}")
+for Ls in (1, 4):
+    th, p = t_(th0).clone(), t_(p0).clone()
+    tl, gl = pl.leapfrog(th, p, 0.02, Ls)
+    for c in range(C):
+        tho, po_, to_, go_ = co.leapfrog(th0[c].astype(np.float64), p0[c].astype(np.float64), 0.02, Ls)
+        bad = np.nonzero(np.abs(th[c].cpu().numpy() - tho) > 2e-3)[0]
+        badp = np.nonzero(np.abs(p[c].cpu().numpy() - po_) > 2e-2)[0]
+        badg = np.nonzero(np.abs(gl[c].cpu().numpy() - go_) > 2e-2 * max(1, np.abs(go_).max()))[0]
+        if len(badp) and c < 2:
+            i = badp[0]
+            print(f"   index {i}: theta0 {th0[c, i]:.6f} -> {th[c, i].item():.6f} (oracle {tho[i]:.6f}); momentum {p0[c, i]:.6f} -> {p[c, i].item():.6f} "
+                  f"(oracle {po_[i]:.6f}); gradient at the start {g[c, i].item():.6f}, at the end {gl[c, i].item():.6f} (oracle {go_[i]:.6f})")
+        print(f"leapfrog L={Ls} chain {c}: wrong theta {bad.tolist()[:12]} momentum {badp.tolist()[:12]} end gradient {badg.tolist()[:12]} target err {abs(tl[c].item() - to_):.2e}")
 print("layout:", " ".join(f"W{l}[{sum((dims[j]+1)*dims[j+1] for j in range(l))}..) b{l}[{sum((dims[j]+1)*dims[j+1] for j in range(l)) + dims[l]*dims[l+1]}..)" for l in range(len(dims)-1)))
