@@ -384,7 +384,7 @@ __device__ __forceinline__ void for_each2(Vec<DKV>& a, Vec<DKV>& b, F f) {
 // scratch (profiles/r04_ab_lds_early.txt): not taken for this kernel, whose shipped build spills outside those regions and
 // is pinned by the golden traces; the switch is here for the day its allocation changes.
 #ifndef EY_MF_NOBRANCH
-#define EY_MF_NOBRANCH 0
+#define EY_MF_NOBRANCH 2
 #endif
 // stage the operand images of theta in this wave's LDS region
 struct W1Lo { u32x4 v[2]; };  // BF3 = 2: the low pieces of W1's row c (the A operand of F1), kept in registers
@@ -393,7 +393,19 @@ __device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, i
   constexpr float SC = ActScale<SH::ACT>::value;
 #pragma unroll
   for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = SC * th.w1[r];
-  if constexpr (EY_MF_NOBRANCH && BF3 == 2) {
+  if constexpr (EY_MF_NOBRANCH == 2) {
+    // (no store behind a per-lane branch, and no store for nothing: the two halves of the wave hold the same small vectors,
+    // so each half stores half of their images -- W0's rows i = 0, 1 | 2, 3; W2's image | its transpose; b1 | b0)
+    const bool up = h != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      lw[O_W0IMG + (4 * (c >> 2) + j + 2 * h) * 5 + (c & 3)] = SC * (up ? th.w0[j + 2] : th.w0[j]);
+    const int w2base = up ? O_W2TIMG + c * 4 : O_W2IMG + c, w2step = up ? 1 : TS36;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)  // outputs beyond DK are zero rows / columns of the two images
+      lw[w2base + o * w2step] = o < SH::DK ? th.w2[o < SH::DK ? o : 0] : 0.0f;
+    lw[(up ? O_B0IMG : O_B1IMG) + c] = SC * (up ? th.b0 : th.b1);
+  } else if constexpr (EY_MF_NOBRANCH && BF3 == 2) {
     // (no store behind a per-lane branch: the upper half writes the same values to a junk slot -- the tail of the first
     // transpose buffer, which holds nothing between evaluations -- so that no vector register can be spilled and reloaded
     // under a partial EXEC mask)
@@ -462,6 +474,7 @@ __device__ __forceinline__ void store_T(float* tb, const f32x16& v, int c, int h
 // LDS latency is never waited for.
 struct Pace {
   int* prog;    // [waves] tiles left (+ bias), per wave of this workgroup
+  int* junk;    // a word nobody reads any more (this wave's SIMD id slot, dead once the partners are found)
   int wave, partner;
   int left;
   int bias;     // added to what this wave publishes and compares: the wave then runs `bias` tiles ahead of its partner
@@ -471,7 +484,8 @@ struct Pace {
 __device__ __forceinline__ int pace_post(Pace& pc, int lane) {
   if (!pc.on) return 0;
   pc.left = __builtin_amdgcn_readfirstlane(pc.left - 1);
-  if (lane == 0) __hip_atomic_store(&pc.prog[pc.wave], pc.left + pc.bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (lane 0 publishes; the other lanes store into this wave's junk word: no store behind a per-lane branch)
+  __hip_atomic_store(lane == 0 ? &pc.prog[pc.wave] : pc.junk, pc.left + pc.bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return __hip_atomic_load(&pc.prog[pc.partner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // EY_PHASE_PRIO (diagnostic builds, default off): priority by phase, see chain_enter below
@@ -713,7 +727,19 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       if (!GRAD) return;
       d2[0] = valid ? (yy / pr - (1.0f - yy) / (1.0f - pr)) * (pr * (1.0f - pr)) : 0.0f;
     }
-    if constexpr (EY_MF_NOBRANCH && BF3 == 2) {
+    if constexpr (EY_MF_NOBRANCH == 2) {
+      // (no per-lane branch: every lane holds its row's delta2, the lower half stores outputs 0 and 1, the upper half 2 and
+      // 3 -- zeros beyond DK --, and only the lower half's copies enter the bias sums)
+      const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
+      const bool up = h != 0;
+#pragma unroll
+      for (int o = 0; o < DKV; ++o) db2[o] += up ? 0.0f : d2[o];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float lo = j < DKV ? d2[j < DKV ? j : 0] : 0.0f, hi = j + 2 < DKV ? d2[j + 2 < DKV ? j + 2 : 0] : 0.0f;
+        lw[O_D2BUF + (j + 2 * h) * D2S + a2] = up ? hi : lo;
+      }
+    } else if constexpr (EY_MF_NOBRANCH && BF3 == 2) {
       // (the upper half adds zeros and stores to its junk slot behind H1's transposed copy: no per-lane branch)
       const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
       const bool own = h == 0;
@@ -985,7 +1011,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec<DKV>& n
   {
     int k = 0;
     for_each(now, c, h, lane, [&](float& v, int idx, bool counts) {
-      x[k] = (counts && from_memory) ? thg[idx] : v;
+      x[k] = from_memory ? thg[idx] : v;  // (from_memory is the same in every lane)
       ++k;
     });
   }
@@ -994,8 +1020,8 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec<DKV>& n
     const int k0 = half == 0 ? 0 : 16, k1 = half == 0 ? 16 : 26 + DKV;
     double a1[16], a2[16];
     int k = 0;
-    for_each(now, c, h, lane, [&](float&, int idx, bool counts) {
-      if (k >= k0 && k < k1 && counts) {
+    for_each(now, c, h, lane, [&](float&, int idx, bool) {
+      if (k >= k0 && k < k1) {
         a1[k - k0] = m1[idx];
         a2[k - k0] = m2[idx];
       }
@@ -1003,8 +1029,8 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec<DKV>& n
     });
     __builtin_amdgcn_sched_barrier(0);
     k = 0;
-    for_each(now, c, h, lane, [&](float&, int idx, bool counts) {
-      if (k >= k0 && k < k1 && counts) {
+    for_each(now, c, h, lane, [&](float&, int idx, bool) {
+      if (k >= k0 && k < k1) {
         const double t = (double)x[k];
         m1[idx] = a1[k - k0] + t;
         m2[idx] = a2[k - k0] + t * t;
@@ -1013,7 +1039,7 @@ __device__ __forceinline__ void add_moments(KArgs& A, int64_t chain, Vec<DKV>& n
     });
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (lane == 0) A.mom_acc[chain] += accepted ? 1.0 : 0.0;
+  A.mom_acc[chain] += accepted ? 1.0 : 0.0;
 }
 
 // The chain's N(0,1) stream for all NPAR elements, generated by the wave together: lane l computes the blocks of four
@@ -1063,8 +1089,8 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   if (MODE == MODE_GRAD) {
     write_images<BF3, SH>(lw, th, c, h, lane, wl);
     const float t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc, wl);
-    for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
-    if (lane == 0) A.target[chain] = t;
+    for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { grg[idx] = v; });
+    A.target[chain] = t;
     return;
   }
 
@@ -1105,13 +1131,13 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     }
     const EyRng ru = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_UNIFORM);
     const float u = A.u ? A.u[chain] : ey_rng_uniform<float>(ru);
-    const bool acc = __logf(u) < log_rate;  // mala.py:66, metropolis_hastings.py:56
+    const bool acc = __builtin_amdgcn_readfirstlane((int)(__logf(u) < log_rate)) != 0;  // mala.py:66, metropolis_hastings.py:56 (a scalar)
     if (acc) {
-      for_each(p, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) thg[idx] = v; });
+      for_each(p, c, h, lane, [&](float& v, int idx, bool counts) { thg[idx] = v; });
       if (MODE == MODE_MALA)
-        for_each(gp, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
+        for_each(gp, c, h, lane, [&](float& v, int idx, bool counts) { grg[idx] = v; });
     }
-    if (lane == 0) {
+    {  // (every lane stores the same value: no store behind a per-lane branch)
       if (acc) A.target[chain] = tv;
       A.accepted[chain] = acc ? 1 : 0;
       if (A.rate) A.rate[chain] = log_rate;
@@ -1123,7 +1149,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     if (A.rec_samples) {  // the state this chain is left in (chain_list.py:64-67): both candidates are in registers
       float* so = A.rec_samples + ((int64_t)it * A.C + chain) * NPAR;
       for_each2(th, p, [&](float& tv0, float& pv) { tv0 = acc ? pv : tv0; });
-      for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) so[idx] = v; });
+      for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { so[idx] = v; });
     }
     if (A.n_iters > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     return;
@@ -1176,10 +1202,10 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
 
   if (MODE == MODE_LEAPFROG) {
     float* pout = A.pio + chain * NPAR;
-    for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) thg[idx] = v; });
-    for_each(p, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) pout[idx] = -v; });  // hmc.py:122
-    for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
-    if (lane == 0) A.target[chain] = t;
+    for_each(th, c, h, lane, [&](float& v, int idx, bool counts) { thg[idx] = v; });
+    for_each(p, c, h, lane, [&](float& v, int idx, bool counts) { pout[idx] = -v; });  // hmc.py:122
+    for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { grg[idx] = v; });
+    A.target[chain] = t;
     return;
   }
 
@@ -1200,12 +1226,14 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   if (rate > 1.0f) rate = 1.0f;
   const EyRng ru = ey_rng_make(A.seed, A.chain_offset + (uint64_t)chain, iter, EY_STREAM_UNIFORM);
   const float u = A.u ? A.u[chain] : ey_rng_uniform<float>(ru);
-  const bool acc = u < rate;  // strict <, NaN => reject (hmc.py:148)
+  // strict <, NaN => reject (hmc.py:148); the same in every lane, and read as a scalar so that the stores behind it are behind
+  // a scalar branch
+  const bool acc = __builtin_amdgcn_readfirstlane((int)(u < rate)) != 0;
   if (acc) {
-    for_each(th, ce, he, le, [&](float& v, int idx, bool counts) { if (counts) thg[idx] = v; });
-    for_each(g, ce, he, le, [&](float& v, int idx, bool counts) { if (counts) grg[idx] = v; });
+    for_each(th, ce, he, le, [&](float& v, int idx, bool counts) { thg[idx] = v; });
+    for_each(g, ce, he, le, [&](float& v, int idx, bool counts) { grg[idx] = v; });
   }
-  if (le == 0) {
+  {  // (every lane stores the same value: no store behind a per-lane branch)
     if (acc) A.target[chain] = t;
     A.accepted[chain] = acc ? 1 : 0;
     if (A.rate) A.rate[chain] = rate;
@@ -1226,9 +1254,9 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     float* so = A.rec_samples + ((int64_t)it * A.C + chain) * NPAR;
     const float* old = thg;
     asm volatile("" : "+s"(old));  // see add_moments
-    for_each(th, ce, he, le, [&](float& v, int idx, bool counts) { if (counts) so[idx] = acc ? v : old[idx]; });
+    for_each(th, ce, he, le, [&](float& v, int idx, bool counts) { so[idx] = acc ? v : old[idx]; });
   }
-  if (le == 0) {
+  {  // (every lane stores the same value: no store behind a per-lane branch)
     if (A.rec_targets) A.rec_targets[(int64_t)it * A.C + chain] = acc ? t : t_cur;
     if (A.rec_accepted) A.rec_accepted[(int64_t)it * A.C + chain] = acc ? 1 : 0;
     if (A.accept_count && acc) A.accept_count[chain] += 1;
@@ -1278,6 +1306,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   __syncthreads();
   Pace pc;
   pc.prog = ctl;
+  pc.junk = ctl + MF_WAVES + wave;
   pc.wave = wave;
   pc.partner = wave;
   pc.left = 0;

@@ -16,7 +16,7 @@ y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random(
 P = sum((dims[l] + 1) * dims[l + 1] for l in range(len(dims) - 1))
 mu, sigma = 0.1 * rng.standard_normal(P), 0.5 + rng.random(P)
 t_ = lambda a: torch.tensor(np.asarray(a), dtype=dt, device=DEV).contiguous()
-pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV); pl.f32_products = "exact"
+pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV); pl.f32_products = os.environ.get("F32_PRODUCTS", "exact")
 pl.set_data(t_(x), t_(y)); pl.set_prior(torch.tensor(mu), torch.tensor(sigma))
 co = COracle(dims, acts, lik, x, y, mu, sigma, dtype=np.float64, nthreads=4)
 C = 6
