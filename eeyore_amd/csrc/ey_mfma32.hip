@@ -377,15 +377,12 @@ __device__ __forceinline__ void for_each2(Vec<DKV>& a, Vec<DKV>& b, F f) {
   for (int o = 0; o < DKV; ++o) f(a.b2[o], b.b2[o]);
 }
 
-// EY_MF_NOBRANCH (A/B builds, default off): the bf16x3 piece-image form without its two per-lane branches around LDS stores
-// (`if (h == 0)` around the small images and around delta2: the upper half then stores to a junk slot in the tail of the first
-// transpose buffer) -- the rule the fused16 family now follows (a register spilled and reloaded inside a
-// per-lane branch loses its inactive lanes).  Same bits, 0.815 against 0.800 ms per draw and 120 against 64 bytes of
-// scratch (profiles/r04_ab_lds_early.txt): not taken for this kernel, whose shipped build spills outside those regions and
-// is pinned by the golden traces; the switch is here for the day its allocation changes.
-#ifndef EY_MF_NOBRANCH
-#define EY_MF_NOBRANCH 2
-#endif
+// No memory operation of this kernel sits behind a per-lane branch (a register that the allocator spills and
+// reloads inside one comes back with its inactive lanes lost).  Where only some lanes have something to store, the work is
+// shared out instead: the two halves of the wave hold the same small vectors (W0, W2, b1, b0 and a row's delta2), so each
+// half stores half of their images; replicas store the final state beside the counted copy (the same bits to the same
+// address); what lane 0 alone published, every lane stores (or, in the tile loop, the other lanes store into a dead word: Pace::junk).
+// Measured against the branches: same bits, 0.789 against 0.793 ms per draw (profiles/r04_mfma32_no_lane_branches.txt).
 // stage the operand images of theta in this wave's LDS region
 struct W1Lo { u32x4 v[2]; };  // BF3 = 2: the low pieces of W1's row c (the A operand of F1), kept in registers
 template <int BF3, typename SH>
@@ -393,7 +390,7 @@ __device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, i
   constexpr float SC = ActScale<SH::ACT>::value;
 #pragma unroll
   for (int r = 0; r < 16; ++r) lw[O_W1IMG + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = SC * th.w1[r];
-  if constexpr (EY_MF_NOBRANCH == 2) {
+  {
     // (no store behind a per-lane branch, and no store for nothing: the two halves of the wave hold the same small vectors,
     // so each half stores half of their images -- W0's rows i = 0, 1 | 2, 3; W2's image | its transpose; b1 | b0)
     const bool up = h != 0;
@@ -405,33 +402,6 @@ __device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, i
     for (int o = 0; o < 4; ++o)  // outputs beyond DK are zero rows / columns of the two images
       lw[w2base + o * w2step] = o < SH::DK ? th.w2[o < SH::DK ? o : 0] : 0.0f;
     lw[(up ? O_B0IMG : O_B1IMG) + c] = SC * (up ? th.b0 : th.b1);
-  } else if constexpr (EY_MF_NOBRANCH && BF3 == 2) {
-    // (no store behind a per-lane branch: the upper half writes the same values to a junk slot -- the tail of the first
-    // transpose buffer, which holds nothing between evaluations -- so that no vector register can be spilled and reloaded
-    // under a partial EXEC mask)
-    const int junk = O_TB0 + 1152 + lane;
-    const bool own = h == 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lw[own ? O_W0IMG + (4 * (c >> 2) + i) * 5 + (c & 3) : junk] = SC * th.w0[i];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {  // outputs beyond DK are zero rows / columns of the two images
-      const float w = o < SH::DK ? th.w2[o < SH::DK ? o : 0] : 0.0f;
-      lw[own ? O_W2IMG + o * TS36 + c : junk] = w;
-      lw[own ? O_W2TIMG + c * 4 + o : junk] = w;
-    }
-    lw[own ? O_B1IMG + c : junk] = SC * th.b1;
-    lw[own ? O_B0IMG + c : junk] = SC * th.b0;
-  } else if (h == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lw[O_W0IMG + (4 * (c >> 2) + i) * 5 + (c & 3)] = SC * th.w0[i];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {  // outputs beyond DK are zero rows / columns of the two images
-      const float w = o < SH::DK ? th.w2[o < SH::DK ? o : 0] : 0.0f;
-      lw[O_W2IMG + o * TS36 + c] = w;
-      lw[O_W2TIMG + c * 4 + o] = w;
-    }
-    lw[O_B1IMG + c] = SC * th.b1;
-    lw[O_B0IMG + c] = SC * th.b0;
   }
   wave_lds_fence();
   if constexpr (BF3) {
@@ -727,7 +697,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       if (!GRAD) return;
       d2[0] = valid ? (yy / pr - (1.0f - yy) / (1.0f - pr)) * (pr * (1.0f - pr)) : 0.0f;
     }
-    if constexpr (EY_MF_NOBRANCH == 2) {
+    {
       // (no per-lane branch: every lane holds its row's delta2, the lower half stores outputs 0 and 1, the upper half 2 and
       // 3 -- zeros beyond DK --, and only the lower half's copies enter the bias sums)
       const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
@@ -738,23 +708,6 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       for (int j = 0; j < 2; ++j) {
         const float lo = j < DKV ? d2[j < DKV ? j : 0] : 0.0f, hi = j + 2 < DKV ? d2[j + 2 < DKV ? j + 2 : 0] : 0.0f;
         lw[O_D2BUF + (j + 2 * h) * D2S + a2] = up ? hi : lo;
-      }
-    } else if constexpr (EY_MF_NOBRANCH && BF3 == 2) {
-      // (the upper half adds zeros and stores to its junk slot behind H1's transposed copy: no per-lane branch)
-      const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
-      const bool own = h == 0;
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        if (o < DKV) db2[o < DKV ? o : 0] += own ? d2[o < DKV ? o : 0] : 0.0f;
-        lw[own ? O_D2BUF + o * D2S + a2 : O_TB0 + 1152 + lane] = o < DKV ? d2[o < DKV ? o : 0] : 0.0f;
-      }
-    } else if (h == 0) {
-      // delta2 regrouped [o][half][s'][i] with row = 8s'+4*half+i, the k order of the transposed reads below
-      const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
-#pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        if (o < DKV) db2[o < DKV ? o : 0] += d2[o < DKV ? o : 0];
-        lw[O_D2BUF + o * D2S + a2] = o < DKV ? d2[o < DKV ? o : 0] : 0.0f;
       }
     }
     wave_lds_fence();
