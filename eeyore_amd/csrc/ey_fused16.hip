@@ -85,7 +85,8 @@ struct F16Args {
 // EY_F16_PART: the family is built as two translation units.  0 (this file as it stands) = the host side and every
 // instantiation except the one-wave-per-SIMD ones named next; 1 (ey_fused16_d32.hip, which includes this file) =
 // k_fused16<double, 32, 4, *> and the HMC kernels of the f32 H = 64 shapes, k_fused16<float, 64, 4, 2 | 3, F16_HMC>, with
-// their launchers only.  The split exists for one compiler flag: at one wave per SIMD (512 registers) the compiler selects the
+// their launchers only; 2 (ey_fused16_plain.hip) = the plain HMC kernels (F16_HMC_PLAIN) of the other shapes, built beside the
+// main unit so that they cost the build no time.  The split exists for one compiler flag: at one wave per SIMD (512 registers) the compiler selects the
 // MFMAs in their AGPR form and then keeps the loop-carried accumulators in architectural registers all the same, copying
 // them in and out around every product (a third of the vector instructions of the f64 tile loop); -mllvm
 // -amdgpu-mfma-vgpr-form on that unit removes the copies (+7 % on the f64 headline model, same bits), and cannot be given
@@ -93,6 +94,12 @@ struct F16Args {
 // argument.
 #ifndef EY_F16_PART
 #define EY_F16_PART 0
+#endif
+#ifndef EY_F16_W16
+#define EY_F16_W16 16  // waves per CU of the f32 H = 16 instantiations (see f16_launch)
+#endif
+#ifndef EY_F16_PLAIN_UNIT
+#define EY_F16_PLAIN_UNIT 1  // 0: A/B builds without ey_fused16_plain.hip's kernels
 #endif
 #ifndef EY_F16_HMC_OWN
 #define EY_F16_HMC_OWN 4  // the instantiations of up to this many waves per CU get an HMC kernel of their own (f16_launch_t)
@@ -1236,9 +1243,12 @@ static int f16_launch_kernel(F16Args<T>& a, unsigned grid, size_t bytes, hipStre
   EY_HIP(hipGetLastError());
   return EY_OK;
 }
-// (defined in ey_fused16_d32.hip, EY_F16_PART)
+// (defined in ey_fused16_d32.hip, EY_F16_PART 1)
 int ey_f16_launch_d32(F16Args<double>& a, int n_cu, hipStream_t s);
 int ey_f16_launch_f32h64_hmc(F16Args<float>& a, int v, unsigned grid, size_t bytes, hipStream_t s);
+// (defined in ey_fused16_plain.hip, EY_F16_PART 2: the plain HMC kernels of the shapes at two and four waves per SIMD)
+int ey_f16_launch_plain(F16Args<float>& a, int h, int v, unsigned grid, size_t bytes, hipStream_t s);
+int ey_f16_launch_plain(F16Args<double>& a, int h, int v, unsigned grid, size_t bytes, hipStream_t s);
 
 template <typename T, int H, int WAVES, int V>
 static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
@@ -1266,6 +1276,11 @@ static int f16_launch_t(F16Args<T>& a, int n_cu, hipStream_t s) {
       return f16_launch_kernel<T, H, WAVES, V, F16_HMC>(a, grid, bytes, s);
     }
   }
+#if EY_F16_PART == 0 && EY_F16_PLAIN_UNIT
+  // the shapes at two and four waves per SIMD: the plain HMC draw alone gets an instantiation (ey_fused16_plain.hip), +4-5 %
+  if constexpr (WAVES > EY_F16_HMC_OWN)
+    if (a.mode == F16_HMC && a.prior_uniform && !a.temp && !a.da_state) return ey_f16_launch_plain(a, H, V, grid, bytes, s);
+#endif
   return f16_launch_kernel<T, H, WAVES, V, -1>(a, grid, bytes, s);
   }
 }
@@ -1287,7 +1302,23 @@ static int f16_launch_w(F16Args<T>& a, int n_cu, hipStream_t s) {
   }
 }
 
-#if EY_F16_PART == 1
+#if EY_F16_PART == 2
+template <typename T, int H, int WAVES>
+static int f16_plain_v(F16Args<T>& a, int v, unsigned grid, size_t bytes, hipStream_t s) {
+  switch (v) {
+    case 0: return f16_launch_kernel<T, H, WAVES, 0, F16_HMC_PLAIN>(a, grid, bytes, s);
+    case 1: return f16_launch_kernel<T, H, WAVES, 1, F16_HMC_PLAIN>(a, grid, bytes, s);
+    case 2: return f16_launch_kernel<T, H, WAVES, 2, F16_HMC_PLAIN>(a, grid, bytes, s);
+    default: return f16_launch_kernel<T, H, WAVES, 3, F16_HMC_PLAIN>(a, grid, bytes, s);
+  }
+}
+int ey_f16_launch_plain(F16Args<float>& a, int h, int v, unsigned grid, size_t bytes, hipStream_t s) {
+  return h == 16 ? f16_plain_v<float, 16, EY_F16_W16>(a, v, grid, bytes, s) : f16_plain_v<float, 32, 8>(a, v, grid, bytes, s);
+}
+int ey_f16_launch_plain(F16Args<double>& a, int h, int v, unsigned grid, size_t bytes, hipStream_t s) {
+  return f16_plain_v<double, 16, 8>(a, v, grid, bytes, s);
+}
+#elif EY_F16_PART == 1
 int ey_f16_launch_d32(F16Args<double>& a, int n_cu, hipStream_t s) { return f16_launch_w<double, 32, 4>(a, n_cu, s); }
 int ey_f16_launch_f32h64_hmc(F16Args<float>& a, int v, unsigned grid, size_t bytes, hipStream_t s) {
   // (H = 64 only ever takes the padded instantiations, f16_launch_w)
@@ -1303,9 +1334,6 @@ int ey_f16_launch_f32h64_hmc(F16Args<float>& a, int v, unsigned grid, size_t byt
 // than eight on the small shapes (MLP(4-16-16-3) 34.4 -> 39.0 TFLOP/s, same bits).  At that register budget the kernel
 // spills, and that is what exposed the family's per-lane branches (see O_JUNK): until they were removed the padded
 // instantiation's MALA log-rate came out wrong there (profiles/r04_f16_w16_flags.txt).
-#ifndef EY_F16_W16
-#define EY_F16_W16 16
-#endif
 template <typename T>
 static int f16_launch(ey_plan* pl, F16Args<T>& a, hipStream_t s) {
   const EyModel& m = pl->m;

@@ -11,5 +11,5 @@ $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $T/fixed.s -o
 $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $T/f.co $T/dev.o
 $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$T/f.co -output=$T/f.hipfb
 /opt/rocm/bin/hipcc $CXX $2 --offload-host-only -Xclang -fcuda-include-gpubinary -Xclang $T/f.hipfb -c ${SRC:-$ROOT/eeyore_amd/csrc/ey_fused16.hip} -o $T/ey_fused16.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/tools/abl/lib_$1.so $T/ey_fused16.o $O/ey_fused16_d32.o $O/ey_api.o $O/ey_generic.o $O/ey_mfma32.o $O/ey_large.o $O/ey_stats.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/tools/abl/lib_$1.so $T/ey_fused16.o $O/ey_fused16_d32.o $O/ey_fused16_plain.o $O/ey_api.o $O/ey_generic.o $O/ey_mfma32.o $O/ey_large.o $O/ey_stats.o
 echo built tools/abl/lib_$1.so
