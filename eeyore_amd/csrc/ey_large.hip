@@ -770,6 +770,10 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_dma(BG g) {
 // ds_read_b128 of the fragment pattern when rows 8 apart do (bit 3), and the parity of both serves both: round 3's bit 3 alone
 // left the row-contiguous stores at 16.0 cycles instead of 13.6 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.33 on config 5's
 // weight-gradient product, now 0.000; profiles/r04_cfg5_swizzle.txt).
+#ifndef EY_BF3_MINB
+#define EY_BF3_MINB 3  // workgroups per CU the bf16x3 product is compiled for (three: 168 registers per lane and ~280 bytes of
+                       // scratch; two, without the spills, measured 2-5 % slower on config 5: 4.99 / 4.22 against 4.89 / 4.00 ms)
+#endif
 #ifndef EY_BF3_SWZ_MASK
 #define EY_BF3_SWZ_MASK 0x0C
 #endif
@@ -865,7 +869,7 @@ __global__ void __launch_bounds__(256) k_bf3_presplit(const float* __restrict__ 
 // product 4.54 -> 4.24 ms.  (The same for x as the B operand of the first layer's weight gradient measured 5 % SLOWER,
 // 6.97 -> 7.35 ms: 48 bytes per task instead of 32 through an L2 that product already saturates.  Not kept.)
 template <bool AK, bool BK_, bool PRE = false, int KTAIL = 0>
-__global__ void __launch_bounds__(256, 3) k_bgemm_bf3(BG g) {
+__global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
   __shared__ __attribute__((aligned(16))) u32x4_t As[2][3 * 128 * 2];
   __shared__ __attribute__((aligned(16))) u32x4_t Bs[2][3 * 128 * 2];
   __shared__ float rs_red[2][128];
