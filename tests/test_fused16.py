@@ -355,6 +355,85 @@ def test_fused16_saturated_bce_is_nan_and_rejected(tag):
     assert torch.equal(th2[0], th[0]) and torch.equal(th2[2], th[2])
 
 
+# the shapes of the family's three translation units, one or two hidden layers, exact and padded widths
+PLAIN_SHAPES = [
+    ([4, 32, 32, 3], [1, 1, 0], 1, "f64", 150),   # ey_fused16_d32: the headline model in the reference's default dtype
+    ([4, 24, 20, 3], [1, 2, 0], 1, "f64", 40),    #   padded
+    ([5, 32, 3], [1, 0], 1, "f64", 50),           #   one hidden layer
+    ([3, 28, 2], [2, 1], 0, "f64", 33),           #   one hidden layer, padded, BCE
+    ([4, 64, 64, 3], [1, 1, 0], 1, "f32", 150),   # ey_fused16_d32: f32 H = 64
+    ([6, 50, 40, 3], [2, 1, 0], 1, "f32", 70),
+    ([4, 64, 3], [1, 0], 1, "f32", 50),
+    ([4, 16, 16, 3], [1, 1, 0], 1, "f32", 150),   # ey_fused16_plain: f32 H = 16
+    ([4, 12, 10, 3], [1, 3, 0], 1, "f32", 60),
+    ([4, 16, 3], [1, 0], 1, "f32", 40),
+    ([4, 20, 20, 3], [1, 1, 0], 1, "f32", 90),    # ey_fused16_plain: f32 H = 32
+    ([8, 32, 32, 10], [2, 1, 0], 1, "f32", 64),
+    ([4, 32, 2], [1, 1], 0, "f32", 48),
+    ([4, 16, 16, 3], [1, 1, 0], 1, "f64", 77),    # ey_fused16_plain: f64 H = 16
+    ([4, 12, 3], [2, 0], 1, "f64", 30),
+]
+
+
+@pytest.mark.parametrize("dims,acts,lik,tag,N", PLAIN_SHAPES)
+def test_plain_hmc_kernels_vs_oracle_and_vs_the_general_kernel(dims, acts, lik, tag, N):
+    """Every parameter under the same prior, no temperature, no tuner: the HMC draw then runs an instantiation with those
+    options compiled out (F16_HMC_PLAIN) -- the case `HMC.run` on a plain posterior and the bench issue, and the
+    one the suite above (per-parameter priors) never reaches.  The draw on recorded randomness against the C oracle
+    (hmc.py:126-156), and against the same draw through the general kernel (a temperature vector of ones)."""
+    from eeyore_amd.plan import Plan
+    npdt, dt = (np.float64, torch.float64) if tag == "f64" else (np.float32, torch.float32)
+    rng = np.random.default_rng(sum(dims) + 3 * N)
+    x = rng.standard_normal((N, dims[0]))
+    y = np.eye(dims[-1])[rng.integers(0, dims[-1], N)] if lik == 1 else (rng.random((N, dims[-1])) < 0.5).astype(np.float64)
+    P = sum((dims[l] + 1) * dims[l + 1] for l in range(len(dims) - 1))
+    mu0, s0 = 0.05, 1.3
+    pl = Plan(dims, [1] * (len(dims) - 1), acts, lik, dt, DEV)
+    if tag == "f32":
+        pl.f32_products = "exact"
+    pl.set_data(_t(x, dt), _t(y, dt))
+    pl.set_prior(torch.full((P,), mu0, dtype=torch.float64), torch.full((P,), s0, dtype=torch.float64))
+    assert pl.kernel == "fused16"
+    co = COracle(dims, acts, lik, x, y, np.full(P, mu0), np.full(P, s0), dtype=npdt, nthreads=4)
+    C = 9
+    tol = 1e-10 if tag == "f64" else 2e-4
+    th0 = ((0.3 if lik == 1 else 0.15) * rng.standard_normal((C, P))).astype(npdt)
+    p0 = rng.standard_normal((C, P)).astype(npdt)
+    u = rng.random(C).astype(npdt)
+    eps, Ls = (0.02, 5) if lik == 1 else (0.01, 4)
+    t, g = pl.log_target_grad(_t(th0, dt))
+    tv0, g0 = t.cpu().numpy().astype(npdt), g.cpu().numpy().astype(npdt)
+    th_p, t_p, g_p = _t(th0, dt).clone(), t.clone(), g.clone()
+    plain = pl.hmc_step(th_p, t_p, g_p, eps, Ls, p0=_t(p0, dt), u=_t(u, dt))
+    tho, tvo, go = th0.copy(), tv0.copy(), g0.copy()
+    acc, hc, hp = co.hmc_draw(tho, tvo, go, p0, u, eps, Ls)
+    rate = np.minimum(np.exp(np.minimum(hc - hp, 0)), 1)
+    decided = np.abs(u - rate) > (1e-8 if tag == "f64" else 5e-3)
+    got = plain["accepted"].cpu().numpy()
+    np.testing.assert_array_equal(got[decided], acc[decided])
+    np.testing.assert_allclose(plain["h_prop"].cpu().numpy(), hp, rtol=tol * 10, atol=tol * 100)
+    np.testing.assert_allclose(plain["h_cur"].cpu().numpy(), hc, rtol=tol * 10, atol=tol * 100)
+    same = got == acc
+    np.testing.assert_allclose(th_p.cpu().numpy()[same], tho[same], rtol=tol * 10, atol=tol)
+    np.testing.assert_allclose(t_p.cpu().numpy()[same], tvo[same], rtol=tol * 5, atol=tol * 20)
+    np.testing.assert_allclose(g_p.cpu().numpy()[same], go[same], rtol=tol * 50, atol=tol * 50 * max(1.0, np.abs(go).max()))
+    # the general kernel on the same draw: a temperature of one multiplies by exactly one
+    th_g, t_g, g_g = _t(th0, dt).clone(), t.clone(), g.clone()
+    gen = pl.hmc_step(th_g, t_g, g_g, eps, Ls, p0=_t(p0, dt), u=_t(u, dt), temp=torch.ones(C, dtype=dt, device=DEV))
+    gtol = 1e-13 if tag == "f64" else 2e-5
+    both = decided & (gen["accepted"].cpu().numpy() == got)
+    assert both.sum() >= decided.sum() - 1
+    np.testing.assert_allclose(gen["h_prop"].cpu().numpy(), plain["h_prop"].cpu().numpy(), rtol=gtol * 10, atol=gtol * 100)
+    np.testing.assert_allclose(th_g.cpu().numpy()[both], th_p.cpu().numpy()[both], rtol=gtol * 10, atol=gtol)
+    # whole launches of the plain kernel with the device's own randomness: Philox draws, records, several iterations
+    th_r, t_r, g_r = _t(th0, dt).clone(), t.clone(), g.clone()
+    th_s, t_s, g_s = _t(th0, dt).clone(), t.clone(), g.clone()
+    pl.hmc_run(th_r, t_r, g_r, eps, Ls, 3, seed=11, it=40)
+    for i in range(3):
+        pl.hmc_step(th_s, t_s, g_s, eps, Ls, seed=11, it=40 + i)
+    assert torch.equal(th_r, th_s) and torch.equal(t_r, t_s)
+
+
 def test_heads_the_fused_kernels_do_not_take_are_routed_elsewhere():
     """BCE-sum on more than four sigmoid outputs and CE-sum on more than sixteen logits are outside the fused kernels'
     range: the plan must say so (another family serves it) and the values must still be the oracle's."""
@@ -423,7 +502,7 @@ def test_fused16_built_at_O1_passes_the_oracle_suite():
                            env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert check.returncode == 0 and "PASS" in check.stdout, check.stdout[-2000:]
     suite = subprocess.run([sys.executable, "-m", "pytest", "tests/test_fused16.py", "-q", "-x", "-p", "no:cacheprovider",
-                            "-k", "value_gradient_and_draws or philox_and_run_blocks or layers_without_bias"],
+                            "-k", "value_gradient_and_draws or philox_and_run_blocks or layers_without_bias or plain_hmc_kernels"],
                            env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert suite.returncode == 0, suite.stdout[-3000:]
     assert " passed" in suite.stdout and "failed" not in suite.stdout
