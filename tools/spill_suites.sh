@@ -5,7 +5,7 @@
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-units=${@:-ey_mfma32 ey_generic ey_large ey_fused16}
+units=${@:-ey_fused16 ey_fused16_d32 ey_fused16_plain ey_mfma32 ey_generic ey_large}
 for u in $units; do
   lib=eeyore_amd/lib/libeeyore_amd_spill_$u.so
   [ -f "$lib" ] || { echo "$lib missing (make -C eeyore_amd/csrc spill)"; exit 2; }
