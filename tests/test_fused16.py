@@ -375,6 +375,10 @@ PLAIN_SHAPES = [
 ]
 
 
+# ... and shapes drawn at random (another stream than the suite's above; EY_FUZZ_SEEDS scales it: 48 -> 24 shapes)
+PLAIN_SHAPES += _random_cases(max(4, int(os.environ.get("EY_FUZZ_SEEDS", "48")) // 2), seed=77)
+
+
 @pytest.mark.parametrize("dims,acts,lik,tag,N", PLAIN_SHAPES)
 def test_plain_hmc_kernels_vs_oracle_and_vs_the_general_kernel(dims, acts, lik, tag, N):
     """Every parameter under the same prior, no temperature, no tuner: the HMC draw then runs an instantiation with those
