@@ -46,12 +46,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // round trips and two more splits.  The images take the transpose buffers' places (H1's transposed copy, dead by then,
 // lies in the first 4.5 KB of delta1's image; delta0's, made when dW1 has read both, in H0's); the low pieces of W1's rows
 // stay in registers (8), which makes the room.
-#define O_W1P 0        // BF3: [piece 0..2][k-step 0..1][lane] x 16 bytes (BF3 = 2: pieces 0..1)
-#define O_W1IMG (BF3 == 2 ? 2560 : (BF3 ? 1536 : 0))
-#define O_TB0 (BF3 == 2 ? 2560 : (BF3 ? 1536 : 1152))
-#define O_TB1 (BF3 == 2 ? 1024 : (BF3 ? 2688 : 2304))
-#define O_SMALL (BF3 == 2 ? 4096 : (BF3 ? 3840 : 3456))
-#define O_STAGE (BF3 == 2 ? O_TB1 : O_TB0)  // >= 2304 contiguous floats that are free between evaluations
+// BF3 = 3 (the pipelined tile loop at one wave per SIMD, eval_pipe below: four waves share the CU's LDS, 37 KB each): two
+// row tiles are in flight, so nothing shares a buffer any more -- W1 pieces 4 KB | H0's piece image, one per tile parity,
+// 2 x 6 KB | delta1's piece image 6 KB | H1 transposed 4.5 KB | delta0 transposed 4.5 KB | small 2.5 KB.
+#define O_W1P 0        // BF3: [piece 0..2][k-step 0..1][lane] x 16 bytes (BF3 >= 2: pieces 0..1)
+#define O_W1IMG (BF3 == 3 ? 1024 : (BF3 == 2 ? 2560 : (BF3 ? 1536 : 0)))
+#define O_TB0 (BF3 == 3 ? 4096 : (BF3 == 2 ? 2560 : (BF3 ? 1536 : 1152)))
+#define O_TB1 (BF3 == 3 ? 1024 : (BF3 == 2 ? 1024 : (BF3 ? 2688 : 2304)))
+#define O_SMALL (BF3 == 3 ? 7936 : (BF3 == 2 ? 4096 : (BF3 ? 3840 : 3456)))
+#define O_STAGE (BF3 >= 2 ? O_TB1 : O_TB0)  // >= 2304 contiguous floats that are free between evaluations
+#define O_H1T 5632     // BF3 = 3 only: H1 with lane <-> feature (for dW2), [32][36]
+#define O_D0T 6784     // BF3 = 3 only: delta0 likewise (for dW0)
+#define PIPE_IMG 1536  // floats of one piece image
 #define O_W0IMG (O_SMALL + 0)     // [32][5]
 #define O_W2IMG (O_SMALL + 160)   // [4][36]
 #define O_W2TIMG (O_SMALL + 304)  // [32][4]
@@ -62,8 +68,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // its four 16-byte pieces from jj = 0..3, which 32 floats apart land on the same banks for jj and jj + 2 (a two-way
 // conflict on eight reads per tile: the 10 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 1); 36 apart they do not.
 #define D2S 36
-#define WAVE_FLOATS (BF3 == 2 ? 4736 : (BF3 ? 4480 : 4096))
-#define WAVE_FLOATS_OF(bf3) ((bf3) == 2 ? 4736 : ((bf3) ? 4480 : 4096))
+#define WAVE_FLOATS (BF3 == 3 ? 8576 : (BF3 == 2 ? 4736 : (BF3 ? 4480 : 4096)))
+#define WAVE_FLOATS_OF(bf3) ((bf3) == 3 ? 8576 : ((bf3) == 2 ? 4736 : ((bf3) ? 4480 : 4096)))
 #define XTILE_FLOATS 304  // per row tile: [32][5] (x0..x3, label) + [4][D2S] (x regrouped for the 4x4x1 product)
 
 // canonical offsets of MLP(4-32-32-3) in theta
@@ -176,6 +182,11 @@ __device__ __forceinline__ float hsum(float v) {
 #define EY_PHASE_TIMING 0
 #endif
 #if EY_PHASE_TIMING
+#if defined(EY_MF_PART) && EY_MF_PART == 1  // the pipelined form's unit keeps counters (and readers, at the end) of its own
+#define g_ey_phase g_ey_phase_p
+#define g_ey_dbg g_ey_dbg_p
+#define g_ey_wave_t g_ey_wave_t_p
+#endif
 __device__ unsigned long long g_ey_phase[32];
 __device__ int g_ey_dbg[64];
 __device__ unsigned long long g_ey_wave_t[3 * 8192];  // per chain: kernel entry, wave start, wave end (s_memrealtime)
@@ -282,6 +293,19 @@ __device__ __forceinline__ void split16(const f32x16& v, Pieces& P) {
       P.lo[s][d] = pk_bf16(sa, sb);
     }
 }
+// the same split of one pair in two steps (the pipelined tile loop places them in different MFMA gaps)
+__device__ __forceinline__ unsigned split_hi(float a, float b, float& ra, float& rb) {
+  const unsigned hh = pk_bf16(a, b);
+  ra = a - __builtin_bit_cast(float, hh << 16);
+  rb = b - __builtin_bit_cast(float, hh & 0xffff0000u);
+  return hh;
+}
+__device__ __forceinline__ unsigned split_mid_lo(float ra, float rb, unsigned& ll) {
+  const unsigned mm_ = pk_bf16(ra, rb);
+  const float sa = ra - __builtin_bit_cast(float, mm_ << 16), sb = rb - __builtin_bit_cast(float, mm_ & 0xffff0000u);
+  ll = pk_bf16(sa, sb);
+  return mm_;
+}
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -314,6 +338,30 @@ __device__ __forceinline__ f32x16 product_bf3(const Pieces& A, const Pieces& B, 
 #pragma unroll
   for (int s = 0; s < 2; ++s) acc = mfma_bf16(A.hi[s], B.hi[s], acc);
   return acc;
+}
+
+// the K-th of the twelve piece products of product_bf3<SWAPPED>, in its order
+template <int K, bool SWAPPED>
+__device__ __forceinline__ f32x16 bf3_step(const Pieces& A, const Pieces& B, const f32x16& acc) {
+  if constexpr (K < 6) {
+    constexpr int s = K / 3, j = K % 3;
+    if constexpr (j == 0) return SWAPPED ? mfma_bf16(A.lo[s], B.hi[s], acc) : mfma_bf16(A.hi[s], B.lo[s], acc);
+    else if constexpr (j == 1) return SWAPPED ? mfma_bf16(A.hi[s], B.lo[s], acc) : mfma_bf16(A.lo[s], B.hi[s], acc);
+    else return mfma_bf16(A.mid[s], B.mid[s], acc);
+  } else if constexpr (K < 10) {
+    constexpr int s = (K - 6) / 2, j = (K - 6) % 2;
+    if constexpr (j == 0) return SWAPPED ? mfma_bf16(A.mid[s], B.hi[s], acc) : mfma_bf16(A.hi[s], B.mid[s], acc);
+    else return SWAPPED ? mfma_bf16(A.hi[s], B.mid[s], acc) : mfma_bf16(A.mid[s], B.hi[s], acc);
+  } else {
+    return mfma_bf16(A.hi[K - 10], B.hi[K - 10], acc);
+  }
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>());
+  }
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -419,7 +467,7 @@ __device__ __forceinline__ void write_images(float* lw, const Vec<SH::DK>& th, i
     u32x4* pv = reinterpret_cast<u32x4*>(lw + O_W1P) + lane;
     pv[0 * 64] = A.hi[0]; pv[1 * 64] = A.hi[1];
     pv[2 * 64] = A.mid[0]; pv[3 * 64] = A.mid[1];
-    if constexpr (BF3 == 2) {
+    if constexpr (BF3 >= 2) {
       wl.v[0] = A.lo[0]; wl.v[1] = A.lo[1];
     } else {
       pv[4 * 64] = A.lo[0]; pv[5 * 64] = A.lo[1];
@@ -945,6 +993,389 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
   return lik + prior;
 }
 
+// ---- The pipelined evaluation (BF3 = 3; one wave per SIMD, 512 registers, four waves per CU).
+// What a SIMD overlaps (DESIGN.md 4.1.2, MI355X_MICROARCH.md constants table): a v_mfma_f32_32x32x16_bf16 holds the
+// vector issue port for 8 of its 32 cycles, and plain / transcendental / convert instructions that FOLLOW it in the same
+// wave's program order issue in the other 24 -- but inside one row tile everything is one dependency chain (sigmoid ->
+// split -> product -> sigmoid ...), and the partner wave of a SIMD cannot use the gap either (a wave whose next
+// instruction is an MFMA waiting for the pipe holds the port).  So this form keeps TWO row tiles in flight in one wave:
+// the backward half of tile t runs against the forward half of tile t + 1, phase by phase, every bf16 product of one
+// tile issued with the vector work of the other placed in its gaps by hand (a scheduling barrier per gap):
+//   ph0  F0(t+1), sigmoid, split of H0(t+1)                                      (vector work only)
+//   ph1  F1(t+1): 12 MFMAs      ||  delta1(t) = dH1 * act'(H1), db1 sums, split of delta1(t)
+//   ph2  dH0(t):  12 MFMAs      ||  H1(t+1) = act(F1), its transposed store
+//   ph3  logits(t+1) on the 4x4x1 products; the transposed piece loads of dW1(t)
+//   ph4  dW1(t):  12 MFMAs      ||  delta0(t) = dH0 * act'(H0) and its transposed store, softmax / delta2 of t+1
+//   ph5  dW0(t), then dW2(t+1) and dH1(t+1) on the 4x4x1 products
+// The arithmetic of a tile is eval<BF3 = 2>'s, operation for operation and in the same order of accumulation over the
+// tiles (the row-contracting products take all four 8-row k-groups of a short last tile: its padding rows add zeros).
+template <int ACT>
+__device__ __forceinline__ float act_one(float a) {
+  if (ACT == EY_ACT_RELU) return fmaxf(a, 0.0f);
+  float hh = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a) + 1.0f);
+  if (ACT == EY_ACT_TANH) hh = __builtin_fmaf(2.0f, hh, -1.0f);
+  return hh;
+}
+template <int ACT>
+__device__ __forceinline__ float dact_one(float d, float hh) {
+  if (ACT == EY_ACT_RELU) return hh > 0.0f ? d : 0.0f;
+  const float dh = ACT == EY_ACT_TANH ? __builtin_fmaf(-hh, hh, 1.0f) : __builtin_fmaf(-hh, hh, hh);
+  return d * dh;
+}
+#define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
+// An MFMA is a pure value to the instruction selector, which is free to emit it on the far side of any number of scheduling
+// barriers (it sank all twelve products of a phase below the phase's last barrier).  The empty volatile statement takes
+// the accumulator in and out: the MFMA that produced it cannot come later, the one that consumes it not earlier.
+#define PIPE_PIN(x) asm volatile("" : "+v"(x))
+template <bool UPRIOR, typename SH>
+__device__ float eval_pipe(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec<SH::DK>& g, bool has_temp, float temp,
+                           int c, int h, int lane, bool need_value, const W1Lo& wl) {
+  constexpr int BF3 = 3;  // the LDS carve of this form (the O_* offsets)
+  constexpr int DKV = SH::DK;
+  constexpr int ACT = SH::ACT;
+  const int jj = lane & 3;
+  const bool up = h != 0;
+  const int a2 = ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3);
+  f32x16 dW1, db1T;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dW1[r] = 0.0f; db1T[r] = 0.0f; }
+  f32x4 dW0a = {0, 0, 0, 0}, dW0b = {0, 0, 0, 0}, dW2a = {0, 0, 0, 0}, dW2b = {0, 0, 0, 0};
+  float db1 = 0.0f, db0 = 0.0f, db2[DKV], b2s[DKV], lik = 0.0f;
+#pragma unroll
+  for (int o = 0; o < DKV; ++o) {
+    db2[o] = 0.0f;
+    b2s[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th.b2[o])));
+  }
+#if EY_PHASE_TIMING
+  unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool ph_on = (blockIdx.x & 63) == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+  unsigned long long ph_t = ph_on ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
+  // theta's own W1 as the A operand of dH0 (its floats stay where they are: 512 registers)
+  Pieces Bw;
+  {
+    f32x16 w1v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w1v[r] = th.w1[r];
+    split16(w1v, Bw);
+  }
+  // row c of the scaled W1, the A operand of F1, once per evaluation
+  Pieces A1p;
+  {
+    const u32x4* pv = reinterpret_cast<const u32x4*>(lw + O_W1P) + lane;
+    A1p.hi[0] = pv[0 * 64]; A1p.hi[1] = pv[1 * 64];
+    A1p.mid[0] = pv[2 * 64]; A1p.mid[1] = pv[3 * 64];
+    A1p.lo[0] = wl.v[0]; A1p.lo[1] = wl.v[1];
+  }
+  // tile t with its forward half done: H0, H1, dH1 (before the activation's factor)
+  f32x16 H0c, H1c, D1c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { H0c[r] = 0.0f; H1c[r] = 0.0f; D1c[r] = 0.0f; }
+
+  auto body = [&](const int t, auto cur_tag, auto nxt_tag) __attribute__((always_inline)) {
+    constexpr bool CUR = decltype(cur_tag)::value, NXT = decltype(nxt_tag)::value;
+    const float* xt = xs + (t + 1) * XTILE_FLOATS;                       // the data image of tile t + 1
+    const float* xc = xs + t * XTILE_FLOATS;                             // ... of tile t
+    float* h0n = lw + O_TB1 + ((t + 1) & 1) * PIPE_IMG;                  // H0's piece image, by tile parity
+    const float* h0c = lw + O_TB1 + (t & 1) * PIPE_IMG;
+    f32x16 acc, accB, H0n, H1n, D1n;
+    Pieces B1p, Ad, AdU, BhU;
+    int lab = -1;
+    float d2[DKV];
+    f32x4 lg0 = {0, 0, 0, 0}, lg1 = {0, 0, 0, 0};
+    // ---- ph0: F0, H0 = act, split, piece image of tile t + 1                   (mlp.py:45-50)
+    if constexpr (NXT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lw + O_B0IMG + 8 * q + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw[O_W0IMG + c * 5 + 2 * s + h], xt[c * 5 + 2 * s + h], acc, 0, 0, 0);
+      lab = __float_as_int(xt[c * 5 + 4]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) H0n[r] = act_one<ACT>(acc[r]);
+      split16(H0n, B1p);
+      store_pieces(h0n, B1p, c, h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lw + O_B1IMG + 8 * q + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
+      }
+    }
+    PIPE_SB();
+    PH(0);
+    // ---- ph1: F1(t+1) || delta1(t) = dH1 * act'(H1), db1 sums, split, piece image
+    {
+      f32x16 D1;
+      float ra[8], rb[8];
+      static_for<12>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        if constexpr (NXT) { acc = bf3_step<k, false>(A1p, B1p, acc); PIPE_PIN(acc); }
+        if constexpr (CUR) {
+          constexpr int j0 = (16 * k) / 12, j1 = (16 * (k + 1)) / 12;
+#pragma unroll
+          for (int j = j0; j < j1; ++j) {
+            const int u = j >> 1, s = u >> 2, d = u & 3;
+            if ((j & 1) == 0) {
+              D1[2 * u] = dact_one<ACT>(D1c[2 * u], H1c[2 * u]);
+              D1[2 * u + 1] = dact_one<ACT>(D1c[2 * u + 1], H1c[2 * u + 1]);
+              db1T[2 * u] += D1[2 * u];
+              db1T[2 * u + 1] += D1[2 * u + 1];
+              Ad.hi[s][d] = split_hi(D1[2 * u], D1[2 * u + 1], ra[u], rb[u]);
+            } else {
+              unsigned ll;
+              Ad.mid[s][d] = split_mid_lo(ra[u], rb[u], ll);
+              Ad.lo[s][d] = ll;
+            }
+          }
+        }
+        PIPE_SB();
+      });
+      if constexpr (CUR) {
+        wave_lds_fence();  // (the transposed loads of the previous tile's image were issued long ago)
+        store_pieces(lw + O_TB0, Ad, c, h);
+        wave_lds_fence();
+      }
+    }
+    PIPE_SB();
+    PH(1);
+    // ---- ph2: dH0(t)^T = W1^T delta1^T || H1(t+1) = act(F1) and its transposed copy for dW2
+    if constexpr (CUR) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
+    }
+    static_for<12>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      if constexpr (CUR) { accB = bf3_step<k, true>(Bw, Ad, accB); PIPE_PIN(accB); }
+      if constexpr (NXT) {
+        // sixteen elements over gaps 1 .. 11 (the last F1 product is still running in gap 0): two each in 1 .. 5, one in 6 .. 11
+        constexpr int e0 = k == 0 ? 0 : (k <= 5 ? 2 * (k - 1) : 10 + (k - 6)), e1 = k == 0 ? 0 : (k <= 5 ? 2 * k : 11 + (k - 6));
+#pragma unroll
+        for (int r = e0; r < e1; ++r) {
+          H1n[r] = act_one<ACT>(acc[r]);
+          lw[O_H1T + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = H1n[r];
+        }
+      }
+      PIPE_SB();
+    });
+    PH(2);
+    // ---- ph3: the transposed piece loads of dW1(t); logits(t+1) = W2 H1^T + b2 on the 4x4x1 products
+    if constexpr (CUR) {
+      wave_lds_fence();
+      load_pieces_transposed(lw + O_TB0, AdU, h, lane);
+      load_pieces_transposed(h0c, BhU, h, lane);
+    }
+    if constexpr (NXT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(lw + O_W2IMG + jj * TS36 + 8 * q + 4 * h);
+        lg0 = mfma4(wv[0], H1n[4 * q + 0], lg0);
+        lg1 = mfma4(wv[1], H1n[4 * q + 1], lg1);
+        lg0 = mfma4(wv[2], H1n[4 * q + 2], lg0);
+        lg1 = mfma4(wv[3], H1n[4 * q + 3], lg1);
+      }
+    }
+    PIPE_SB();
+    PH(3);
+    // ---- ph4: dW1(t) += delta1^T H0 || delta0(t) = dH0 * act'(H0) with its transposed copy; softmax / delta2 of t + 1
+    {
+      float lg[DKV], e[DKV], mx = 0.0f, ssum = 1.0f, llab = 0.0f, rs = 0.0f;
+      bool valid = false;
+      static_for<12>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        if constexpr (CUR) { dW1 = bf3_step<k, false>(AdU, BhU, dW1); PIPE_PIN(dW1); }
+        if constexpr (CUR && k < 8) {
+#pragma unroll
+          for (int r = 2 * k; r < 2 * k + 2; ++r) {
+            const float d0 = dact_one<ACT>(accB[r], H0c[r]);
+            lw[O_D0T + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = d0;
+          }
+        }
+        if constexpr (NXT && SH::LIK == EY_LIK_CE_SUM) {
+          // CE-sum log-likelihood and output delta = onehot - softmax           (constants.py:17)
+          if constexpr (k == 1) {
+#pragma unroll
+            for (int o = 0; o < DKV; ++o) lg[o] = hsum(lg0[o] + lg1[o]) + b2s[o];
+          }
+          if constexpr (k == 3) {
+            valid = lab >= 0;
+            mx = lg[0];
+#pragma unroll
+            for (int o = 1; o < DKV; ++o) mx = fmaxf(mx, lg[o]);
+            ssum = 0.0f;
+            llab = lg[0];
+#pragma unroll
+            for (int o = 0; o < DKV; ++o) {
+              e[o] = __expf(lg[o] - mx);
+              ssum += e[o];
+              if (o > 0) llab = lab == o ? lg[o] : llab;
+            }
+          }
+          if constexpr (k == 5) {
+            if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
+            rs = __builtin_amdgcn_rcpf(ssum);
+          }
+          if constexpr (k == 7) {
+#pragma unroll
+            for (int o = 0; o < DKV; ++o) d2[o] = valid ? ((lab == o ? 1.0f : 0.0f) - e[o] * rs) : 0.0f;
+          }
+        }
+        if constexpr (NXT && SH::LIK != EY_LIK_CE_SUM) {
+          // BCE-sum on the sigmoid output with the naive logs of eeyore/stats/loss.py:2 (see eval)
+          if constexpr (k == 1) lg[0] = hsum(lg0[0] + lg1[0]) + b2s[0];
+          if constexpr (k == 5) {
+            const float yy = __int_as_float(lab);
+            valid = yy >= 0.0f;
+            const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(NEG_LOG2E * lg[0]));
+            if (need_value && valid && h == 0) lik += __logf(pr) * yy + __logf(1.0f - pr) * (1.0f - yy);
+            d2[0] = valid ? (yy / pr - (1.0f - yy) / (1.0f - pr)) * (pr * (1.0f - pr)) : 0.0f;
+          }
+        }
+        if constexpr (NXT && k == 9) {
+          // (no per-lane branch: the lower half stores outputs 0 and 1, the upper half 2 and 3 -- zeros beyond DK --, and only
+          // the lower half's copies enter the bias sums)
+#pragma unroll
+          for (int o = 0; o < DKV; ++o) db2[o] += up ? 0.0f : d2[o];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float lo = j < DKV ? d2[j < DKV ? j : 0] : 0.0f, hi = j + 2 < DKV ? d2[j + 2 < DKV ? j + 2 : 0] : 0.0f;
+            lw[O_D2BUF + (j + 2 * h) * D2S + a2] = up ? hi : lo;
+          }
+        }
+        PIPE_SB();
+      });
+    }
+    PH(4);
+    // ---- ph5: dW0(t) += delta0^T x, db0 (delta0 with lane <-> feature through its transposed copy)
+    if constexpr (CUR) {
+      wave_lds_fence();
+      const float* x2 = xc + 160 + jj * D2S + h * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_D0T + c * TS36 + 8 * s + 4 * h);
+        const f32x4 xu = *reinterpret_cast<const f32x4*>(x2 + 4 * s);
+        dW0a = mfma4(du[0], xu[0], dW0a);
+        dW0b = mfma4(du[1], xu[1], dW0b);
+        dW0a = mfma4(du[2], xu[2], dW0a);
+        dW0b = mfma4(du[3], xu[3], dW0b);
+        db0 += (du[0] + du[1]) + (du[2] + du[3]);
+      }
+    }
+    PIPE_SB();
+    PH(5);
+    // ---- dW2(t+1) += delta2^T H1 (transposed reads), dH1(t+1)^T = W2^T delta2^T
+    if constexpr (NXT) {
+      wave_lds_fence();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f32x4 hu = *reinterpret_cast<const f32x4*>(lw + O_H1T + c * TS36 + 8 * s + 4 * h);
+        const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_D2BUF + jj * D2S + h * 16 + 4 * s);
+        dW2a = mfma4(du[0], hu[0], dW2a);
+        dW2b = mfma4(du[1], hu[1], dW2b);
+        dW2a = mfma4(du[2], hu[2], dW2a);
+        dW2b = mfma4(du[3], hu[3], dW2b);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wt = *reinterpret_cast<const f32x4*>(lw + O_W2TIMG + (8 * q + 4 * h + jj) * 4);
+        f32x4 d = {0, 0, 0, 0};
+#pragma unroll
+        for (int o = 0; o < DKV; ++o) d = mfma4(wt[o], d2[o], d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) D1n[4 * q + i] = d[i];
+      }
+      wave_lds_fence();
+      H0c = H0n;
+      H1c = H1n;
+      D1c = D1n;
+    }
+    PIPE_SB();
+    PH(6);
+  };
+  const int T = A.ntiles;
+  body(-1, std::false_type(), std::true_type());
+#pragma unroll 1
+  for (int t = 0; t + 1 < T; ++t) body(t, std::true_type(), std::true_type());
+  body(T - 1, std::true_type(), std::false_type());
+
+  // db1: the tile-layout sums (lane <-> row) through H1's transpose buffer, each lane then adds its feature's 16 rows
+  wave_lds_fence();
+  store_T(lw + O_H1T, db1T, c, h);
+  wave_lds_fence();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const f32x4 du = *reinterpret_cast<const f32x4*>(lw + O_H1T + c * TS36 + 8 * s + 4 * h);
+    db1 += (du[0] + du[1]) + (du[2] + du[3]);
+  }
+  wave_lds_fence();
+  // ---- combine the two row-parity halves and the lanes
+#pragma unroll
+  for (int r = 0; r < 16; ++r) g.w1[r] = dW1[r];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g.w0[i] = hsum(dW0a[i] + dW0b[i]);
+#pragma unroll
+  for (int o = 0; o < DKV; ++o) {
+    g.w2[o] = hsum(dW2a[o] + dW2b[o]);
+    g.b2[o] = wsum(db2[o]);
+  }
+  g.b1 = hsum(db1);
+  g.b0 = hsum(db0);
+  // ---- prior (bayesian_model.py:46-50): elementwise Normal(mu, sigma); temperature scales everything (:33-34,48-49)
+  float qsum = 0.0f;
+  if (UPRIOR || A.prior_uniform) {
+    const float mu0 = A.mu0, iv0 = A.iv0;
+    for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int, bool counts) {
+      const float d = tv - mu0;
+      if (counts) qsum += d * d * iv0;
+      float gn = gv - d * iv0;
+      if (has_temp) gn *= temp;
+      gv = gn;
+    });
+  } else {
+    for_each_pair(th, g, c, h, lane, [&](float& tv, float& gv, int idx, bool counts) {
+      const float d = tv - A.mu[idx];
+      const float iv = A.inv_var[idx];
+      if (counts) qsum += d * d * iv;
+      float gn = gv - d * iv;
+      if (has_temp) gn *= temp;
+      gv = gn;
+    });
+  }
+  float prior = 0.0f;
+  if (need_value) {
+    lik = wsum(lik);
+    prior = A.prior_const - 0.5f * wsum(qsum);
+  }
+  if (has_temp) { lik *= temp; prior *= temp; }
+#if EY_PHASE_TIMING
+  if (ph_on) {
+    const float keep = lik + prior + g.w1[0] + g.b1;  // the epilogue's results must exist before the clock is read
+    if (keep == 1.2345e-30f) g.b0 += 1.0f;
+  }
+  PH(10);
+  if (ph_on && lane == 0) {
+    for (int i = 0; i < 11; ++i) atomicAdd(&g_ey_phase[i], ph_acc[i]);
+    atomicAdd(&g_ey_phase[15], 1ull);
+  }
+#endif
+  return lik + prior;
+}
+
+template <int PARK, bool UPRIOR, int BF3, typename SH, bool GRAD = true>
+__device__ __forceinline__ float eval_any(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec<SH::DK>& g, bool has_temp,
+                                          float temp, int c, int h, int lane, bool need_value, Pace& pc, const W1Lo& wl) {
+  if constexpr (BF3 == 3) {
+    if constexpr (GRAD) return eval_pipe<UPRIOR, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, need_value, wl);
+    else return 0.0f;  // (the pipelined form is instantiated for modes that take the gradient)
+  } else {
+    return eval<PARK, UPRIOR, BF3, SH, GRAD>(A, xs, lw, th, g, has_temp, temp, c, h, lane, need_value, pc, wl);
+  }
+}
+
 // Attached running moments: s1 += theta, s2 += theta^2, acc += accepted for the state this chain is left in, with the
 // arithmetic of ey_stats_update (the product of two floats is exact in double).  `now` holds the state where the lane
 // has it in registers; `from_memory` says to take it from theta in HBM instead (a rejected HMC proposal).
@@ -1041,7 +1472,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
 
   if (MODE == MODE_GRAD) {
     write_images<BF3, SH>(lw, th, c, h, lane, wl);
-    const float t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc, wl);
+    const float t = eval_any<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc, wl);
     for_each(g, c, h, lane, [&](float& v, int idx, bool counts) { grg[idx] = v; });
     A.target[chain] = t;
     return;
@@ -1070,7 +1501,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     });
     wave_lds_fence();  // the staged normals have been read; the evaluation reuses that LDS
     write_images<BF3, SH>(lw, p, c, h, lane, wl);
-    const float tv = eval<PARK, UPRIOR, BF3, SH, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc, wl);
+    const float tv = eval_any<PARK, UPRIOR, BF3, SH, MODE == MODE_MALA>(A, xs, lw, p, gp, has_temp, temp, c, h, lane, true, pc, wl);
     const float t_old = A.target[chain];
     float log_rate = tv - t_old;  // symmetric kernel: metropolis_hastings.py:50
     if (MODE == MODE_MALA) {
@@ -1129,7 +1560,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
   // leapfrog, hmc.py:100-124 (grad_potential = -grad): the first half step of the momentum
   if (MODE == MODE_LEAPFROG || A.recompute) {  // hmc.py:104
     write_images<BF3, SH>(lw, th, c, h, lane, wl);
-    t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc, wl);
+    t = eval_any<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, true, pc, wl);
     for_each2(p, g, [&](float& pv, float& gv) { pv = __builtin_fmaf(0.5f * eps, gv, pv); });
   } else {
     // the cached gradient goes from memory straight into the momentum: loaded into a register vector of its own before
@@ -1146,7 +1577,7 @@ __device__ __forceinline__ void run_chain(KArgs& A, const float* xs, float* lw, 
     KO(1);
     write_images<BF3, SH>(lw, th, c, h, lane, wl);
     KO(2);
-    t = eval<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc, wl);
+    t = eval_any<PARK, UPRIOR, BF3, SH>(A, xs, lw, th, g, has_temp, temp, c, h, lane, k == A.L, pc, wl);
     KO(3);
     const float w = (k < A.L) ? eps : 0.5f * eps;
     for_each2(p, g, [&](float& pv, float& gv) { pv = pv + w * gv; });
@@ -1309,6 +1740,69 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_mfma32(MfArgs A) {
   if (lane == 0) __hip_atomic_store(&ctl[wave], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // nothing left
 }
 
+// The pipelined form's launch: one 4-wave workgroup per CU, ONE wave per SIMD (512 registers per lane), every wave walks
+// over chains blockIdx + gridDim*wave, + 4*gridDim, ... chain-major like k_mfma32.  No pacing: a wave has its SIMD to itself.
+template <int MODE, bool UPRIOR, bool DA, typename SH>
+__global__ void __launch_bounds__(256, 1) k_mfma32p(MfArgs A) {
+  constexpr int BF3 = 3;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int xfloats = A.ntiles * XTILE_FLOATS;
+  for (int i = tid; i < xfloats; i += 256) smem[i] = A.xpack[i];
+  const float* xs = smem;
+  float* lw = smem + xfloats + wave * WAVE_FLOATS;
+  __syncthreads();
+  Pace pc;
+  pc.prog = nullptr; pc.junk = nullptr; pc.wave = wave; pc.partner = wave; pc.left = 0; pc.bias = 0; pc.on = false; pc.hi = false;
+  const int64_t first = (int64_t)blockIdx.x + (int64_t)gridDim.x * wave, stride = (int64_t)gridDim.x * 4;
+  const int n_iters = A.n_iters;
+  for (int64_t chain = first; chain < A.C; chain += stride) {
+    for (int it = 0; it < n_iters; ++it) {
+      KArgs* Ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (see k_mfma32)
+      asm volatile("" : "+s"(Ap));
+      run_chain<MODE, 0, UPRIOR, DA, BF3, SH>(*Ap, xs, lw, chain, it, c, h, lane, pc);
+    }
+  }
+}
+
+#ifndef EY_MF_PART
+#define EY_MF_PART 0
+#endif
+#define MF_PIPE_TILES 8   // the pipelined form's per-wave regions (4 x 34.3 KB) leave room for 8 row tiles (N <= 256)
+// (defined in the translation unit of its own, ey_mfma32p.hip = this file with EY_MF_PART 1: built without packed f32
+// instructions, which never issue in the shadow of a bf16 MFMA)
+int ey_mfma32p_hmc(MfArgs& a, int n_cu, hipStream_t s);
+#if EY_MF_PART == 1
+int ey_mfma32p_hmc(MfArgs& a, int n_cu, hipStream_t s) {
+  const size_t bytes = sizeof(float) * ((size_t)a.ntiles * XTILE_FLOATS + 4 * (size_t)WAVE_FLOATS_OF(3));
+  const int most = (int)(sizeof(float) * ((size_t)MF_PIPE_TILES * XTILE_FLOATS + 4 * (size_t)WAVE_FLOATS_OF(3)));
+  const unsigned grid = (unsigned)std::min<int64_t>(a.C, n_cu > 0 ? n_cu : 256);
+#define MFP_LAUNCH(DA)                                                                                              \
+  do {                                                                                                             \
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma32p<MODE_HMC, true, DA, MfHeadline>),            \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, most));                                 \
+    hipLaunchKernelGGL((k_mfma32p<MODE_HMC, true, DA, MfHeadline>), dim3(grid), dim3(256), bytes, s, a);            \
+  } while (0)
+  if (a.da_state) MFP_LAUNCH(true);
+  else MFP_LAUNCH(false);
+#undef MFP_LAUNCH
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
+#if EY_PHASE_TIMING
+extern "C" int ey_debug_phase_read_p(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ey_phase), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ey_phase), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+#else
 // ----------------------------------------------------------------------------------------------- host side
 // 1: the headline model (both product forms); 2: a 4-32-32 model with another hidden activation or the BCE head, served
 // in the bf16x3 form only (the exact form of those is fused16's); 0: not this kernel's
@@ -1447,6 +1941,7 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
     const int variant = t_ey_variant & 15;
     if (variant & 1) return mf_launch_v<MODE, 4, 0>(a, pl->n_cu, s);
     if (bf3) {
+      if (a.prior_uniform && a.ntiles >= 2 && a.ntiles <= MF_PIPE_TILES && (variant & 8)) return ey_mfma32p_hmc(a, pl->n_cu, s);
       if (a.prior_uniform && a.ntiles <= MF_TRD_TILES && !(variant & 4))
         return a.da_state ? mf_launch_v<MODE, 8, 0, true, true, 2>(a, pl->n_cu, s)
                           : mf_launch_v<MODE, 8, 0, true, false, 2>(a, pl->n_cu, s);
@@ -1553,3 +2048,4 @@ extern "C" int ey_debug_phase_read(unsigned long long* out16, int reset) {
   return 0;
 }
 #endif
+#endif  // EY_MF_PART
