@@ -586,6 +586,27 @@ __device__ __forceinline__ void load_pieces_transposed(const float* img, Pieces&
   }
 }
 
+// EY_MF_GAPS: which bf16 products of the tile loop (BF3 = 2) take vector work of their own tile into their gaps
+// (bit 0: dW1 <- delta0 and its transposed store).  See eval.  MEASURED AND NOT KEPT (round 5, profiles/r05_ab_gaps.txt):
+// same bits, 0.8183 / 0.8154 against 0.8188 / 0.8157 ms per draw -- with two waves per SIMD the gaps of one wave's products
+// are not what the pair waits for.
+#ifndef EY_MF_GAPS
+#define EY_MF_GAPS 0
+#endif
+// (an MFMA is a pure value to the instruction selector, which may emit it on the far side of any number of scheduling
+// barriers; the empty volatile statement takes the accumulator in and out, which pins the product that made it)
+#define GAP_PIN(x) asm volatile("" : "+v"(x))
+// d * act'(g) from the activation value, one element, as times_dact computes it -- through opaque statements, so that the
+// vectoriser does not pair the elements into packed instructions again
+template <int ACT>
+__device__ __forceinline__ float dact_gap(float d, float hh) {
+  if (ACT == EY_ACT_RELU) return hh > 0.0f ? d : 0.0f;
+  float dh, o;
+  if (ACT == EY_ACT_TANH) asm("v_fma_f32 %0, -%1, %1, 1.0" : "=v"(dh) : "v"(hh));
+  else asm("v_fma_f32 %0, -%1, %1, %1" : "=v"(dh) : "v"(hh));
+  asm("v_mul_f32_e32 %0, %1, %2" : "=v"(o) : "v"(d), "v"(dh));
+  return o;
+}
 // log-target and gradient of the position whose images are staged in lw.  Returns the (tempered) log-target.
 // `need_value` (wave-uniform) = false skips the value-only work (row log-sum-exp terms, quadratic form of the prior
 // and their reductions): inside a trajectory only the gradient is consumed, hmc.py:108-121.
@@ -807,6 +828,31 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       chain_enter(pc);
       acc = product_bf3<true>(Bw, Ad, acc);
       chain_exit(pc);
+      if constexpr ((EY_MF_GAPS & 1) != 0) {
+        // ---- B2(1) with delta0 in its gaps.  A v_mfma_f32_32x32x16_bf16 holds the vector issue port for 8 of its 32 cycles;
+        // plain vector instructions of the SAME wave that follow it in program order issue in the other 24 (a partner
+        // wave's do not: profiles/r05_wave1_probe.txt), so delta0 = dH0 * act'(H0) and its transposed store -- the only
+        // work of this tile that does not wait for dW1 -- go two elements behind each of the first eight products instead
+        // of in front of all twelve.  Unpacked (packed f32 instructions never issue beside a bf16 MFMA); same arithmetic.
+        PH(7);
+        Pieces AdU, BhU;
+        load_pieces_transposed(lw + O_TB0, AdU, h, lane);
+        load_pieces_transposed(lw + O_TB1, BhU, h, lane);
+        wave_lds_fence();  // delta0's copy goes where H0's image lies: behind the loads above
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<12>([&](auto kk) {
+          constexpr int k = decltype(kk)::value;
+          dW1 = bf3_step<k, false>(AdU, BhU, dW1);
+          GAP_PIN(dW1);
+          if constexpr (k < 8) {
+#pragma unroll
+            for (int r = 2 * k; r < 2 * k + 2; ++r)
+              lw[O_TB1 + (8 * (r >> 2) + 4 * h + (r & 3)) * TS36 + c] = dact_gap<SH::ACT>(acc[r], H0[r]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        wave_lds_fence();
+      } else {
       const f32x16 D0 = times_dact<SH::ACT>(acc, H0);
       PH(7);
       // ---- B2(1): dW1[out][in] += sum_n delta1[n][out] H0[n][in]: both operands from the piece images, transposed
@@ -822,6 +868,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       wave_lds_fence();
       store_T(lw + O_TB1, D0, c, h);
       wave_lds_fence();
+      }
 #pragma unroll
       for (int r = 4 * SG; r < 16; ++r) H0U[r] = 0.0f;
 #pragma unroll
