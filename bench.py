@@ -83,6 +83,54 @@ def cpu_reference_faithful(x, y, sigma, budget_s=8.0):
                                       f"run serially in the reference, so x chains = the same number"}
 
 
+def cpu_reference_faithful_config1(budget_s=4.0):
+    """the same torch-CPU counterpart for BASELINE configs[0] -- HMC, 1 chain, MLP(2-2-1) sigmoid-sigmoid,
+    BCE-sum, XOR 4 x 2, prior N(0, 100), step 0.1, L = 10, f64, theta0 = the reference's test vector
+    (eeyore/samplers/hmc.py:126-170 on tests/*mlp221*'s model) -- timed on this host beside the GPU run."""
+    from oracle.torch_autograd_path import TorchReferencePath
+    x = np.array([[0., 0.], [0., 1.], [1., 0.], [1., 1.]])
+    y = np.array([[0.], [1.], [1.], [0.]])
+    tp = TorchReferencePath([2, 2, 1], [1, 1], 0, x, y, 0.0, 100.0, dtype=torch.float64)
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    cur = tp.start(torch.tensor([1.1, -2.9, -0.4, 0.8, 4.3, 9.2, 4.44, -3.4, 7.2], dtype=torch.float64))
+    for _ in range(5):
+        cur = tp.hmc_draw(cur, 0.1, 10)
+    t0 = time.perf_counter()
+    iters = 0
+    while time.perf_counter() - t0 < budget_s:
+        cur = tp.hmc_draw(cur, 0.1, 10)
+        iters += 1
+    t = time.perf_counter() - t0
+    torch.set_num_threads(threads_before)
+    return {"value": iters * 10 / t, "unit": "leapfrog-steps/sec x chains", "cores": 1, "kind": "port",
+            "sample": f"BASELINE configs[0]: 1 chain x {iters} HMC iterations (L=10, L+1 autograd evaluations each), MLP(2-2-1) on XOR, "
+                      f"f64, torch {torch.__version__} CPU autograd op for op as the reference, {t:.1f} s"}
+
+
+def gpu_config1(dev, iters=2000):
+    """BASELINE configs[0] on the device through the C ABI (the generic kernels' register-resident form): one chain,
+    MLP(2-2-1), XOR, f64, L = 10, launches of 100 draws (ey_hmc_run), beside the CPU line above."""
+    from eeyore_amd.plan import Plan
+    x = torch.tensor([[0., 0.], [0., 1.], [1., 0.], [1., 1.]], dtype=torch.float64, device=dev)
+    y = torch.tensor([[0.], [1.], [1.], [0.]], dtype=torch.float64, device=dev)
+    pl = Plan([2, 2, 1], [1, 1], [1, 1], 0, torch.float64, dev)
+    pl.set_data(x, y)
+    pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), 100.0))
+    th = torch.tensor([[1.1, -2.9, -0.4, 0.8, 4.3, 9.2, 4.44, -3.4, 7.2]], dtype=torch.float64, device=dev)
+    t, g = pl.log_target_grad(th)
+    pl.hmc_run(th, t, g, 0.1, 10, 100, seed=3, it=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(iters // 100):
+        pl.hmc_run(th, t, g, 0.1, 10, 100, seed=3, it=101 + 100 * b)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": (iters // 100) * 100 * 10 / dt, "unit": "leapfrog-steps/sec x chains", "kernel": pl.kernel,
+            "sample": f"1 chain x {(iters // 100) * 100} HMC iterations in launches of 100 (L=10), f64, {dt * 1e3:.1f} ms"}
+
+
 def usable_cpus():
     """Hardware threads this process may run on: the scheduler's affinity mask, cut down by a cgroup CPU quota where one
     is set (a container may see every thread of the host and still be throttled to a share of them)."""
@@ -227,11 +275,26 @@ def dry_run(args, rank, world):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    # the collectives the measuring run issues behind its timed region, on host tensors: the R-hat summary (one all-reduce of
+    # the [3, P] partial sums, distributed.ChainStats.summary) and the ESS gather (distributed.reduce_ess), over UNEVEN
+    # shards of seeded chains (rank r holds 3 + r % 3 of them), so that the first multi-GPU run is not their first N-rank run
+    from eeyore_amd.distributed import ChainStats, reduce_ess
+    rng = np.random.default_rng(100 + rank)
+    c_local, p_dim, n_it = 3 + rank % 3, 11, 30
+    x = torch.tensor(rng.standard_normal((c_local, n_it, p_dim)).cumsum(1) * 0.1)
+    st = ChainStats(c_local, p_dim, "cpu")
+    for i in range(n_it):
+        st.update(x[:, i], torch.tensor(rng.random(c_local) < 0.7))
+    summ = st.summary()
+    ess = reduce_ess(torch.tensor(rng.uniform(5.0, 300.0, (c_local, p_dim))))
     if rank == 0:
         print(json.dumps({"metric": "leapfrog-steps/sec x chains, HMC MLP(4-32-32-3)", "value": None, "dry_run": True,
                           "unit": "leapfrog-steps/sec x chains", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
-                          "higher_is_better": True, "scaling": "weak"}), flush=True)
+                          "higher_is_better": True, "scaling": "weak",
+                          "config": {"collectives": {"rhat_num_chains": summ["num_chains"], "rhat_max": float(summ["rhat"].max().item()),
+                                                     "ess_num_chains": ess["num_chains"],
+                                                     "expected_num_chains": sum(3 + r % 3 for r in range(world))}}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -286,6 +349,8 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--iters-per-launch", type=int, default=25,
                     help="HMC iterations (bench steps) per kernel launch: ey_hmc_run, as HMC.run issues them; 1 = ey_hmc_step")
+    ap.add_argument("--min-launches", type=int, default=5,
+                    help="the timed region holds at least this many launches (of --iters-per-launch iterations each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-record", action="store_true",
                     help="do not record the chains in the timed region (round 3's figure: the kernel without the sample store)")
@@ -340,14 +405,19 @@ def main():
     if args.force_generic:
         ipl = 1  # the generic family replays attached moments from recorded samples; keep its one-step form
 
-    # --steps rounded up to whole launches: the timed region is what HMC.run issues after burn-in
-    steps_timed = ((args.steps + ipl - 1) // ipl) * ipl
+    # --steps rounded up to whole launches: the timed region is what HMC.run issues after burn-in -- and
+    # to at least --min-launches of them: one 21 ms launch is a single sample of a quantity that moves by
+    # +-10 % from launch to launch; `steps` in the line is what was timed, `config.steps_requested` what was asked for
+    n_launches = max((args.steps + ipl - 1) // ipl, 1 if args.force_generic else max(1, args.min_launches))
+    steps_timed = n_launches * ipl
     # the chain buffer of the timed region, [iterations, C, P] + targets + accept flags, as ChainBuffer holds a run
     # (200 steps x 4096 x 1315 floats = 4.3 GB), and one launch's worth for the untimed launches around it
     record = not args.no_record and not args.force_generic
     n_rec = steps_timed if record else 0
     rec = dict(s=plan.empty(max(n_rec, ipl), C, P), t=plan.empty(max(n_rec, ipl), C),
                a=plan.empty(max(n_rec, ipl), C, dtype=torch.uint8)) if record else None
+
+    launch_events = None  # a list while the timed region runs: one event in front of every launch (and one behind the last)
 
     def steps(it, n, rec_at=None):
         """n bench steps = n HMC iterations of every chain, starting at iteration number `it`: whole launches of `ipl`
@@ -357,6 +427,10 @@ def main():
         done = 0
         while done < n:
             k = min(ipl, n - done)
+            if launch_events is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                launch_events.append(ev)
             kw = {}
             if record:
                 r0 = 0 if rec_at is None else rec_at + done
@@ -403,7 +477,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    launch_events = []
     steps(it, steps_timed, rec_at=0); it += steps_timed
+    ev_end = torch.cuda.Event(enable_timing=True)
+    ev_end.record()
+    timed_events, launch_events = launch_events + [ev_end], None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -456,6 +534,7 @@ def main():
         s_elapsed, s_acc = through_sampler_run(xs, ys, sigma, theta0, dev, steps_timed, ipl, seed, chain_offset, world, gloo)
         via_sampler = (s_elapsed, s_acc)
 
+    launch_gaps = [a.elapsed_time(b) for a, b in zip(timed_events[:-1], timed_events[1:])]
     if rank == 0:
         f_step = flops_per_leapfrog_step(DIMS, N_ROWS)
         total_chains = C * world
@@ -483,8 +562,13 @@ def main():
                 "f32_products": None if args.force_generic else products,
                 "gradient_evaluations_per_iteration": L_STEPS, "iterations_per_launch": ipl,
                 "steps_requested": args.steps,
-                "steps_note": f"--steps {args.steps} rounded up to {steps_timed} = {steps_timed // ipl} whole launch(es) of {ipl} "
-                              f"iterations, as HMC.run issues them" if steps_timed != args.steps else "whole launches",
+                "steps_note": (f"--steps {args.steps} rounded up to {steps_timed} = {steps_timed // ipl} whole launch(es) of {ipl} "
+                               f"iterations, as HMC.run issues them (at least --min-launches {args.min_launches}); `steps` and "
+                               f"`ms_per_step` are those of the timed region") if steps_timed != args.steps else "whole launches",
+                "launches_timed": steps_timed // ipl,
+                "launch_ms_min": round(min(launch_gaps), 4), "launch_ms_median": round(float(np.median(launch_gaps)), 4),
+                "launch_ms_max": round(max(launch_gaps), 4),
+                "launch_ms_note": "start-to-start of consecutive launches inside the timed region (HIP events on the launch stream)",
                 "recorded_in_timed_region": ("samples [steps, C, P], targets [steps, C], accepted [steps, C] (the chain buffer "
                                              "HMC.run fills after burn-in)") if record else None,
                 "stats_summary_ms": round(summary_ms, 3),
@@ -569,6 +653,11 @@ def main():
                 base["other_thread_count"] = {k: share[k] for k in ("value", "cores", "sample")}
             line["cpu_baseline"] = base
             line["cpu_baseline"]["reference_faithful"] = cpu_reference_faithful(xs, ys, sigma, budget_s=6.0)
+            try:  # the same for BASELINE configs[0], CPU and device side by side (secondary figures)
+                line["cpu_baseline"]["reference_faithful_config1"] = cpu_reference_faithful_config1()
+                line["cpu_baseline"]["reference_faithful_config1"]["gpu_same_config"] = gpu_config1(dev)
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"]["reference_faithful_config1"] = {"error": repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

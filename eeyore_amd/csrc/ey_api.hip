@@ -462,14 +462,11 @@ int ey_hmc_run(ey_plan* pl, void* theta, void* target, void* grad, double step, 
       rc = ey_generic_hmc(pl, theta, target, grad, nullptr, nullptr, step, step_vec, L, temp, C, seed, iter,
                           chain_offset, flags, accepted, nullptr, nullptr, nullptr, s, &run);
     if (rc != EY_OK || !pl->mom_s1) return rc;
-    const size_t es = esize(pl);
-    for (int it = 0; it < n_iters; ++it) {
-      const void* th_it = n_iters > 1 ? (const void*)((const char*)samples + (size_t)it * C * pl->m.P * es) : theta;
-      const void* ac_it = accepted_rec ? (const void*)((const char*)accepted_rec + (size_t)it * C) : accepted;
-      rc = ey_stats_update(th_it, ac_it, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2, pl->mom_acc, stream);
-      if (rc) return rc;
-    }
-    return EY_OK;
+    if (n_iters == 1)
+      return ey_stats_update(theta, accepted_rec ? accepted_rec : accepted, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2,
+                             pl->mom_acc, stream);
+    return ey_stats_update_run(samples, accepted_rec, n_iters, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2, pl->mom_acc,
+                               stream);
   }
   // models beyond LDS: the layerwise path has no in-kernel iteration loop; the launches are queued back to back
   const size_t es = esize(pl);
@@ -522,14 +519,8 @@ static int moments_replay(ey_plan* pl, const EyRun* run, const void* theta, cons
                                                         pl->mom_acc, stream);
   int rcc = moments_replay_check(pl, run, who);
   if (rcc) return rcc;
-  const size_t es = esize(pl);
-  for (int it = 0; it < run->n_iters; ++it) {
-    int rc = ey_stats_update((const char*)run->samples + (size_t)it * C * pl->m.P * es,
-                             (const char*)run->accepted + (size_t)it * C, C, pl->m.P, pl->dtype, pl->mom_s1,
-                             pl->mom_s2, pl->mom_acc, stream);
-    if (rc) return rc;
-  }
-  return EY_OK;
+  return ey_stats_update_run(run->samples, run->accepted, run->n_iters, C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2,
+                             pl->mom_acc, stream);
 }
 
 // copy the state after one iteration of a host-looped run into the per-iteration records
@@ -779,6 +770,80 @@ __global__ void k_stats_update(const T* __restrict__ theta, double* __restrict__
 __global__ void k_acc_update(const unsigned char* __restrict__ accepted, double* __restrict__ acc, int64_t C) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) acc[c] += (double)accepted[c];
+}
+
+// The same sums over the n_it recorded iterations of a launch in ONE pass: every element's accumulators are read once,
+// take the element's n_it states in iteration order (the additions ey_stats_update would make launch after launch, or the
+// step kernel draw after draw: the same bits) and are written once -- the record buffer streams through (4 bytes per
+// state) instead of the f64 accumulators being read and written once per iteration (32 bytes per state).
+template <typename T>
+__global__ void k_stats_update_run(const T* __restrict__ samples, int n_it, double* __restrict__ s1, double* __restrict__ s2,
+                                   int64_t n4, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t b = 4 * i;
+    if (b + 3 < n && sizeof(T) == 4 && (n & 3) == 0) {
+      double2* p1 = reinterpret_cast<double2*>(s1 + b);
+      double2* p2 = reinterpret_cast<double2*>(s2 + b);
+      double2 a0 = p1[0], a1 = p1[1], q0 = p2[0], q1 = p2[1];
+      const float* src = reinterpret_cast<const float*>(samples) + b;
+      int it = 0;
+      for (; it + 4 <= n_it; it += 4) {  // four iterations' loads in flight
+        float4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const float4*>(src + (int64_t)(it + k) * n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          a0.x += t[k].x; a0.y += t[k].y; a1.x += t[k].z; a1.y += t[k].w;
+          q0.x += (double)t[k].x * t[k].x; q0.y += (double)t[k].y * t[k].y;
+          q1.x += (double)t[k].z * t[k].z; q1.y += (double)t[k].w * t[k].w;
+        }
+      }
+      for (; it < n_it; ++it) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)it * n);
+        a0.x += t.x; a0.y += t.y; a1.x += t.z; a1.y += t.w;
+        q0.x += (double)t.x * t.x; q0.y += (double)t.y * t.y; q1.x += (double)t.z * t.z; q1.y += (double)t.w * t.w;
+      }
+      p1[0] = a0; p1[1] = a1; p2[0] = q0; p2[1] = q1;
+    } else {
+      for (int64_t k = b; k < n && k < b + 4; ++k) {
+        double a = s1[k], q = s2[k];
+        for (int it = 0; it < n_it; ++it) {
+          const double t = (double)samples[(int64_t)it * n + k];
+          a += t;
+          q += t * t;
+        }
+        s1[k] = a;
+        s2[k] = q;
+      }
+    }
+  }
+}
+__global__ void k_acc_update_run(const unsigned char* __restrict__ accepted, int n_it, double* __restrict__ acc, int64_t C) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = acc[c];
+  for (int it = 0; it < n_it; ++it) a += (double)accepted[(int64_t)it * C + c];
+  acc[c] = a;
+}
+int ey_stats_update_run(const void* samples, const void* accepted_rec, int n_it, int64_t C, int64_t P, int dtype, void* s1,
+                        void* s2, void* acc, void* stream) {
+  if (!samples || !s1 || !s2) EY_FAIL(EY_ERR_INVALID, "ey_stats_update_run: null argument");
+  if (C <= 0 || P <= 0 || n_it <= 0) return EY_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = C * P, n4 = (n + 3) / 4;
+  const unsigned nb = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  if (dtype == EY_F32)
+    hipLaunchKernelGGL(k_stats_update_run<float>, dim3(nb), dim3(256), 0, s, (const float*)samples, n_it, (double*)s1,
+                       (double*)s2, n4, n);
+  else
+    hipLaunchKernelGGL(k_stats_update_run<double>, dim3(nb), dim3(256), 0, s, (const double*)samples, n_it, (double*)s1,
+                       (double*)s2, n4, n);
+  if (accepted_rec && acc)
+    hipLaunchKernelGGL(k_acc_update_run, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned char*)accepted_rec, n_it, (double*)acc, C);
+  EY_HIP(hipGetLastError());
+  return EY_OK;
 }
 
 extern "C" int ey_stats_update(const void* theta, const void* accepted, int64_t C, int64_t P, int dtype, void* s1,

@@ -148,6 +148,10 @@ struct EyRun {
   int* accept_count;  // [C] int32 (+=), or null
 };
 
+// the attached moments from the records of a launch, in one streaming pass (ey_api.hip)
+int ey_stats_update_run(const void* samples, const void* accepted_rec, int n_it, int64_t C, int64_t P, int dtype, void* s1,
+                        void* s2, void* acc, void* stream);
+
 // generic kernels (ey_generic.hip)
 int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                           void* target, void* grad, hipStream_t s);

@@ -1940,6 +1940,16 @@ static int mf_launch_v(MfArgs& a, int n_cu, hipStream_t s) {
   return EY_OK;
 }
 
+static bool mf_moments_from_records(const ey_plan* pl, const MfArgs& a) {
+  static const bool in_kernel = [] { const char* e = getenv("EY_MF_MOMENTS_IN_KERNEL"); return e && atoi(e) != 0; }();  // A/B knob
+  return pl->mom_s1 && a.rec_samples && a.rec_accepted && a.n_iters > 1 && !in_kernel;
+}
+static int mf_finish(ey_plan* pl, const MfArgs& a, int rc, hipStream_t s) {
+  if (rc != EY_OK || !mf_moments_from_records(pl, a)) return rc;
+  return ey_stats_update_run(a.rec_samples, a.rec_accepted, a.n_iters, a.C, pl->m.P, pl->dtype, pl->mom_s1, pl->mom_s2,
+                             pl->mom_acc, s);
+}
+
 #define MF_COMMA ,
 template <int MODE>
 static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
@@ -1959,7 +1969,10 @@ static int mf_launch(ey_plan* pl, MfArgs& a, hipStream_t s) {
     static const int stagger = [] { const char* e = getenv("EY_MF_STAGGER"); return e ? atoi(e) : 2; }();
     a.stagger = stagger;
   }
-  if (MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) {
+  // attached moments: accumulated by the kernel draw by draw -- unless the launch records samples and accept flags anyway
+  // (mf_moments_from_records): then one streaming pass over the records behind the launch makes the same sums, bit for bit
+  // (mf_finish), and the f64 accumulators are read and written once per launch instead of once per iteration
+  if ((MODE == MODE_HMC || MODE == MODE_MALA || MODE == MODE_MH) && !mf_moments_from_records(pl, a)) {
     a.mom_s1 = pl->mom_s1;
     a.mom_s2 = pl->mom_s2;
     a.mom_acc = pl->mom_acc;
@@ -2037,7 +2050,7 @@ int ey_mfma32_hmc(ey_plan* pl, void* theta, void* target, void* grad, const void
   a.recompute = (flags & EY_RECOMPUTE_INITIAL_GRAD) ? 1 : 0;
   a.accepted = (unsigned char*)accepted; a.rate = (float*)rate; a.hcur = (float*)hcur; a.hprop = (float*)hprop;
   mf_set_run(a, run);
-  return mf_launch<MODE_HMC>(pl, a, s);
+  return mf_finish(pl, a, mf_launch<MODE_HMC>(pl, a, s), s);
 }
 
 int ey_mfma32_mala(ey_plan* pl, void* theta, void* target, void* grad, const void* z, const void* u, double step,
@@ -2049,7 +2062,7 @@ int ey_mfma32_mala(ey_plan* pl, void* theta, void* target, void* grad, const voi
   a.step_vec = (const float*)step_vec; a.temp = (const float*)temp; a.seed = seed; a.iter = iter;
   a.chain_offset = chain_offset; a.accepted = (unsigned char*)accepted; a.rate = (float*)log_rate;
   mf_set_run(a, run);
-  return mf_launch<MODE_MALA>(pl, a, s);
+  return mf_finish(pl, a, mf_launch<MODE_MALA>(pl, a, s), s);
 }
 
 int ey_mfma32_mh(ey_plan* pl, void* theta, void* target, const void* z, const void* u, const void* scale,
@@ -2061,7 +2074,7 @@ int ey_mfma32_mh(ey_plan* pl, void* theta, void* target, const void* z, const vo
   a.seed = seed; a.iter = iter; a.chain_offset = chain_offset; a.accepted = (unsigned char*)accepted;
   a.rate = (float*)log_rate;
   mf_set_run(a, run);
-  return mf_launch<MODE_MH>(pl, a, s);
+  return mf_finish(pl, a, mf_launch<MODE_MH>(pl, a, s), s);
 }
 
 int ey_mfma32_log_target_grad(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* target, void* grad,

@@ -17,6 +17,9 @@
 // read adjacent series of one iteration.  A 256-thread workgroup stages BS series (all n values, centred, in double or
 // float as the input) in LDS as [i][BS]; 256/BS threads share the lag sums of a series.  Every lag pair costs 2n
 // multiply-adds per series from LDS; the loop ends when every series of the workgroup has stopped.  All sums in double.
+#include <algorithm>
+#include <cstdlib>
+
 #include "ey_common.h"
 
 #define ST_THREADS 256
@@ -561,25 +564,40 @@ extern "C" int ey_inse_multivariate(const void* x, int64_t n, int64_t C, int64_t
   if (dtype != EY_F32 && dtype != EY_F64) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: bad dtype");
   if (n < 2) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: at least two iterations are needed");
   if (p < 1 || p > MW_P) EY_FAIL(EY_ERR_UNSUPPORTED, "ey_inse_multivariate: 1 <= p <= 64 (use ey_inse_univariate per parameter beyond)");
-  if (n > 0x7fffffff / MW_P) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: too many iterations");
+  if (n > (0x7fffffff - 256) / MW_P) EY_FAIL(EY_ERR_INVALID, "ey_inse_multivariate: too many iterations");  // (32-bit loop indices up to n * 64 + the block size)
   const size_t bytes = (size_t)n * (size_t)p * sizeof(double);
   if (p > MV_PMAX || bytes > ST_LDS_BYTES) {  // the wide form: the centred chains in a workspace, matrices in LDS
     if (C <= 0) return EY_OK;
     hipStream_t s = (hipStream_t)stream;
+    // (everything that can fail before the workspace exists comes first; nothing returns between its allocation and its release)
+    EY_HIP(hipFuncSetAttribute(dtype == EY_F32 ? reinterpret_cast<const void*>(k_inse_mv_wide<float>)
+                                               : reinterpret_cast<const void*>(k_inse_mv_wide<double>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)MW_LDS_BYTES));
+    // The centred chains of one launch lie in a workspace of 64 columns per iteration whatever p is: bounded (EY_MV_WORKSPACE_MB,
+    // 1 GiB by default), the chains going through it in as many launches as that takes (4096 chains x 10 000 iterations would
+    // otherwise ask HIP's pool -- not torch's cache, which holds the device -- for 21 GB at once).
+    static const size_t cap = [] { const char* e = getenv("EY_MV_WORKSPACE_MB"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 1024) << 20; }();
+    const size_t per_chain = (size_t)n * MW_P * sizeof(double);
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(C, (int64_t)(cap / per_chain)));
     double* xcw = nullptr;
-    EY_HIP(hipMallocAsync((void**)&xcw, (size_t)C * (size_t)n * MW_P * sizeof(double), s));
-    if (dtype == EY_F32) {
-      EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inse_mv_wide<float>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)MW_LDS_BYTES));
-      hipLaunchKernelGGL(k_inse_mv_wide<float>, dim3((unsigned)C), dim3(ST_THREADS), MW_LDS_BYTES, s, (const float*)x, n, C,
-                         (int)p, stride_n, stride_c, xcw, (double*)sig, (double*)cov, (double*)mean, (int*)num_pairs);
-    } else {
-      EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_inse_mv_wide<double>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)MW_LDS_BYTES));
-      hipLaunchKernelGGL(k_inse_mv_wide<double>, dim3((unsigned)C), dim3(ST_THREADS), MW_LDS_BYTES, s, (const double*)x, n, C,
-                         (int)p, stride_n, stride_c, xcw, (double*)sig, (double*)cov, (double*)mean, (int*)num_pairs);
+    EY_HIP(hipMallocAsync((void**)&xcw, (size_t)chunk * per_chain, s));
+    const size_t es = dtype == EY_F32 ? sizeof(float) : sizeof(double);
+    hipError_t le = hipSuccess;
+    for (int64_t c0 = 0; c0 < C && le == hipSuccess; c0 += chunk) {
+      const int64_t cn = std::min<int64_t>(chunk, C - c0);
+      const char* xc = (const char*)x + (size_t)c0 * (size_t)stride_c * es;
+      double* sg = (double*)sig + c0 * p * p;
+      double* cv = cov ? (double*)cov + c0 * p * p : nullptr;
+      double* mn = mean ? (double*)mean + c0 * p : nullptr;
+      int* np_ = num_pairs ? (int*)num_pairs + c0 : nullptr;
+      if (dtype == EY_F32)
+        hipLaunchKernelGGL(k_inse_mv_wide<float>, dim3((unsigned)cn), dim3(ST_THREADS), MW_LDS_BYTES, s, (const float*)xc, n, cn,
+                           (int)p, stride_n, stride_c, xcw, sg, cv, mn, np_);
+      else
+        hipLaunchKernelGGL(k_inse_mv_wide<double>, dim3((unsigned)cn), dim3(ST_THREADS), MW_LDS_BYTES, s, (const double*)xc, n, cn,
+                           (int)p, stride_n, stride_c, xcw, sg, cv, mn, np_);
+      le = hipGetLastError();
     }
-    const hipError_t le = hipGetLastError();
     (void)hipFreeAsync(xcw, s);
     EY_HIP(le);
     return EY_OK;

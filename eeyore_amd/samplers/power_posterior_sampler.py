@@ -94,7 +94,12 @@ class PowerPosteriorSampler(SerialSampler):
         if self.num_replicas == 1:
             return ChainFile(keys=keys, path=folder, mode=mode)
         width = len(str(self.num_replicas))
-        return [ChainFile(keys=keys, path=folder / f"replica{r + 1:0{width}}", mode=mode) for r in range(self.num_replicas)]
+        handles = [ChainFile(keys=keys, path=folder / f"replica{r + 1:0{width}}", mode=mode) for r in range(self.num_replicas)]
+        # K x R x len(keys) descriptors would stay open until garbage collection (8 temperatures x 1024 replicas x 3 keys
+        # against a limit of 1024): ChainFile.update reopens its files anyway, so they are closed here
+        for handle in handles:
+            handle.close()
+        return handles
 
     # ---- ladder and partner distribution (power_posterior_sampler.py:84-125)
     def default_indicator(self):
@@ -210,9 +215,11 @@ class PowerPosteriorSampler(SerialSampler):
         if self.storage == 'list':
             chain.update(state)
             return
-        # on file: one row per saved iteration and replica, as ChainFile.update writes a single chain's state
+        # on file: one row per saved iteration and replica, as ChainFile.update writes a single chain's state; the [R, ...]
+        # state crosses to the host once per key, not once per replica
+        host = {k: v.detach().cpu() for k, v in state.items()}
         for r, handle in enumerate([chain] if R == 1 else chain):
-            handle.update({k: (int(v[r]) if k == 'accepted' else v[r]) for k, v in state.items()})
+            handle.update({k: (int(v[r]) if k == 'accepted' else v[r]) for k, v in host.items()})
 
     def draw(self, x, y, savestate=False):
         """power_posterior_sampler.py:174-182."""

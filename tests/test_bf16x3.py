@@ -283,3 +283,45 @@ def test_other_4_32_32_models_in_both_layouts(n_rows):
         got = out["accepted"].cpu().numpy()
         assert decided.sum() > 0.7 * C and (got[decided] == acc[decided]).all()
         np.testing.assert_allclose(out["h_prop"].cpu().numpy(), hp, rtol=3e-4, atol=3e-2)
+
+
+@pytest.mark.parametrize("n_rows", [33, 64, 150, 200, 256])
+def test_pipelined_tile_loop_equals_the_two_wave_form(n_rows):
+    """Variant bit 3: the HMC draw of the headline model with the pipelined tile loop (one wave per SIMD, two row tiles in
+    flight, eval_pipe / k_mfma32p; 2 .. 8 row tiles) against the shipped form (two waves per SIMD, one tile at a time).  The
+    arithmetic of a tile is the same operation for operation, so positions, gradients and accept decisions agree bit for
+    bit and the log-targets to an ulp (the row sums of the log-likelihood contract differently); each also against the f64
+    oracle; a launch of several iterations with records equals single launches."""
+    rec = _headline()
+    pl, x, y = _plan(rec, n_rows=n_rows)
+    o64 = COracle(rec["dims"].tolist(), rec["acts"].tolist(), int(rec["lik"]), np.asarray(x, np.float32).astype(np.float64), y,
+                  rec["prior_mu"], np.asarray(rec["prior_sigma"], np.float32).astype(np.float64), dtype=np.float64, nthreads=8)
+    C, L, step = 40, 7, 0.02
+    th0 = (0.2 * pl.philox_normal(C, seed=77 + n_rows, it=0)).contiguous()
+    t0, g0 = pl.log_target_grad(th0)
+    res = {}
+    for variant in (0, 8):
+        pl.set_variant(variant)
+        a = [th0.clone(), t0.clone(), g0.clone()]
+        out = pl.hmc_step(a[0], a[1], a[2], step, L, seed=9, it=1)
+        one = [v.clone() for v in a] + [out["accepted"].clone(), out["h_prop"].clone()]
+        samples, targets, acc = pl.empty(4, C, pl.P), pl.empty(4, C), pl.empty(4, C, dtype=torch.uint8)
+        pl.hmc_run(a[0], a[1], a[2], step, L, 4, seed=9, it=2, samples=samples, targets=targets, accepted_rec=acc)
+        b = [v.clone() for v in one[:3]]
+        for i in range(4):
+            pl.hmc_step(b[0], b[1], b[2], step, L, seed=9, it=2 + i)
+            assert torch.equal(samples[i], b[0]) and torch.equal(targets[i], b[1])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+        res[variant] = one + [a[0].clone(), a[1].clone()]
+    pl.set_variant(0)
+    v0, v8 = res[0], res[8]
+    assert torch.equal(v0[0], v8[0]) and torch.equal(v0[2], v8[2]) and torch.equal(v0[3], v8[3]) and torch.equal(v0[5], v8[5])
+    np.testing.assert_allclose(v8[1].cpu().numpy(), v0[1].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(v8[4].cpu().numpy(), v0[4].cpu().numpy(), rtol=1e-6, atol=1e-3)
+    assert 0 < int(v8[3].sum().item())
+    # the leapfrog's end point through the oracle: the proposal of an accepted chain
+    thn, tn, gn = th0.cpu().numpy().astype(np.float64), t0.cpu().numpy(), g0.cpu().numpy()
+    for c in np.flatnonzero(v8[3].cpu().numpy())[:6]:
+        tt, gg, _, _ = o64.log_target_grad(v8[0][c].cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(v8[1][c].item(), tt, rtol=2e-6, atol=2e-4)
+        np.testing.assert_allclose(v8[2][c].cpu().numpy(), gg, rtol=1e-5, atol=2e-6 * max(1.0, np.abs(gg).max()))

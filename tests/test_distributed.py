@@ -275,3 +275,94 @@ def test_bench_launcher_reports_a_failed_rank():
     """A rank that dies makes the launcher exit non-zero (here: a world size the children refuse)."""
     rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--chains-per-gpu", "not-a-number"])
     assert rc != 0
+
+
+# ----------------------------------------------------------------------------------- eight ranks, uneven shards (gloo)
+# BASELINE configs[3] and [4] run on eight GPUs, and no 8-GPU node is available to this suite: these tests take the
+# whole multi-rank path -- chain statistics, sharded multi_rhat, the tempering exchange, bench.py's own launcher --
+# through eight gloo ranks holding DIFFERENT numbers of chains, so that the first RCCL run is not also the first 8-rank run.
+_EIGHT_COUNTS = [3, 1, 2, 4, 1, 3, 2, 1]  # chains per rank: 17 in all
+
+
+def _ar_chains(C=17, n=400, p=3):
+    rng = np.random.default_rng(7)
+    x = np.zeros((C, n, p))
+    e = rng.standard_normal((C, n, p))
+    x[:, 0] = e[:, 0]
+    for i in range(1, n):
+        x[:, i] = 0.6 * x[:, i - 1] + e[:, i]
+    return torch.tensor(x + 0.05 * rng.standard_normal((C, 1, p)))
+
+
+def _eight_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import eeyore_amd.stats as st
+    from eeyore_amd.distributed import TemperingExchange, multi_rhat_from_local_parts
+    x = _ar_chains()
+    off = sum(_EIGHT_COUNTS[:rank])
+    mine = x[off:off + _EIGHT_COUNTS[rank]]
+    # (a) running-moment R-hat summary: one all-reduce of [3, P]
+    acc = torch.ones(mine.shape[0], dtype=torch.bool)
+    s = ChainStats(mine.shape[0], mine.shape[2], "cpu")
+    for i in range(mine.shape[1]):
+        s.update(mine[:, i], acc)
+    summ = s.summary()
+    # (b) the sharded multi_rhat: all-reduce of the sum of MC covariances, all-gather of the (padded) chain means
+    w_sum = sum(st.inse_mc_cov(c) for c in mine)
+    r = multi_rhat_from_local_parts(w_sum, mine.mean(1), x.shape[1])
+    # (c) the tempering exchange: eight ladder positions, one per rank
+    temps = [(i / world) ** 4 for i in range(1, world + 1)]
+    ex = TemperingExchange(temps, 20, rank, world, "cpu", seed=5, decide=_torch_decide)
+    hist = []
+    for it in range(8):
+        g = torch.Generator().manual_seed(1000 * it + rank)
+        ex.exchange(-50.0 + 10.0 * torch.randn(20, generator=g, dtype=torch.float64))
+        hist.append(ex.labels.clone())
+    q.put((rank, summ["rhat"].numpy(), summ["num_chains"], float(r[0]), r[2].numpy(), torch.stack(hist).numpy(), ex.num_swaps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_with_uneven_shards_agree_with_one_process():
+    import eeyore_amd.stats as st
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    x = _ar_chains()
+    one = _summary(x, torch.ones(x.shape[0], x.shape[1], dtype=torch.bool))
+    ref = st.multi_rhat(x)
+    for r in range(world):
+        rhat, m, mrhat, W, labels, swaps = got[r]
+        assert m == 17
+        np.testing.assert_allclose(rhat, one["rhat"].numpy(), rtol=1e-11)
+        np.testing.assert_allclose(mrhat, float(ref[0]), rtol=1e-10)
+        np.testing.assert_allclose(W, ref[2].numpy(), rtol=1e-10, atol=1e-14)
+    labels = np.stack([got[r][4] for r in range(world)])  # [rank, attempt, replica]
+    assert (np.sort(labels, axis=0) == np.arange(world)[:, None, None]).all()  # a permutation of the ladder at every attempt
+    assert len({got[r][5] for r in range(world)}) == 1 and got[0][5] > 0
+    assert np.abs(np.diff(labels, axis=1)).max() <= 1
+
+
+def test_bench_dry_run_with_eight_ranks():
+    """`python bench.py --gpus 8 --dry-run` (gloo): the launcher, the rendezvous, the MAX over eight ranks and the two
+    statistics collectives of the measuring run (R-hat summary, ESS gather) over uneven shards; one JSON line."""
+    rc, lines, err = _run_bench(["--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-run"],
+                                {"EEYORE_DIST_BACKEND": "gloo"}, timeout=600)
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["dry_run"] is True and lines[0]["value"] is None
+    col = lines[0]["config"]["collectives"]
+    assert col["rhat_num_chains"] == col["ess_num_chains"] == col["expected_num_chains"] == sum(3 + r % 3 for r in range(8))
+    assert np.isfinite(col["rhat_max"])
+    assert lines[0]["ms_per_step"] * 20 >= 80.0 - 1e-6  # the slowest of the eight ranks (sleeps 80 ms) sets the time

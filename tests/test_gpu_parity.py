@@ -960,6 +960,45 @@ def test_attached_moments_equal_a_separate_stats_pass(force_generic):
     pl.hmc_step(th[:10].clone(), t[:10].clone(), g[:10].clone(), 0.05, 2, seed=1, it=1)
 
 
+def test_attached_moments_of_a_recorded_run_come_from_the_records():
+    """A launch of several iterations that records samples and accept flags leaves the attached moments to ONE streaming
+    pass over the records (ey_stats_update_run: the f64 accumulators are read and written once per launch, not once per
+    iteration): the sums must be those of one ey_stats_update per recorded iteration, bit for bit -- HMC, MALA, MH; and the
+    same launch without records (moments in the kernel) must agree with both."""
+    from eeyore_amd.distributed import ChainStats
+    rec, pl = _cfg3_plan()
+    C, n_it = 300, 6
+    th0 = 0.2 * pl.philox_normal(C, seed=18, it=0)
+    t0, g0 = pl.log_target_grad(th0)
+    scale = torch.full((pl.P,), 0.01, dtype=torch.float32, device=DEV)
+    for kind in ("hmc", "mala", "mh"):
+        got = {}
+        for recorded in (True, False):
+            st = ChainStats(C, pl.P, DEV)
+            st.attach(pl)
+            th, t, g = th0.clone(), t0.clone(), g0.clone()
+            kw = {}
+            if recorded:
+                samples, acc = pl.empty(n_it, C, pl.P), pl.empty(n_it, C, dtype=torch.uint8)
+                kw = dict(samples=samples, accepted_rec=acc)
+            if kind == "hmc":
+                pl.hmc_run(th, t, g, 0.05, 6, n_it, seed=8, it=1, **kw)
+            elif kind == "mala":
+                pl.mala_run(th, t, g, 0.002, n_it, seed=8, it=1, **kw)
+            else:
+                pl.mh_run(th, t, scale, n_it, seed=8, it=1, **kw)
+            torch.cuda.synchronize()
+            got[recorded] = (st.s1.clone(), st.s2.clone(), st.acc.clone(), th.clone())
+            pl.detach_moments()
+        ref = ChainStats(C, pl.P, DEV)
+        for i in range(n_it):
+            ref.update(samples[i], acc[i])
+        assert 0 < int(acc.sum().item()) < n_it * C
+        for a, b in ((got[True], (ref.s1, ref.s2, ref.acc)), (got[False], (ref.s1, ref.s2, ref.acc))):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), kind
+        assert torch.equal(got[True][3], got[False][3])
+
+
 def test_mfma32_philox_and_per_chain_step():
     rec, pl = _cfg3_plan()
     C = 256
