@@ -639,6 +639,13 @@ def main():
                 line["roofline"]["traffic"] = ((2.0 * pm["FETCH_SIZE_KB"] + pm["WRITE_SIZE_KB"]) * 1024.0 * ipl
                                                / pm.get("iterations_per_launch", 1))
                 line["roofline"]["traffic_source"] = pm.get("source", "profiles/pmc_latest.json")
+                if "behind_every_launch" in pm:  # the moments pass over the records (ey_stats_update_run), per launch
+                    b = pm["behind_every_launch"]
+                    line["roofline"]["traffic_of_the_moments_pass_behind_each_launch"] = (2.0 * b["FETCH_SIZE_KB"] + b["WRITE_SIZE_KB"]) * 1024.0
+                line["roofline"]["traffic_algorithmic"] = {
+                    "survey_8d_bytes_per_launch": (2 * P + P) * 4 * C * ipl,
+                    "note": "SURVEY 8(d): (2 P + P_store) * 4 / L bytes per leapfrog step per chain = theta and gradient in, the "
+                            "recorded sample out, per iteration; an accepted draw also writes theta and the gradient back"}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 figure (the other ranks would wait for it)
             # BASELINE.md section 3 item 3, "generous CPU": one chain per hardware thread on ALL threads this process may
             # use; beside it the 16 threads that are a one-GPU box's share of the host, and the reference-faithful path

@@ -51,13 +51,17 @@ def test_bench_contract_small_run():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
-    # --steps is rounded up to whole launches of 25 iterations (what HMC.run issues); the line says what was asked for
-    assert d["n_gpus"] == 1 and d["steps"] == 25 and d["config"]["steps_requested"] == 3 and d["vs_baseline"] is None
+    # --steps is rounded up to whole launches of 25 iterations (what HMC.run issues), at least five of them (one 21 ms launch is
+    # one sample of a quantity that moves by 10 %); `steps` is what was timed and the line says what was asked for
+    assert d["n_gpus"] == 1 and d["steps"] == 125 and d["config"]["steps_requested"] == 3 and d["vs_baseline"] is None
     assert d["config"]["iterations_per_launch"] == 25 and "rounded up" in d["config"]["steps_note"]
+    assert d["config"]["launches_timed"] == 5
+    assert 0 < d["config"]["launch_ms_min"] <= d["config"]["launch_ms_median"] <= d["config"]["launch_ms_max"]
+    assert abs(d["ms_per_step"] * 125 - 5 * d["config"]["launch_ms_median"]) < 0.5 * d["ms_per_step"] * 125
     # the timed region records the chains as HMC.run does, and the same workload through the sampler surface is beside it
     assert d["config"]["recorded_in_timed_region"].startswith("samples [steps, C, P]")
     via = d["config"]["through_sampler_run"]
-    assert via["iterations"] == 25 and 0.5 < via["ratio_to_headline"] < 1.5 and 0 < via["acceptance"] <= 1
+    assert via["iterations"] == 125 and 0.5 < via["ratio_to_headline"] < 1.5 and 0 < via["acceptance"] <= 1
     assert 0 < d["roofline"]["frac_exact_f32_products"] < d["roofline"]["frac"] and 0 < d["roofline"]["bf16_pipe_flops_frac"] < 1
     # the arithmetic type is f32; the default form of the kernel's products is named beside it, both forms' rates recorded
     assert d["dtype"] == "f32 (bf16x3 products, f32 accumulate)" and d["config"]["f32_products"] == "bf16x3"
@@ -68,6 +72,9 @@ def test_bench_contract_small_run():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 100 * cb["value"]
+    # the reference's own op sequence timed for BASELINE configs[0] too, the device's figure for it beside it
+    c1 = cb["reference_faithful_config1"]
+    assert "error" not in c1 and c1["value"] > 0 and c1["gpu_same_config"]["value"] > c1["value"]
     # the ESS gather runs on the driver-sized run too, and the secondary figure (config 5's share of one GPU) is beside the metric
     assert d["config"]["ess"]["num_chains"] == 512 and d["config"]["ess"]["mean"] > 0
     sec = d["config"]["secondary"]["config5_share_one_gpu"]

@@ -12,5 +12,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BA
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/d -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_ANY SQ_LEVEL_WAVES SQ_WAVES --output-format csv -d $OUT/e -- $CMD > /dev/null 2>&1
-python3 tools/pmc_summary.py $OUT "k_mfma32<0" $OUT/pmc_latest.json 25 > $OUT/summary.txt
+python3 tools/pmc_summary.py $OUT "k_mfma32<0" $OUT/pmc_latest.json 25 k_stats_update_run > $OUT/summary.txt
 cat $OUT/summary.txt
