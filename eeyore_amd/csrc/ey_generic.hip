@@ -57,6 +57,15 @@ __device__ inline T dact_fn(int code, T h) {
   }
 }
 
+// A lane-strided pass over n elements with the SAME trip count in every lane: index i = lane + 64 k clamped to n - 1, `on`
+// saying whether the lane's element exists.  A lane beyond n in the last round repeats the work of element n - 1's owner --
+// the same inputs, hence the same bits to the same address -- and must keep its terms out of sums (select the term's
+// INPUT to zero, so that the expression contracts as it did).  No memory operation behind a per-lane branch, no
+// loop-carried register under a partial EXEC mask.
+#define EY_LANE_PASS(n, i, on)                                                                               \
+  for (int ey_k_ = 0, ey_n_ = (n), i = lane < ey_n_ ? lane : ey_n_ - 1, on = lane < ey_n_; ey_k_ < (ey_n_ + WAVE - 1) / WAVE; \
+       ++ey_k_, on = lane + ey_k_ * WAVE < ey_n_, i = on ? lane + ey_k_ * WAVE : ey_n_ - 1)
+
 template <typename T>
 __device__ inline T wave_sum(T v) {
 #pragma unroll
@@ -279,7 +288,7 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
           const T o = out[j];
           const T yy = valid ? y[(size_t)n * dK + j] : T(0);
           const T term = Num<T>::log(o) * yy + Num<T>::log(T(1) - o) * (T(1) - yy);
-          if (valid) lik += term;
+          lik += valid ? term : T(0);
           row_lik += term;
           if (GRAD) {
             const T dd = (yy / o - (T(1) - yy) / (T(1) - o)) * dact_fn<T>(act_out, o);
@@ -300,7 +309,7 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
           if (j == lab) olab = out[j];
         }
       row_lik = olab - (mx + Num<T>::log(ssum));
-      if (valid) lik += row_lik;
+      lik += valid ? row_lik : T(0);
       if (GRAD) {
 #pragma unroll
         for (int j = 0; j < TINY_DH; ++j)
@@ -375,7 +384,7 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
       T v = src[0];
       for (int w = 1; w < rw.nw; ++w) v += src[w * WAVE];
       const T tot = tiny_wsum<T>(v);
-      if (lane == 0) totals[idx] = tot;
+      totals[idx] = tot;  // (wave-uniform: every lane stores it)
     }
     __syncthreads();
     if (GRAD)
@@ -394,12 +403,14 @@ __device__ __forceinline__ T tiny_rows(const EyModel& m, const T* th, T* gr, boo
 #pragma unroll
             for (int i = 0; i < (k == 0 ? TINY_D0 : TINY_DH); ++i)
               if (i < din) {
+                // (the total is wave-uniform: every lane stores it -- no store behind a per-lane branch while the
+                // partial gradients of all the other elements are live in registers)
                 const T tot = tiny_wsum<T>(G[k][j][i]);
-                if (lane == 0) gr[m.woff[k] + j * din + i] = tot;
+                gr[m.woff[k] + j * din + i] = tot;
               }
             if (m.boff[k] >= 0) {
               const T tot = tiny_wsum<T>(GB[k][j]);
-              if (lane == 0) gr[m.boff[k] + j] = tot;
+              gr[m.boff[k] + j] = tot;
             }
           }
       }
@@ -572,9 +583,12 @@ __device__ T eval_target(const EyModel& m, const Lds<T>& l, const T* th, T* gr, 
   const T* mu = static_cast<const T*>(m.mu);
   const T* iv = static_cast<const T*>(m.inv_var);
   T q = T(0);
-  for (int i = lane; i < m.P; i += WAVE) {
+  // (EY_LANE_PASS: the same trip count in every lane -- a sum carried across a loop whose last round runs under a partial
+  // EXEC mask is what the fast-allocator build of this unit got wrong)
+  EY_LANE_PASS(m.P, i, on) {
     const T d = th[i] - mu[i];
-    q += d * d * iv[i];
+    const T dz = on ? d : T(0);
+    q += dz * dz * iv[i];
     if (GRAD) {
       T g = gr[i] - d * iv[i];
       if (has_temp) g *= temp;
@@ -642,12 +656,13 @@ __global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_hmc(EyModel m, T*
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   T kin = T(0);
   if (!p0) fill_normals<T>(p, rn, P);
-  for (int i = lane; i < P; i += WAVE) {
+  EY_LANE_PASS(P, i, on) {
     l.th[i] = theta[c * P + i];
     l.gr[i] = grad[c * P + i];
     const T pi = p0 ? p0[c * P + i] : p[i];
     p[i] = pi;
-    kin += pi * pi;
+    const T pz = on ? pi : T(0);
+    kin += pz * pz;
   }
   kin = wave_sum(kin);
   const T t_cur = t_state;
@@ -664,7 +679,10 @@ __global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_hmc(EyModel m, T*
     for (int i = lane; i < P; i += WAVE) p[i] = p[i] + w * l.gr[i];
   }
   kin = T(0);
-  for (int i = lane; i < P; i += WAVE) kin += p[i] * p[i];  // p -> -p leaves it unchanged (hmc.py:122)
+  EY_LANE_PASS(P, i, on) {  // p -> -p leaves it unchanged (hmc.py:122)
+    const T pz = on ? p[i] : T(0);
+    kin += pz * pz;
+  }
   kin = wave_sum(kin);
   const T h_prop = -t + T(0.5) * kin;
   T rate = Num<T>::exp(h_cur - h_prop);  // hmc.py:143-146
@@ -762,7 +780,7 @@ __global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_mala(EyModel m, T
   const EyRng rn = ey_rng_make(seed, chain_offset + (uint64_t)c, iter, EY_STREAM_NORMAL);
   T qf = T(0);
   if (!z_in) fill_normals<T>(prop, rn, P);
-  for (int i = lane; i < P; i += WAVE) {
+  EY_LANE_PASS(P, i, on) {
     const T th = theta[c * P + i], g = grad[c * P + i];
     l.th[i] = th;
     l.gr[i] = g;
@@ -770,15 +788,15 @@ __global__ void __launch_bounds__(RW ? RW_MAX * WAVE : WAVE) k_mala(EyModel m, T
     const T loc = th + T(0.5) * eps * g;  // kernel_mean (mala.py:35-36)
     const T pr = loc + sc * zi;           // Normal(loc, scale).sample()
     prop[i] = pr;
-    const T d = pr - loc;
+    const T d = on ? pr - loc : T(0);
     qf += d * d;
   }
   __syncthreads();
   const T tv = eval_target<T, true, TINY>(m, l, prop, gp, ht, tc, nullptr, nullptr, nullptr, rw);
   T qb = T(0);
-  for (int i = lane; i < P; i += WAVE) {
+  EY_LANE_PASS(P, i, on) {
     const T loc2 = prop[i] + T(0.5) * eps * gp[i];
-    const T d = l.th[i] - loc2;
+    const T d = on ? l.th[i] - loc2 : T(0);
     qb += d * d;
   }
   qf = wave_sum(qf);

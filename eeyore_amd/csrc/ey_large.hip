@@ -1437,6 +1437,15 @@ static int bgemm(const BGT<double>& g, int batch, hipStream_t s, int* cursor = n
   return EY_OK;
 }
 
+// A thread-strided pass over n elements with the SAME trip count in every thread (see EY_LANE_PASS in ey_generic.hip): index
+// i clamped to n - 1, `on` saying whether the thread's element exists.  Sums select their term's input to zero for a thread
+// beyond n: no register carried across a loop whose last round runs under a partial EXEC mask.
+#define EY_THREAD_PASS(n, i, on)                                                                                      \
+  for (int ey_k_ = 0, ey_n_ = (n), ey_s_ = (int)blockDim.x, i = (int)threadIdx.x < ey_n_ ? (int)threadIdx.x : ey_n_ - 1, \
+           on = (int)threadIdx.x < ey_n_;                                                                             \
+       ey_k_ < (ey_n_ + ey_s_ - 1) / ey_s_;                                                                           \
+       ++ey_k_, on = (int)threadIdx.x + ey_k_ * ey_s_ < ey_n_, i = on ? (int)threadIdx.x + ey_k_ * ey_s_ : ey_n_ - 1)
+
 template <class T>
 __device__ __forceinline__ T block_sum(T v, T* red) {
 #pragma unroll
@@ -1499,8 +1508,8 @@ __global__ void __launch_bounds__(256) k_prior(const T* __restrict__ theta, cons
   const long c = blockIdx.x;
   const T t = temp ? temp[c] : T(1.0);
   T q = T(0.0);
-  for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    const T d = theta[c * P + i] - mu[i];
+  EY_THREAD_PASS(P, i, on) {
+    const T d = on ? theta[c * P + i] - mu[i] : T(0.0);
     q += d * d * iv[i];
   }
   q = block_sum(q, red);
@@ -1525,20 +1534,26 @@ __global__ void __launch_bounds__(256) k_hmc_begin(const T* __restrict__ theta, 
   // momentum (hmc.py:134): one block of four stream elements per thread and round (one Philox call each).  The arrays are
   // distinct (__restrict__) and the rounds unrolled by four, so that the loads of four rounds are in flight together: as
   // plain pointers every element's copy waited for the store before it (5.6 ms for config 5's share, 1.2 TB/s)
+  // (the same number of rounds in every thread, the kinetic energy summed outside the per-element branch: DESIGN.md 4.4)
+  const int nb4 = (P + 3) / 4, rounds = (nb4 + (int)blockDim.x - 1) / (int)blockDim.x;
 #pragma unroll 4
-  for (int b = threadIdx.x; 4 * b < P; b += blockDim.x) {
+  for (int r = 0; r < rounds; ++r) {
+    const int b = (int)threadIdx.x + r * (int)blockDim.x;
     T o[4];
     if (!p0) ey_rng_normal4<T>(rn, (uint32_t)b, o);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = 4 * b + j;
-      if (i >= P) break;
-      const long k = c * P + i;
+      const bool on = i < P;
+      const long k = c * P + (on ? i : P - 1);
       const T pv = p0 ? p0[k] : o[j];
-      p[k] = pv;
-      kin += pv * pv;
-      thp[k] = theta[k];
-      gp[k] = grad[k];
+      const T pz = on ? pv : T(0.0);
+      kin += pz * pz;
+      if (on) {
+        p[k] = pv;
+        thp[k] = theta[k];
+        gp[k] = grad[k];
+      }
     }
   }
   kin = block_sum(kin, red);
@@ -1578,12 +1593,14 @@ __global__ void __launch_bounds__(256) k_leap(T* thp, T* p, const T* gp, int P, 
   for (int j = 0; j < LEAP_EPT; ++j) {
     const int i = i0 + j * 256;
     const long k = c * P + i;
+    if (wp != T(0.0)) pv[j] = pv[j] + ep * gv[j];
+    if (wt != T(0.0)) tv[j] = tv[j] + et * pv[j];
     if (i < P) {
-      if (wp != T(0.0)) { pv[j] = pv[j] + ep * gv[j]; p[k] = pv[j]; }
-      if (wt != T(0.0)) { tv[j] = tv[j] + et * pv[j]; thp[k] = tv[j]; }
-      const T d = tv[j] - mv[j];
-      q += d * d * vv[j];
+      if (wp != T(0.0)) p[k] = pv[j];
+      if (wt != T(0.0)) thp[k] = tv[j];
     }
+    const T d = tv[j] - mv[j];  // (an element beyond P holds zeros throughout: the sum stays outside the per-thread branch)
+    q += d * d * vv[j];
   }
   q = block_sum(q, red);
   if (threadIdx.x == 0) qpart[c * gridDim.x + blockIdx.x] = q;
@@ -1599,7 +1616,10 @@ __global__ void __launch_bounds__(256) k_target(const T* __restrict__ qpart, int
   const int lane = threadIdx.x & 63;
   if (c >= C) return;
   T q = T(0.0);
-  for (int j = lane; j < nblk; j += 64) q += qpart[(long)c * nblk + j];
+  for (int r = 0; r < (nblk + 63) / 64; ++r) {  // (the same trip count in every lane)
+    const int j = lane + 64 * r;
+    q += j < nblk ? qpart[(long)c * nblk + j] : T(0.0);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   if (lane != 0) return;
@@ -1621,7 +1641,10 @@ __global__ void __launch_bounds__(256) k_hmc_end(T* __restrict__ theta, T* __res
   __shared__ int s_acc;
   const long c = blockIdx.x;
   T kin = T(0.0);
-  for (int i = threadIdx.x; i < P; i += blockDim.x) kin += p[c * P + i] * p[c * P + i];
+  EY_THREAD_PASS(P, i, on) {
+    const T pz = on ? p[c * P + i] : T(0.0);
+    kin += pz * pz;
+  }
   kin = block_sum(kin, red);
   if (threadIdx.x == 0) {
     const T h_prop = -tprop[c] + T(0.5) * kin;

@@ -750,7 +750,9 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
         ssum += e[o];
         if (o > 0) llab = lab == o ? lg[o] : llab;
       }
-      if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
+      // (need_value is wave-uniform; which lanes' rows count is a selection, not a branch: a register the allocator spills and
+      // reloads inside a per-lane branch of the tile loop comes back with its other lanes lost)
+      if (need_value) lik += (valid && h == 0) ? llab - (mx + __logf(ssum)) : 0.0f;
       if (!GRAD) return;  // nothing was written to LDS in this tile
       const float rs = __builtin_amdgcn_rcpf(ssum);
 #pragma unroll
@@ -762,7 +764,7 @@ __device__ float eval(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th, Vec
       const float yy = __int_as_float(lab);
       const bool valid = yy >= 0.0f;
       const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(NEG_LOG2E * lg[0]));
-      if (need_value && valid && h == 0) lik += __logf(pr) * yy + __logf(1.0f - pr) * (1.0f - yy);
+      if (need_value) lik += (valid && h == 0) ? __logf(pr) * yy + __logf(1.0f - pr) * (1.0f - yy) : 0.0f;
       if (!GRAD) return;
       d2[0] = valid ? (yy / pr - (1.0f - yy) / (1.0f - pr)) * (pr * (1.0f - pr)) : 0.0f;
     }
@@ -1263,7 +1265,9 @@ __device__ float eval_pipe(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th
             }
           }
           if constexpr (k == 5) {
-            if (need_value && valid && h == 0) lik += llab - (mx + __logf(ssum));
+            // (need_value is wave-uniform; which lanes' rows count is a selection, not a branch: a register the allocator spills and
+      // reloads inside a per-lane branch of the tile loop comes back with its other lanes lost)
+      if (need_value) lik += (valid && h == 0) ? llab - (mx + __logf(ssum)) : 0.0f;
             rs = __builtin_amdgcn_rcpf(ssum);
           }
           if constexpr (k == 7) {
@@ -1278,7 +1282,7 @@ __device__ float eval_pipe(KArgs& A, const float* xs, float* lw, Vec<SH::DK>& th
             const float yy = __int_as_float(lab);
             valid = yy >= 0.0f;
             const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(NEG_LOG2E * lg[0]));
-            if (need_value && valid && h == 0) lik += __logf(pr) * yy + __logf(1.0f - pr) * (1.0f - yy);
+            if (need_value) lik += (valid && h == 0) ? __logf(pr) * yy + __logf(1.0f - pr) * (1.0f - yy) : 0.0f;
             d2[0] = valid ? (yy / pr - (1.0f - yy) / (1.0f - pr)) * (pr * (1.0f - pr)) : 0.0f;
           }
         }
