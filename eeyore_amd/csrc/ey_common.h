@@ -152,6 +152,10 @@ struct EyRun {
 int ey_stats_update_run(const void* samples, const void* accepted_rec, int n_it, int64_t C, int64_t P, int dtype, void* s1,
                         void* s2, void* acc, void* stream);
 
+// fused value + gradient of mid-size MLPs, f32 (ey_mid.hip)
+bool ey_mid_supports(const ey_plan* pl);
+int ey_mid_eval(ey_plan* pl, const float* theta, const float* temp, int C, float* lik_o, float* grad, hipStream_t s);
+
 // generic kernels (ey_generic.hip)
 int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,
                           void* target, void* grad, hipStream_t s);

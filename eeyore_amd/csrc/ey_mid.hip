@@ -1,0 +1,557 @@
+// Fused value + gradient of a MID-SIZE MLP (hidden widths 33 .. 128, one or two hidden layers, a narrow output layer), f32:
+// ONE launch per evaluation, one persistent 8-wave workgroup per chain at a time, the chain's weights resident in LDS for
+// all of its row tiles and the weight-gradient accumulators resident in registers.
+//
+// The layerwise path (ey_large.hip) serves such a model as one batched GEMM launch per layer and direction; at K = 100 a
+// workgroup of those products is seven k-chunks between a prologue and an epilogue of one memory round trip each, and
+// MLP(20-100-100-5) ran at a quarter of the f32 matrix peak, MLP(10-100-10) at a tenth.  Here a chain's theta (<= ~60 KB) is
+// staged in LDS once per evaluation and the chain's rows go through it 32 at a time:
+//   * the workgroup is 2 row groups x 4 feature blocks: wave (rt, fb) owns features 32 fb .. 32 fb + 31 of every hidden
+//     layer for the row tiles 2 k + rt; both groups share the weight images, each has its own activation buffers;
+//   * every layer is computed transposed, H_l^T = W_l H_{l-1}^T, on v_mfma_f32_32x32x2_f32 (accumulator register 4q + j of
+//     lane (c, h) <-> feature 8q + 4h + j of row c), operands read from LDS with ds_read_b128 along k (k-step (u, j) gives
+//     k-slot h the index 8u + 4h + j in both operands);
+//   * the narrow output layer (d_K <= 16) is not a matrix product: every wave dots its 32 features of H with the output
+//     weights on the vector ALUs, the four partial logits per (row, output) meet in LDS, one wave finishes the loss;
+//   * backward: dW_l = delta_{l+1}^T H_l contracts over the tile's 32 rows (16 MFMAs per 32 x 32 block pair, the pairs of a
+//     layer dealt round-robin to the four waves of a group, accumulated in registers across ALL row tiles of the chain);
+//     delta_l = (delta_{l+1} W_l) * act'(H_l) takes act'(H_l) from the registers the forward pass left it in and
+//     overwrites H_l's LDS buffer;
+//   * at the end the two row groups' accumulators meet through LDS, the prior gradient and the temperature are applied
+//     (bayesian_model.py:46-50, :33-34) and the gradient is written once.
+// Reference semantics: MLP.forward eeyore/models/mlp.py:45-50, CE / BCE sums eeyore/constants/constants.py:15-18 and
+// eeyore/stats/loss.py:1-11, the gradient eeyore/models/log_target_model.py:15-23 (autograd there).
+#include <algorithm>
+#include <cstdlib>
+
+#include "ey_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MID_NL 3  // layers at most (two hidden layers and the output layer)
+
+struct MidArgs {
+  const float* theta;   // [C, P]
+  const float* x;       // [N, d0]
+  const float* y;       // [N, dK]
+  const int* labels;    // [N]
+  const float* mu;      // [P]
+  const float* iv;      // [P]
+  const float* temp;    // [C] or null
+  float* lik_o;         // [C]: the untempered log-likelihood
+  float* grad;          // [C, P]: gradient of the tempered log-target
+  int C, N, P, nl, lik, prior_uniform;
+  float mu0, iv0;
+  int dims[MID_NL + 1], woff[MID_NL], boff[MID_NL], act[MID_NL];
+  // LDS carve, in floats
+  int w_at[MID_NL], ldw[MID_NL];  // weights of layer l: [d_{l+1}][ldw], columns beyond d_l zero
+  int b_at[MID_NL];               // bias of layer l: [roundup32(d_{l+1})], zero beyond d_{l+1} / when the layer has none
+  int grp_at, grp_floats;         // the two row groups' regions
+  int h_at[MID_NL], ldh[MID_NL];  // inside a region: the data tile (l = 0) and H_l / delta_l (l >= 1): [32][ldh]
+  int d3_at;                      // delta of the output layer [32][16 + 4]
+  int pl_at, dkp;                 // partial logits [4 waves][dkp][32 rows]
+  int total_floats;
+};
+
+__device__ __forceinline__ float mid_act(int code, float g) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+    case EY_ACT_TANH: return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * g)) - 1.0f;
+    case EY_ACT_RELU: return g > 0.0f ? g : 0.0f;
+    default: return g;
+  }
+}
+__device__ __forceinline__ float mid_dact(int code, float h) {
+  switch (code) {
+    case EY_ACT_SIGMOID: return h * (1.0f - h);
+    case EY_ACT_TANH: return 1.0f - h * h;
+    case EY_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
+    default: return 1.0f;
+  }
+}
+__device__ __forceinline__ f32x16 mid_mfma(float a, float b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// H^T block = W H_in^T + b for output features f0 .. f0 + 31 (rows beyond d_out read the last row: their results are
+// dropped where they are stored), contraction over kpad = roundup8(d_in) columns (zero beyond d_in in both images)
+__device__ __forceinline__ f32x16 mid_fwd_block(const float* W, int ldw, int d_out, int f0, const float* bias, const float* Hin,
+                                                int ldh, int kpad, int c, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + f0 + 8 * q + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
+  }
+  const int fr = f0 + c < d_out ? f0 + c : d_out - 1;
+  const float* wr = W + fr * ldw + 4 * h;
+  const float* hr = Hin + c * ldh + 4 * h;
+  for (int k0 = 0; k0 < kpad; k0 += 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(wr + k0), b = *reinterpret_cast<const f32x4*>(hr + k0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = mid_mfma(a[j], b[j], acc);
+  }
+  return acc;
+}
+// (delta W)^T block for input features i0 .. i0 + 31: out[i][row] = sum_f W[f][i] delta[row][f]; delta's columns beyond
+// d_out are zero, so the rows of W read for them (clamped) contribute nothing
+__device__ __forceinline__ f32x16 mid_dh_block(const float* W, int ldw, int d_out, int d_in, int i0, const float* D, int ldd,
+                                               int c, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int ic = i0 + c < d_in ? i0 + c : d_in - 1;
+  const float* dr = D + c * ldd + 4 * h;
+  const int fpad = (d_out + 7) & ~7;
+  for (int f0 = 0; f0 < fpad; f0 += 8) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(dr + f0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = f0 + 4 * h + j;
+      const float a = W[(f < d_out ? f : d_out - 1) * ldw + ic];
+      acc = mid_mfma(a, b[j], acc);
+    }
+  }
+  return acc;
+}
+// acc[f][i] += sum over the tile's 32 rows of delta[row][f0 + .] Hprev[row][i0 + .]; returns this lane's share (its half's 16
+// rows) of the column sum of delta for feature f0 + c (the bias gradient)
+__device__ __forceinline__ float mid_dw_block(f32x16& acc, const float* D, int ldd, int f0, int fhi, const float* Hp, int ldh,
+                                              int i0, int ihi, int c, int h) {
+  const float* dr = D + (f0 + c < fhi ? f0 + c : fhi - 1);  // (columns beyond the images are read from their last one: unused outputs)
+  const float* hp = Hp + (i0 + c < ihi ? i0 + c : ihi - 1);
+  float s = 0.0f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 8 * u + 4 * h + j;
+      const float a = dr[row * ldd], b = hp[row * ldh];
+      acc = mid_mfma(a, b, acc);
+      s += a;
+    }
+  }
+  return s;
+}
+
+// BIGX: the first layer has more than 32 inputs (up to four block pairs per wave instead of one)
+template <bool BIGX>
+__global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave >> 2, fb = wave & 3;
+  const int c = lane & 31, h = lane >> 5;
+  const int nl = A.nl, dK = A.dims[nl];
+  const int gtid = tid & 255;  // thread within its row group
+  float* grp = smem + A.grp_at + rt * A.grp_floats;
+  constexpr int S0 = BIGX ? 4 : 1;  // block-pair slots of the first layer per wave
+  const int ntiles = (A.N + 31) / 32, rounds = (ntiles + 1) / 2;
+
+  for (int chain = blockIdx.x; chain < A.C; chain += gridDim.x) {
+    const float* th = A.theta + (size_t)chain * A.P;
+    __syncthreads();  // the previous chain's reads of the images are done
+    // ---- stage the chain's weights and biases
+    for (int l = 0; l < nl; ++l) {
+      const int din = A.dims[l], dout = A.dims[l + 1], ldw = A.ldw[l];
+      float* W = smem + A.w_at[l];
+      for (int e = tid; e < dout * ldw; e += 512) {
+        const int f = e / ldw, k = e - f * ldw;
+        W[e] = k < din ? th[A.woff[l] + f * din + k] : 0.0f;
+      }
+      float* B = smem + A.b_at[l];
+      const int bp = (dout + 31) & ~31;
+      for (int e = tid; e < bp; e += 512) B[e] = (e < dout && A.boff[l] >= 0) ? th[A.boff[l] + e] : 0.0f;
+    }
+    f32x16 acc0[S0], acc1[4], accL;
+    float db0[S0], db1[4], dbL = 0.0f, lik = 0.0f;
+#pragma unroll
+    for (int s = 0; s < S0; ++s) {
+      db0[s] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[s][r] = 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      db1[s] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[s][r] = 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accL[r] = 0.0f;
+
+    for (int rd = 0; rd < rounds; ++rd) {
+      const int row0 = 32 * (2 * rd + rt);
+      // ---- the data tile (rows beyond N and columns beyond d0 are zeros)
+      __syncthreads();
+      {
+        const int d0 = A.dims[0], ldx = A.ldh[0];
+        float* X = grp + A.h_at[0];
+        for (int e = gtid; e < 32 * ldx; e += 256) {
+          const int r = e / ldx, k = e - r * ldx;
+          X[e] = (k < d0 && row0 + r < A.N) ? A.x[(size_t)(row0 + r) * d0 + k] : 0.0f;
+        }
+      }
+      __syncthreads();
+      // ---- forward through the hidden layers (mlp.py:45-50); Hr[l] keeps this wave's block of H_{l+1} for act'
+      f32x16 Hr[2];
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        if (l < nl - 1) {
+          const int din = A.dims[l], dout = A.dims[l + 1];
+          if (32 * fb < ((dout + 31) & ~31)) {  // (a wave whose feature block lies beyond the layer's width has nothing here)
+          f32x16 acc = mid_fwd_block(smem + A.w_at[l], A.ldw[l], dout, 32 * fb, smem + A.b_at[l], grp + A.h_at[l], A.ldh[l],
+                                     (din + 7) & ~7, c, h);
+          const int code = A.act[l];
+          float* Ho = grp + A.h_at[l + 1] + c * A.ldh[l + 1] + 32 * fb + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int f = 32 * fb + 8 * q + 4 * h + j;
+              v[j] = f < dout ? mid_act(code, acc[4 * q + j]) : 0.0f;
+              Hr[l][4 * q + j] = v[j];
+            }
+            *reinterpret_cast<f32x4*>(Ho + 8 * q) = v;
+          }
+          }
+          __syncthreads();
+        }
+      }
+      // ---- the output layer: partial logits over this wave's 32 features, on the vector ALUs
+      const int lt = nl - 1;  // the output layer
+      {
+        const f32x16& Hl = nl == 3 ? Hr[1] : Hr[0];
+        const float* W = smem + A.w_at[lt];
+        const int ldw = A.ldw[lt];
+        float* PL = grp + A.pl_at + fb * A.dkp * 32;
+        const bool mine = 32 * fb < ((A.dims[lt] + 31) & ~31);
+        for (int o = 0; o < dK; ++o) {
+          float s = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (!mine) break;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(W + o * ldw + 32 * fb + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += wv[j] * Hl[4 * q + j];
+          }
+          s += __shfl_xor(s, 32, 64);
+          PL[o * 32 + c] = s;  // (both halves hold the sum and store it)
+        }
+      }
+      __syncthreads();
+      // ---- loss and output delta (constants.py:15-18, loss.py:1-11), by the first wave of the group
+      if (fb == 0) {
+        const float* PL = grp + A.pl_at;
+        const float* bL = smem + A.b_at[lt];
+        float* D3 = grp + A.d3_at + c * 20;
+        const int n = row0 + c;
+        const bool valid = n < A.N;
+        const int code = A.act[lt];
+        float out[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+          float v = 0.0f;
+          if (o < dK) {
+            v = ((PL[(0 * A.dkp + o) * 32 + c] + PL[(1 * A.dkp + o) * 32 + c]) + PL[(2 * A.dkp + o) * 32 + c]) +
+                PL[(3 * A.dkp + o) * 32 + c];
+            v = mid_act(code, v + bL[o]);
+          }
+          out[o] = v;
+        }
+        float d[16], row = 0.0f;
+        if (A.lik == EY_LIK_BCE_SUM) {
+#pragma unroll
+          for (int o = 0; o < 16; ++o) {
+            d[o] = 0.0f;
+            if (o < dK) {
+              const float p = out[o], yy = valid ? A.y[(size_t)n * dK + o] : 0.0f;
+              row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
+              d[o] = (yy / p - (1.0f - yy) / (1.0f - p)) * mid_dact(code, p);
+            }
+          }
+        } else {
+          const int lab = valid ? A.labels[n] : 0;
+          float mx = out[0];
+#pragma unroll
+          for (int o = 1; o < 16; ++o) mx = o < dK ? fmaxf(mx, out[o]) : mx;
+          float ssum = 0.0f, olab = out[0], e[16];
+#pragma unroll
+          for (int o = 0; o < 16; ++o) {
+            e[o] = o < dK ? __expf(out[o] - mx) : 0.0f;
+            ssum += e[o];
+            olab = o == lab ? out[o] : olab;
+          }
+          row = olab - (mx + __logf(ssum));
+          const float rs = 1.0f / ssum;
+#pragma unroll
+          for (int o = 0; o < 16; ++o) d[o] = o < dK ? ((o == lab ? 1.0f : 0.0f) - e[o] * rs) * mid_dact(code, out[o]) : 0.0f;
+        }
+        lik += (valid && h == 0) ? row : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(D3 + 4 * q) =
+              f32x4{valid ? d[4 * q] : 0.0f, valid ? d[4 * q + 1] : 0.0f, valid ? d[4 * q + 2] : 0.0f, valid ? d[4 * q + 3] : 0.0f};
+      }
+      __syncthreads();
+      // ---- backward through the output layer: dW_K-1 (block pair (0, fb)), then delta of the last hidden layer
+      f32x16 dn;
+      {
+        const int din = A.dims[lt], nb = (din + 31) >> 5;
+        const float* D3 = grp + A.d3_at;
+        const float* Hl = grp + A.h_at[lt];
+        if (fb < nb) {
+          const float s = mid_dw_block(accL, D3, 20, 0, 16, Hl, A.ldh[lt], 32 * fb, A.ldh[lt], c, h);
+          dbL += fb == 0 ? s : 0.0f;
+        }
+        // delta^T = (W^T delta3^T) * act'(H): contraction over the outputs (zero beyond dK in delta3's image)
+        if (fb < nb) {
+          dn = mid_dh_block(smem + A.w_at[lt], A.ldw[lt], dK, din, 32 * fb, D3, 20, c, h);
+          const f32x16& Hl_r = nl == 3 ? Hr[1] : Hr[0];
+          const int code = A.act[lt - 1];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = 32 * fb + 8 * (r >> 2) + 4 * h + (r & 3);
+            dn[r] = f < din ? dn[r] * mid_dact(code, Hl_r[r]) : 0.0f;
+          }
+        }
+      }
+      __syncthreads();  // every wave has read H_{K-1} for its dW block: the buffer takes delta_{K-1}
+      if (32 * fb < ((A.dims[lt] + 31) & ~31)) {
+        float* Ho = grp + A.h_at[lt] + c * A.ldh[lt] + 32 * fb + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(Ho + 8 * q) = f32x4{dn[4 * q], dn[4 * q + 1], dn[4 * q + 2], dn[4 * q + 3]};
+      }
+      __syncthreads();
+      // ---- backward through the second hidden layer's weights W_1 (three-layer models)
+      if (nl == 3) {
+        const int din = A.dims[1], dout = A.dims[2], mb = (dout + 31) >> 5, nb = (din + 31) >> 5;
+        const float* D = grp + A.h_at[2];
+        const float* Hp = grp + A.h_at[1];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int p = fb + 4 * s;
+          if (p < mb * nb) {
+            const int mm = p / nb, nn = p - mm * nb;
+            const float sm = mid_dw_block(acc1[s], D, A.ldh[2], 32 * mm, A.ldh[2], Hp, A.ldh[1], 32 * nn, A.ldh[1], c, h);
+            db1[s] += nn == 0 ? sm : 0.0f;
+          }
+        }
+        if (fb < nb) {
+          dn = mid_dh_block(smem + A.w_at[1], A.ldw[1], dout, din, 32 * fb, D, A.ldh[2], c, h);
+          const int code = A.act[0];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = 32 * fb + 8 * (r >> 2) + 4 * h + (r & 3);
+            dn[r] = f < din ? dn[r] * mid_dact(code, Hr[0][r]) : 0.0f;
+          }
+        }
+        __syncthreads();
+        if (fb < nb) {
+          float* Ho = grp + A.h_at[1] + c * A.ldh[1] + 32 * fb + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(Ho + 8 * q) = f32x4{dn[4 * q], dn[4 * q + 1], dn[4 * q + 2], dn[4 * q + 3]};
+        }
+        __syncthreads();
+      }
+      // ---- the first layer's weights: dW_0 = delta_1^T x
+      {
+        const int din = A.dims[0], dout = A.dims[1], mb = (dout + 31) >> 5, nb = (din + 31) >> 5;
+        const float* D = grp + A.h_at[1];
+        const float* Xp = grp + A.h_at[0];
+#pragma unroll
+        for (int s = 0; s < S0; ++s) {
+          const int p = fb + 4 * s;
+          if (p < mb * nb) {
+            const int mm = p / nb, nn = p - mm * nb;
+            const float sm = mid_dw_block(acc0[s], D, A.ldh[1], 32 * mm, A.ldh[1], Xp, A.ldh[0], 32 * nn, A.ldh[0], c, h);
+            db0[s] += nn == 0 ? sm : 0.0f;
+          }
+        }
+      }
+    }  // row tiles
+
+    // ---- the two row groups' sums meet (group 1 -> LDS -> group 0), prior gradient and temperature, write-out
+    const float tsc = A.temp ? A.temp[chain] : 1.0f;
+    float* gout = A.grad + (size_t)chain * A.P;
+    float* red = smem + A.grp_at;  // both regions are free now: [4 waves][17][64 lanes]
+    auto combine = [&](f32x16& acc, float& dbv) {
+      __syncthreads();
+      if (rt == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(fb * 17 + r) * 64 + lane] = acc[r];
+        red[(fb * 17 + 16) * 64 + lane] = dbv;
+      }
+      __syncthreads();
+      if (rt == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(fb * 17 + r) * 64 + lane];
+        dbv += red[(fb * 17 + 16) * 64 + lane];
+      }
+    };
+    auto emit = [&](int l, int mm, int nn, const f32x16& acc, float dbv) {
+      const int din = A.dims[l], dout = A.dims[l + 1];
+      const float* W = smem + A.w_at[l];
+      const int i = 32 * nn + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = 32 * mm + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (f < dout && i < din) {
+          const int idx = A.woff[l] + f * din + i;
+          const float m_ = A.prior_uniform ? A.mu0 : A.mu[idx], i_ = A.prior_uniform ? A.iv0 : A.iv[idx];
+          gout[idx] = (acc[r] - (W[f * A.ldw[l] + i] - m_) * i_) * tsc;
+        }
+      }
+      if (nn == 0 && A.boff[l] >= 0) {
+        const float tot = dbv + __shfl_xor(dbv, 32, 64);
+        const int f = 32 * mm + c;
+        if (h == 0 && f < dout) {
+          const int idx = A.boff[l] + f;
+          const float m_ = A.prior_uniform ? A.mu0 : A.mu[idx], i_ = A.prior_uniform ? A.iv0 : A.iv[idx];
+          gout[idx] = (tot - (smem[A.b_at[l] + f] - m_) * i_) * tsc;
+        }
+      }
+    };
+    {
+      const int mb = (A.dims[1] + 31) >> 5, nb = (A.dims[0] + 31) >> 5;
+#pragma unroll
+      for (int s = 0; s < S0; ++s) {
+        combine(acc0[s], db0[s]);
+        const int p = fb + 4 * s;
+        if (rt == 0 && p < mb * nb) emit(0, p / nb, p % nb, acc0[s], db0[s]);
+      }
+    }
+    if (nl == 3) {
+      const int mb = (A.dims[2] + 31) >> 5, nb = (A.dims[1] + 31) >> 5;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        combine(acc1[s], db1[s]);
+        const int p = fb + 4 * s;
+        if (rt == 0 && p < mb * nb) emit(1, p / nb, p % nb, acc1[s], db1[s]);
+      }
+    }
+    {
+      combine(accL, dbL);
+      const int nb = (A.dims[nl - 1] + 31) >> 5;
+      if (rt == 0 && fb < nb) {
+        // the output layer's block: rows of the accumulator are outputs (f < dK), its bias sums sit in lanes c < dK
+        const int l = nl - 1, din = A.dims[l];
+        const float* W = smem + A.w_at[l];
+        const int i = 32 * fb + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = 8 * (r >> 2) + 4 * h + (r & 3);
+          if (f < dK && i < din) {
+            const int idx = A.woff[l] + f * din + i;
+            const float m_ = A.prior_uniform ? A.mu0 : A.mu[idx], i_ = A.prior_uniform ? A.iv0 : A.iv[idx];
+            gout[idx] = (accL[r] - (W[f * A.ldw[l] + i] - m_) * i_) * tsc;
+          }
+        }
+        if (fb == 0 && A.boff[l] >= 0) {
+          const float tot = dbL + __shfl_xor(dbL, 32, 64);
+          if (h == 0 && c < dK) {
+            const int idx = A.boff[l] + c;
+            const float m_ = A.prior_uniform ? A.mu0 : A.mu[idx], i_ = A.prior_uniform ? A.iv0 : A.iv[idx];
+            gout[idx] = (tot - (smem[A.b_at[l] + c] - m_) * i_) * tsc;
+          }
+        }
+      }
+    }
+    // ---- the log-likelihood: lanes of the two groups' first waves, in a fixed order
+    __syncthreads();
+    if (fb == 0) {
+      float v = lik;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[rt] = v;
+    }
+    __syncthreads();
+    if (tid == 0) A.lik_o[chain] = red[0] + red[1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------- host side
+static int mid_ld(int d) {  // a row stride (floats) whose 16-byte reads by 32 consecutive rows miss each other's banks
+  int s = (d + 7) & ~7;
+  if (((s >> 2) & 1) == 0) s += 4;
+  return s;
+}
+// the carve for a model, or false when this kernel does not serve it
+static bool mid_plan(const EyModel& m, MidArgs& a) {
+  if (m.nl < 2 || m.nl > MID_NL) return false;
+  const int nl = m.nl, dK = m.dims[nl];
+  if (dK > 16 || m.dims[0] > 128) return false;
+  int widest = 0;
+  for (int l = 1; l < nl; ++l) {
+    if (m.dims[l] > 128) return false;
+    widest = std::max(widest, m.dims[l]);
+  }
+  if (widest <= 32) return false;  // one feature block: three of the four waves of a group would idle (other kernels serve those)
+  int at = 0;
+  for (int l = 0; l < nl; ++l) {
+    // (the output layer's rows are read 32 features per wave by the partial logits: as wide as the hidden buffers, zero-filled)
+    a.ldw[l] = l == nl - 1 ? ((m.dims[l] + 31) & ~31) + 4 : mid_ld(m.dims[l]);
+    a.w_at[l] = at;
+    at += m.dims[l + 1] * a.ldw[l];
+    at = (at + 3) & ~3;
+  }
+  for (int l = 0; l < nl; ++l) {
+    a.b_at[l] = at;
+    at += (m.dims[l + 1] + 31) & ~31;
+  }
+  a.grp_at = at;
+  int g = 0;
+  a.ldh[0] = mid_ld(m.dims[0]);
+  a.h_at[0] = g;
+  g += 32 * a.ldh[0];
+  for (int l = 1; l < nl; ++l) {
+    a.ldh[l] = ((m.dims[l] + 31) & ~31) + 4;
+    a.h_at[l] = g;
+    g += 32 * a.ldh[l];
+  }
+  a.d3_at = g;
+  g += 32 * 20;
+  a.dkp = (dK + 3) & ~3;
+  a.pl_at = g;
+  g += 4 * a.dkp * 32;
+  g = std::max(g, 4 * 17 * 64 / 2 + 64);  // the end-of-chain reduction scratch spans both regions
+  g = (g + 3) & ~3;
+  a.grp_floats = g;
+  a.total_floats = at + 2 * g;
+  return (size_t)a.total_floats * sizeof(float) <= 160 * 1024;
+}
+
+bool ey_mid_supports(const ey_plan* pl) {
+  if (pl->dtype != EY_F32) return false;
+  MidArgs a = {};
+  return mid_plan(pl->m, a);
+}
+
+// value (untempered log-likelihood per chain) and gradient of the tempered log-target of C chains
+int ey_mid_eval(ey_plan* pl, const float* theta, const float* temp, int C, float* lik_o, float* grad, hipStream_t s) {
+  const EyModel& m = pl->m;
+  MidArgs a = {};
+  if (!mid_plan(m, a)) EY_FAIL(EY_ERR_UNSUPPORTED, "ey_mid_eval: model not served by the fused mid-size kernel");
+  a.theta = theta; a.x = (const float*)m.x; a.y = (const float*)m.y; a.labels = m.labels; a.mu = (const float*)m.mu;
+  a.iv = (const float*)m.inv_var; a.temp = temp; a.lik_o = lik_o; a.grad = grad;
+  a.C = C; a.N = m.N; a.P = m.P; a.nl = m.nl; a.lik = m.lik;
+  a.prior_uniform = pl->prior_uniform ? 1 : 0; a.mu0 = (float)pl->prior_mu0; a.iv0 = (float)pl->prior_iv0;
+  for (int l = 0; l <= m.nl; ++l) a.dims[l] = m.dims[l];
+  for (int l = 0; l < m.nl; ++l) { a.woff[l] = m.woff[l]; a.boff[l] = m.boff[l]; a.act[l] = m.act[l]; }
+  const size_t bytes = (size_t)a.total_floats * sizeof(float);
+  const unsigned grid = (unsigned)std::min<int64_t>(C, pl->n_cu > 0 ? pl->n_cu : 256);
+  if (m.dims[0] > 32) {
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mid<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_mid<true>, dim3(grid), dim3(512), bytes, s, a);
+  } else {
+    EY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mid<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_mid<false>, dim3(grid), dim3(512), bytes, s, a);
+  }
+  EY_HIP(hipGetLastError());
+  return EY_OK;
+}
