@@ -70,6 +70,31 @@ __device__ __forceinline__ float mid_dact(int code, float h) {
     default: return 1.0f;
   }
 }
+// a whole accumulator tile through the activation / times act'(h), the (wave-uniform) switch outside the element loop
+__device__ __forceinline__ void mid_act_tile(int code, f32x16& a) {
+  if (code == EY_ACT_SIGMOID) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * a[r]));
+  } else if (code == EY_ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * a[r])) - 1.0f;
+  } else if (code == EY_ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+  }
+}
+__device__ __forceinline__ void mid_dact_tile(int code, f32x16& d, const f32x16& hh) {
+  if (code == EY_ACT_SIGMOID) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] *= hh[r] * (1.0f - hh[r]);
+  } else if (code == EY_ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] *= 1.0f - hh[r] * hh[r];
+  } else if (code == EY_ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = hh[r] > 0.0f ? d[r] : 0.0f;
+  }
+}
 __device__ __forceinline__ f32x16 mid_mfma(float a, float b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -107,12 +132,14 @@ __device__ __forceinline__ f32x16 mid_dh_block(const float* W, int ldw, int d_ou
   const int fpad = (d_out + 7) & ~7;
   for (int f0 = 0; f0 < fpad; f0 += 8) {
     const f32x4 b = *reinterpret_cast<const f32x4*>(dr + f0);
+    float a[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int f = f0 + 4 * h + j;
-      const float a = W[(f < d_out ? f : d_out - 1) * ldw + ic];
-      acc = mid_mfma(a, b[j], acc);
+      a[j] = W[(f < d_out ? f : d_out - 1) * ldw + ic];
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = mid_mfma(a[j], b[j], acc);
   }
   return acc;
 }
@@ -122,48 +149,75 @@ __device__ __forceinline__ float mid_dw_block(f32x16& acc, const float* D, int l
                                               int i0, int ihi, int c, int h) {
   const float* dr = D + (f0 + c < fhi ? f0 + c : fhi - 1);  // (columns beyond the images are read from their last one: unused outputs)
   const float* hp = Hp + (i0 + c < ihi ? i0 + c : ihi - 1);
-  float s = 0.0f;
+  // (all sixteen operand pairs are in flight before the first product: one LDS round trip per block, not one per MFMA)
+  dr += 4 * h * ldd;
+  hp += 4 * h * ldh;
+  float av[16], bv[16];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = 8 * u + 4 * h + j;
-      const float a = dr[row * ldd], b = hp[row * ldh];
-      acc = mid_mfma(a, b, acc);
-      s += a;
+      av[4 * u + j] = dr[(8 * u + j) * ldd];
+      bv[4 * u + j] = hp[(8 * u + j) * ldh];
     }
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    acc = mid_mfma(av[k], bv[k], acc);
+    s += av[k];
   }
   return s;
 }
 
+// this wave's 32 x 32 block of an activation buffer, in the accumulator layout (register 4q + j <-> feature f0 + 8q + 4h + j of row c)
+__device__ __forceinline__ f32x16 mid_read_block(const float* Hb, int ldh, int f0, int c, int h) {
+  f32x16 v;
+  const float* p = Hb + c * ldh + f0 + 4 * h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + 8 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 * q + j] = t[j];
+  }
+  return v;
+}
+
 // BIGX: the first layer has more than 32 inputs (up to four block pairs per wave instead of one)
+typedef const __attribute__((address_space(4))) MidArgs KA;
+#define MID_ARGS() ({ KA* p_ = (KA*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p_)); p_; })
+
 template <bool BIGX>
-__global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
+__global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
+  // The arguments are read where they are used, from the kernarg segment (scalar loads), through a pointer the compiler
+  // cannot see through (MID_ARGS): hoisted to the top of the kernel its sixty integers stayed live in scalar registers for
+  // the whole launch -- 530 of them spilled into vector lanes, which then spilled 640 vector registers to scratch.
+  KA* A = MID_ARGS();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = wave >> 2, fb = wave & 3;
   const int c = lane & 31, h = lane >> 5;
-  const int nl = A.nl, dK = A.dims[nl];
+  const int nl = A->nl, dK = A->dims[nl];
   const int gtid = tid & 255;  // thread within its row group
-  float* grp = smem + A.grp_at + rt * A.grp_floats;
+  float* grp = smem + A->grp_at + rt * A->grp_floats;
   constexpr int S0 = BIGX ? 4 : 1;  // block-pair slots of the first layer per wave
-  const int ntiles = (A.N + 31) / 32, rounds = (ntiles + 1) / 2;
+  const int ntiles = (A->N + 31) / 32, rounds = (ntiles + 1) / 2;
 
-  for (int chain = blockIdx.x; chain < A.C; chain += gridDim.x) {
-    const float* th = A.theta + (size_t)chain * A.P;
+  for (int chain = blockIdx.x; chain < A->C; chain += gridDim.x) {
+    A = MID_ARGS();
+    const float* th = A->theta + (size_t)chain * A->P;
     __syncthreads();  // the previous chain's reads of the images are done
     // ---- stage the chain's weights and biases
     for (int l = 0; l < nl; ++l) {
-      const int din = A.dims[l], dout = A.dims[l + 1], ldw = A.ldw[l];
-      float* W = smem + A.w_at[l];
+      const int din = A->dims[l], dout = A->dims[l + 1], ldw = A->ldw[l];
+      float* W = smem + A->w_at[l];
       for (int e = tid; e < dout * ldw; e += 512) {
         const int f = e / ldw, k = e - f * ldw;
-        W[e] = k < din ? th[A.woff[l] + f * din + k] : 0.0f;
+        W[e] = k < din ? th[A->woff[l] + f * din + k] : 0.0f;
       }
-      float* B = smem + A.b_at[l];
+      float* B = smem + A->b_at[l];
       const int bp = (dout + 31) & ~31;
-      for (int e = tid; e < bp; e += 512) B[e] = (e < dout && A.boff[l] >= 0) ? th[A.boff[l] + e] : 0.0f;
+      for (int e = tid; e < bp; e += 512) B[e] = (e < dout && A->boff[l] >= 0) ? th[A->boff[l] + e] : 0.0f;
     }
     f32x16 acc0[S0], acc1[4], accL;
     float db0[S0], db1[4], dbL = 0.0f, lik = 0.0f;
@@ -183,37 +237,36 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
     for (int r = 0; r < 16; ++r) accL[r] = 0.0f;
 
     for (int rd = 0; rd < rounds; ++rd) {
+      A = MID_ARGS();
       const int row0 = 32 * (2 * rd + rt);
       // ---- the data tile (rows beyond N and columns beyond d0 are zeros)
       __syncthreads();
       {
-        const int d0 = A.dims[0], ldx = A.ldh[0];
-        float* X = grp + A.h_at[0];
+        const int d0 = A->dims[0], ldx = A->ldh[0];
+        float* X = grp + A->h_at[0];
         for (int e = gtid; e < 32 * ldx; e += 256) {
           const int r = e / ldx, k = e - r * ldx;
-          X[e] = (k < d0 && row0 + r < A.N) ? A.x[(size_t)(row0 + r) * d0 + k] : 0.0f;
+          X[e] = (k < d0 && row0 + r < A->N) ? A->x[(size_t)(row0 + r) * d0 + k] : 0.0f;
         }
       }
       __syncthreads();
-      // ---- forward through the hidden layers (mlp.py:45-50); Hr[l] keeps this wave's block of H_{l+1} for act'
-      f32x16 Hr[2];
+      // ---- forward through the hidden layers (mlp.py:45-50)
 #pragma unroll
       for (int l = 0; l < 2; ++l) {
         if (l < nl - 1) {
-          const int din = A.dims[l], dout = A.dims[l + 1];
+          const int din = A->dims[l], dout = A->dims[l + 1];
           if (32 * fb < ((dout + 31) & ~31)) {  // (a wave whose feature block lies beyond the layer's width has nothing here)
-          f32x16 acc = mid_fwd_block(smem + A.w_at[l], A.ldw[l], dout, 32 * fb, smem + A.b_at[l], grp + A.h_at[l], A.ldh[l],
+          f32x16 acc = mid_fwd_block(smem + A->w_at[l], A->ldw[l], dout, 32 * fb, smem + A->b_at[l], grp + A->h_at[l], A->ldh[l],
                                      (din + 7) & ~7, c, h);
-          const int code = A.act[l];
-          float* Ho = grp + A.h_at[l + 1] + c * A.ldh[l + 1] + 32 * fb + 4 * h;
+          mid_act_tile(A->act[l], acc);
+          float* Ho = grp + A->h_at[l + 1] + c * A->ldh[l + 1] + 32 * fb + 4 * h;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int f = 32 * fb + 8 * q + 4 * h + j;
-              v[j] = f < dout ? mid_act(code, acc[4 * q + j]) : 0.0f;
-              Hr[l][4 * q + j] = v[j];
+              v[j] = f < dout ? acc[4 * q + j] : 0.0f;
             }
             *reinterpret_cast<f32x4*>(Ho + 8 * q) = v;
           }
@@ -221,14 +274,16 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
           __syncthreads();
         }
       }
+      A = MID_ARGS();
       // ---- the output layer: partial logits over this wave's 32 features, on the vector ALUs
       const int lt = nl - 1;  // the output layer
       {
-        const f32x16& Hl = nl == 3 ? Hr[1] : Hr[0];
-        const float* W = smem + A.w_at[lt];
-        const int ldw = A.ldw[lt];
-        float* PL = grp + A.pl_at + fb * A.dkp * 32;
-        const bool mine = 32 * fb < ((A.dims[lt] + 31) & ~31);
+        const bool mine = 32 * fb < ((A->dims[lt] + 31) & ~31);
+        f32x16 Hl;
+        if (mine) Hl = mid_read_block(grp + A->h_at[lt], A->ldh[lt], 32 * fb, c, h);
+        const float* W = smem + A->w_at[lt];
+        const int ldw = A->ldw[lt];
+        float* PL = grp + A->pl_at + fb * A->dkp * 32;
         for (int o = 0; o < dK; ++o) {
           float s = 0.0f;
 #pragma unroll
@@ -243,143 +298,136 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
         }
       }
       __syncthreads();
-      // ---- loss and output delta (constants.py:15-18, loss.py:1-11), by the first wave of the group
+      A = MID_ARGS();
+      // ---- loss and output delta (constants.py:15-18, loss.py:1-11), by the first wave of the group: the outputs pass
+      // through the row's slots of delta's image (no register arrays: d_K is a run-time number)
       if (fb == 0) {
-        const float* PL = grp + A.pl_at;
-        const float* bL = smem + A.b_at[lt];
-        float* D3 = grp + A.d3_at + c * 20;
+        const float* PL = grp + A->pl_at;
+        const float* bL = smem + A->b_at[lt];
+        float* D3 = grp + A->d3_at + c * 20;
         const int n = row0 + c;
-        const bool valid = n < A.N;
-        const int code = A.act[lt];
-        float out[16];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-          float v = 0.0f;
-          if (o < dK) {
-            v = ((PL[(0 * A.dkp + o) * 32 + c] + PL[(1 * A.dkp + o) * 32 + c]) + PL[(2 * A.dkp + o) * 32 + c]) +
-                PL[(3 * A.dkp + o) * 32 + c];
-            v = mid_act(code, v + bL[o]);
-          }
-          out[o] = v;
+        const bool valid = n < A->N;
+        const int code = A->act[lt];
+        float mx = -3.0e38f;
+        for (int o = 0; o < dK; ++o) {
+          float v = ((PL[(0 * A->dkp + o) * 32 + c] + PL[(1 * A->dkp + o) * 32 + c]) + PL[(2 * A->dkp + o) * 32 + c]) +
+                    PL[(3 * A->dkp + o) * 32 + c];
+          v = mid_act(code, v + bL[o]);
+          D3[o] = v;  // (both halves of the wave hold the row and store the same value)
+          mx = fmaxf(mx, v);
         }
-        float d[16], row = 0.0f;
-        if (A.lik == EY_LIK_BCE_SUM) {
-#pragma unroll
-          for (int o = 0; o < 16; ++o) {
-            d[o] = 0.0f;
-            if (o < dK) {
-              const float p = out[o], yy = valid ? A.y[(size_t)n * dK + o] : 0.0f;
-              row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
-              d[o] = (yy / p - (1.0f - yy) / (1.0f - p)) * mid_dact(code, p);
-            }
+        float row = 0.0f;
+        if (A->lik == EY_LIK_BCE_SUM) {
+          for (int o = 0; o < dK; ++o) {
+            const float p = D3[o], yy = valid ? A->y[(size_t)n * dK + o] : 0.0f;
+            row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
+            D3[o] = valid ? (yy / p - (1.0f - yy) / (1.0f - p)) * mid_dact(code, p) : 0.0f;
           }
         } else {
-          const int lab = valid ? A.labels[n] : 0;
-          float mx = out[0];
-#pragma unroll
-          for (int o = 1; o < 16; ++o) mx = o < dK ? fmaxf(mx, out[o]) : mx;
-          float ssum = 0.0f, olab = out[0], e[16];
-#pragma unroll
-          for (int o = 0; o < 16; ++o) {
-            e[o] = o < dK ? __expf(out[o] - mx) : 0.0f;
-            ssum += e[o];
-            olab = o == lab ? out[o] : olab;
+          const int lab = valid ? A->labels[n] : 0;
+          float ssum = 0.0f, olab = 0.0f;
+          for (int o = 0; o < dK; ++o) {
+            const float v = D3[o];
+            ssum += __expf(v - mx);
+            olab = o == lab ? v : olab;
           }
           row = olab - (mx + __logf(ssum));
           const float rs = 1.0f / ssum;
-#pragma unroll
-          for (int o = 0; o < 16; ++o) d[o] = o < dK ? ((o == lab ? 1.0f : 0.0f) - e[o] * rs) * mid_dact(code, out[o]) : 0.0f;
+          for (int o = 0; o < dK; ++o) {
+            const float v = D3[o];
+            D3[o] = valid ? ((o == lab ? 1.0f : 0.0f) - __expf(v - mx) * rs) * mid_dact(code, v) : 0.0f;
+          }
         }
+        for (int o = dK; o < 16; ++o) D3[o] = 0.0f;
         lik += (valid && h == 0) ? row : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f32x4*>(D3 + 4 * q) =
-              f32x4{valid ? d[4 * q] : 0.0f, valid ? d[4 * q + 1] : 0.0f, valid ? d[4 * q + 2] : 0.0f, valid ? d[4 * q + 3] : 0.0f};
       }
       __syncthreads();
+      A = MID_ARGS();
       // ---- backward through the output layer: dW_K-1 (block pair (0, fb)), then delta of the last hidden layer
       f32x16 dn;
       {
-        const int din = A.dims[lt], nb = (din + 31) >> 5;
-        const float* D3 = grp + A.d3_at;
-        const float* Hl = grp + A.h_at[lt];
+        const int din = A->dims[lt], nb = (din + 31) >> 5;
+        const float* D3 = grp + A->d3_at;
+        const float* Hl = grp + A->h_at[lt];
         if (fb < nb) {
-          const float s = mid_dw_block(accL, D3, 20, 0, 16, Hl, A.ldh[lt], 32 * fb, A.ldh[lt], c, h);
+          const float s = mid_dw_block(accL, D3, 20, 0, 16, Hl, A->ldh[lt], 32 * fb, A->ldh[lt], c, h);
           dbL += fb == 0 ? s : 0.0f;
         }
         // delta^T = (W^T delta3^T) * act'(H): contraction over the outputs (zero beyond dK in delta3's image)
         if (fb < nb) {
-          dn = mid_dh_block(smem + A.w_at[lt], A.ldw[lt], dK, din, 32 * fb, D3, 20, c, h);
-          const f32x16& Hl_r = nl == 3 ? Hr[1] : Hr[0];
-          const int code = A.act[lt - 1];
+          dn = mid_dh_block(smem + A->w_at[lt], A->ldw[lt], dK, din, 32 * fb, D3, 20, c, h);
+          mid_dact_tile(A->act[lt - 1], dn, mid_read_block(grp + A->h_at[lt], A->ldh[lt], 32 * fb, c, h));
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int f = 32 * fb + 8 * (r >> 2) + 4 * h + (r & 3);
-            dn[r] = f < din ? dn[r] * mid_dact(code, Hl_r[r]) : 0.0f;
+            dn[r] = f < din ? dn[r] : 0.0f;
           }
         }
       }
       __syncthreads();  // every wave has read H_{K-1} for its dW block: the buffer takes delta_{K-1}
-      if (32 * fb < ((A.dims[lt] + 31) & ~31)) {
-        float* Ho = grp + A.h_at[lt] + c * A.ldh[lt] + 32 * fb + 4 * h;
+      if (32 * fb < ((A->dims[lt] + 31) & ~31)) {
+        float* Ho = grp + A->h_at[lt] + c * A->ldh[lt] + 32 * fb + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<f32x4*>(Ho + 8 * q) = f32x4{dn[4 * q], dn[4 * q + 1], dn[4 * q + 2], dn[4 * q + 3]};
       }
       __syncthreads();
+      A = MID_ARGS();
       // ---- backward through the second hidden layer's weights W_1 (three-layer models)
       if (nl == 3) {
-        const int din = A.dims[1], dout = A.dims[2], mb = (dout + 31) >> 5, nb = (din + 31) >> 5;
-        const float* D = grp + A.h_at[2];
-        const float* Hp = grp + A.h_at[1];
+        const int din = A->dims[1], dout = A->dims[2], mb = (dout + 31) >> 5, nb = (din + 31) >> 5;
+        const float* D = grp + A->h_at[2];
+        const float* Hp = grp + A->h_at[1];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int p = fb + 4 * s;
           if (p < mb * nb) {
             const int mm = p / nb, nn = p - mm * nb;
-            const float sm = mid_dw_block(acc1[s], D, A.ldh[2], 32 * mm, A.ldh[2], Hp, A.ldh[1], 32 * nn, A.ldh[1], c, h);
+            const float sm = mid_dw_block(acc1[s], D, A->ldh[2], 32 * mm, A->ldh[2], Hp, A->ldh[1], 32 * nn, A->ldh[1], c, h);
             db1[s] += nn == 0 ? sm : 0.0f;
           }
         }
         if (fb < nb) {
-          dn = mid_dh_block(smem + A.w_at[1], A.ldw[1], dout, din, 32 * fb, D, A.ldh[2], c, h);
-          const int code = A.act[0];
+          dn = mid_dh_block(smem + A->w_at[1], A->ldw[1], dout, din, 32 * fb, D, A->ldh[2], c, h);
+          mid_dact_tile(A->act[0], dn, mid_read_block(grp + A->h_at[1], A->ldh[1], 32 * fb, c, h));
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int f = 32 * fb + 8 * (r >> 2) + 4 * h + (r & 3);
-            dn[r] = f < din ? dn[r] * mid_dact(code, Hr[0][r]) : 0.0f;
+            dn[r] = f < din ? dn[r] : 0.0f;
           }
         }
         __syncthreads();
         if (fb < nb) {
-          float* Ho = grp + A.h_at[1] + c * A.ldh[1] + 32 * fb + 4 * h;
+          float* Ho = grp + A->h_at[1] + c * A->ldh[1] + 32 * fb + 4 * h;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<f32x4*>(Ho + 8 * q) = f32x4{dn[4 * q], dn[4 * q + 1], dn[4 * q + 2], dn[4 * q + 3]};
         }
         __syncthreads();
       }
+      A = MID_ARGS();
       // ---- the first layer's weights: dW_0 = delta_1^T x
       {
-        const int din = A.dims[0], dout = A.dims[1], mb = (dout + 31) >> 5, nb = (din + 31) >> 5;
-        const float* D = grp + A.h_at[1];
-        const float* Xp = grp + A.h_at[0];
+        const int din = A->dims[0], dout = A->dims[1], mb = (dout + 31) >> 5, nb = (din + 31) >> 5;
+        const float* D = grp + A->h_at[1];
+        const float* Xp = grp + A->h_at[0];
 #pragma unroll
         for (int s = 0; s < S0; ++s) {
           const int p = fb + 4 * s;
           if (p < mb * nb) {
             const int mm = p / nb, nn = p - mm * nb;
-            const float sm = mid_dw_block(acc0[s], D, A.ldh[1], 32 * mm, A.ldh[1], Xp, A.ldh[0], 32 * nn, A.ldh[0], c, h);
+            const float sm = mid_dw_block(acc0[s], D, A->ldh[1], 32 * mm, A->ldh[1], Xp, A->ldh[0], 32 * nn, A->ldh[0], c, h);
             db0[s] += nn == 0 ? sm : 0.0f;
           }
         }
       }
     }  // row tiles
 
+    A = MID_ARGS();
     // ---- the two row groups' sums meet (group 1 -> LDS -> group 0), prior gradient and temperature, write-out
-    const float tsc = A.temp ? A.temp[chain] : 1.0f;
-    float* gout = A.grad + (size_t)chain * A.P;
-    float* red = smem + A.grp_at;  // both regions are free now: [4 waves][17][64 lanes]
+    const float tsc = A->temp ? A->temp[chain] : 1.0f;
+    float* gout = A->grad + (size_t)chain * A->P;
+    float* red = smem + A->grp_at;  // both regions are free now: [4 waves][17][64 lanes]
     auto combine = [&](f32x16& acc, float& dbv) {
       __syncthreads();
       if (rt == 1) {
@@ -395,30 +443,30 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
       }
     };
     auto emit = [&](int l, int mm, int nn, const f32x16& acc, float dbv) {
-      const int din = A.dims[l], dout = A.dims[l + 1];
-      const float* W = smem + A.w_at[l];
+      const int din = A->dims[l], dout = A->dims[l + 1];
+      const float* W = smem + A->w_at[l];
       const int i = 32 * nn + c;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int f = 32 * mm + 8 * (r >> 2) + 4 * h + (r & 3);
         if (f < dout && i < din) {
-          const int idx = A.woff[l] + f * din + i;
-          const float m_ = A.prior_uniform ? A.mu0 : A.mu[idx], i_ = A.prior_uniform ? A.iv0 : A.iv[idx];
-          gout[idx] = (acc[r] - (W[f * A.ldw[l] + i] - m_) * i_) * tsc;
+          const int idx = A->woff[l] + f * din + i;
+          const float m_ = A->prior_uniform ? A->mu0 : A->mu[idx], i_ = A->prior_uniform ? A->iv0 : A->iv[idx];
+          gout[idx] = (acc[r] - (W[f * A->ldw[l] + i] - m_) * i_) * tsc;
         }
       }
-      if (nn == 0 && A.boff[l] >= 0) {
+      if (nn == 0 && A->boff[l] >= 0) {
         const float tot = dbv + __shfl_xor(dbv, 32, 64);
         const int f = 32 * mm + c;
         if (h == 0 && f < dout) {
-          const int idx = A.boff[l] + f;
-          const float m_ = A.prior_uniform ? A.mu0 : A.mu[idx], i_ = A.prior_uniform ? A.iv0 : A.iv[idx];
-          gout[idx] = (tot - (smem[A.b_at[l] + f] - m_) * i_) * tsc;
+          const int idx = A->boff[l] + f;
+          const float m_ = A->prior_uniform ? A->mu0 : A->mu[idx], i_ = A->prior_uniform ? A->iv0 : A->iv[idx];
+          gout[idx] = (tot - (smem[A->b_at[l] + f] - m_) * i_) * tsc;
         }
       }
     };
     {
-      const int mb = (A.dims[1] + 31) >> 5, nb = (A.dims[0] + 31) >> 5;
+      const int mb = (A->dims[1] + 31) >> 5, nb = (A->dims[0] + 31) >> 5;
 #pragma unroll
       for (int s = 0; s < S0; ++s) {
         combine(acc0[s], db0[s]);
@@ -427,7 +475,7 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
       }
     }
     if (nl == 3) {
-      const int mb = (A.dims[2] + 31) >> 5, nb = (A.dims[1] + 31) >> 5;
+      const int mb = (A->dims[2] + 31) >> 5, nb = (A->dims[1] + 31) >> 5;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         combine(acc1[s], db1[s]);
@@ -437,27 +485,27 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
     }
     {
       combine(accL, dbL);
-      const int nb = (A.dims[nl - 1] + 31) >> 5;
+      const int nb = (A->dims[nl - 1] + 31) >> 5;
       if (rt == 0 && fb < nb) {
         // the output layer's block: rows of the accumulator are outputs (f < dK), its bias sums sit in lanes c < dK
-        const int l = nl - 1, din = A.dims[l];
-        const float* W = smem + A.w_at[l];
+        const int l = nl - 1, din = A->dims[l];
+        const float* W = smem + A->w_at[l];
         const int i = 32 * fb + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int f = 8 * (r >> 2) + 4 * h + (r & 3);
           if (f < dK && i < din) {
-            const int idx = A.woff[l] + f * din + i;
-            const float m_ = A.prior_uniform ? A.mu0 : A.mu[idx], i_ = A.prior_uniform ? A.iv0 : A.iv[idx];
-            gout[idx] = (accL[r] - (W[f * A.ldw[l] + i] - m_) * i_) * tsc;
+            const int idx = A->woff[l] + f * din + i;
+            const float m_ = A->prior_uniform ? A->mu0 : A->mu[idx], i_ = A->prior_uniform ? A->iv0 : A->iv[idx];
+            gout[idx] = (accL[r] - (W[f * A->ldw[l] + i] - m_) * i_) * tsc;
           }
         }
-        if (fb == 0 && A.boff[l] >= 0) {
+        if (fb == 0 && A->boff[l] >= 0) {
           const float tot = dbL + __shfl_xor(dbL, 32, 64);
           if (h == 0 && c < dK) {
-            const int idx = A.boff[l] + c;
-            const float m_ = A.prior_uniform ? A.mu0 : A.mu[idx], i_ = A.prior_uniform ? A.iv0 : A.iv[idx];
-            gout[idx] = (tot - (smem[A.b_at[l] + c] - m_) * i_) * tsc;
+            const int idx = A->boff[l] + c;
+            const float m_ = A->prior_uniform ? A->mu0 : A->mu[idx], i_ = A->prior_uniform ? A->iv0 : A->iv[idx];
+            gout[idx] = (tot - (smem[A->b_at[l] + c] - m_) * i_) * tsc;
           }
         }
       }
@@ -471,7 +519,7 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A) {
       if (lane == 0) red[rt] = v;
     }
     __syncthreads();
-    if (tid == 0) A.lik_o[chain] = red[0] + red[1];
+    if (tid == 0) A->lik_o[chain] = red[0] + red[1];
   }
 }
 
