@@ -2165,10 +2165,12 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
   // f32 only: in f64 the fused kernel measured SLOWER than the separate launches (every lane of a row repeats the
   // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
   const bool tail = sizeof(T) == 4 && tail_ok(m) && !EY_VBIT(6);
-  // mid-size models (ey_mid.hip): value and gradient in ONE launch, a workgroup per chain with the weights resident in LDS
+  // mid-size models (ey_mid.hip, variant bit 13): value and gradient in ONE launch, a workgroup per chain with the weights
+  // resident in LDS.  Opt-in: measured level with the launches below on three-layer models (1.00 - 1.09 x) and behind
+  // them on two-layer ones (0.67 x), profiles/r05_mid_ab.txt
   bool mid = false;
   if constexpr (sizeof(T) == 4) {
-    if (grad && !rows_o && !lf && !EY_VBIT(13) && ey_mid_supports(pl)) {
+    if (grad && !rows_o && !lf && EY_VBIT(13) && ey_mid_supports(pl)) {
       if ((rc = ey_mid_eval(pl, (const float*)theta, (const float*)temp, C, (float*)lik_tmp, (float*)grad, s))) return rc;
       mid = true;
     }
@@ -2305,7 +2307,7 @@ static int large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const v
   // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
   const bool tail = sizeof(T) == 4 && tail_ok(m) && !EY_VBIT(6);
   // (the fused mid-size kernel produces the whole gradient in one launch: the leapfrog update then stays k_leap's)
-  const bool fuse = sizeof(T) == 4 && !EY_VBIT(7) && !(!EY_VBIT(13) && ey_mid_supports(pl));
+  const bool fuse = sizeof(T) == 4 && !EY_VBIT(7) && !(EY_VBIT(13) && ey_mid_supports(pl));
   const int nslots = fuse ? leap_fuse_slots(m, tail) : 0;
   const int nq = nblk > nslots ? nblk : nslots;
   const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc + 2 * (size_t)cc * nq;

@@ -51,6 +51,7 @@ struct MidArgs {
   int h_at[MID_NL], ldh[MID_NL];  // inside a region: the data tile (l = 0) and H_l / delta_l (l >= 1): [32][ldh]
   int d3_at;                      // delta of the output layer [32][16 + 4]
   int pl_at, dkp;                 // partial logits [4 waves][dkp][32 rows]
+  int red_per;                    // accumulator blocks per pass of the end-of-chain reduction
   int total_floats;
 };
 
@@ -113,11 +114,17 @@ __device__ __forceinline__ f32x16 mid_fwd_block(const float* W, int ldw, int d_o
   const int fr = f0 + c < d_out ? f0 + c : d_out - 1;
   const float* wr = W + fr * ldw + 4 * h;
   const float* hr = Hin + c * ldh + 4 * h;
-  for (int k0 = 0; k0 < kpad; k0 += 8) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(wr + k0), b = *reinterpret_cast<const f32x4*>(hr + k0);
+  // (the next chunk's operands are in flight while this chunk's four products issue)
+  f32x4 a = *reinterpret_cast<const f32x4*>(wr), b = *reinterpret_cast<const f32x4*>(hr);
+  for (int k0 = 8; k0 < kpad; k0 += 8) {
+    const f32x4 an = *reinterpret_cast<const f32x4*>(wr + k0), bn = *reinterpret_cast<const f32x4*>(hr + k0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = mid_mfma(a[j], b[j], acc);
+    a = an;
+    b = bn;
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = mid_mfma(a[j], b[j], acc);
   return acc;
 }
 // (delta W)^T block for input features i0 .. i0 + 31: out[i][row] = sum_f W[f][i] delta[row][f]; delta's columns beyond
@@ -130,17 +137,29 @@ __device__ __forceinline__ f32x16 mid_dh_block(const float* W, int ldw, int d_ou
   const int ic = i0 + c < d_in ? i0 + c : d_in - 1;
   const float* dr = D + c * ldd + 4 * h;
   const int fpad = (d_out + 7) & ~7;
-  for (int f0 = 0; f0 < fpad; f0 += 8) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(dr + f0);
-    float a[4];
+  auto fetch = [&](int f0, f32x4& b, float (&a)[4]) {
+    b = *reinterpret_cast<const f32x4*>(dr + f0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int f = f0 + 4 * h + j;
       a[j] = W[(f < d_out ? f : d_out - 1) * ldw + ic];
     }
+  };
+  f32x4 b;
+  float a[4];
+  fetch(0, b, a);
+  for (int f0 = 8; f0 < fpad; f0 += 8) {  // (the next chunk's operands in flight under this chunk's products)
+    f32x4 bn;
+    float an[4];
+    fetch(f0, bn, an);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = mid_mfma(a[j], b[j], acc);
+    b = bn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = an[j];
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = mid_mfma(a[j], b[j], acc);
   return acc;
 }
 // acc[f][i] += sum over the tile's 32 rows of delta[row][f0 + .] Hprev[row][i0 + .]; returns this lane's share (its half's 16
@@ -183,6 +202,24 @@ __device__ __forceinline__ f32x16 mid_read_block(const float* Hb, int ldh, int f
 }
 
 // BIGX: the first layer has more than 32 inputs (up to four block pairs per wave instead of one)
+// MID_TIMING (diagnostic builds, tools/mid_phase.py): s_memtime sums per phase, wave 0 of every 64th workgroup
+#ifndef MID_TIMING
+#define MID_TIMING 0
+#endif
+#if MID_TIMING
+__device__ unsigned long long g_mid_phase[32];
+#define MT(i) do { if (mt_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); mt_acc[i] += n_ - mt_t; mt_t = n_; } } while (0)
+extern "C" int ey_debug_mid_phase_read(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mid_phase), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mid_phase), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define MT(i) do { } while (0)
+#endif
 typedef const __attribute__((address_space(4))) MidArgs KA;
 #define MID_ARGS() ({ KA* p_ = (KA*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p_)); p_; })
 
@@ -203,17 +240,38 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
   constexpr int S0 = BIGX ? 4 : 1;  // block-pair slots of the first layer per wave
   const int ntiles = (A->N + 31) / 32, rounds = (ntiles + 1) / 2;
 
+#if MID_TIMING
+  unsigned long long mt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool mt_on = (blockIdx.x & 63) == 0 && wave == 0;
+  unsigned long long mt_t = mt_on ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
   for (int chain = blockIdx.x; chain < A->C; chain += gridDim.x) {
     A = MID_ARGS();
+    MT(15);
     const float* th = A->theta + (size_t)chain * A->P;
     __syncthreads();  // the previous chain's reads of the images are done
     // ---- stage the chain's weights and biases
     for (int l = 0; l < nl; ++l) {
       const int din = A->dims[l], dout = A->dims[l + 1], ldw = A->ldw[l];
       float* W = smem + A->w_at[l];
-      for (int e = tid; e < dout * ldw; e += 512) {
-        const int f = e / ldw, k = e - f * ldw;
-        W[e] = k < din ? th[A->woff[l] + f * din + k] : 0.0f;
+      // (a row per 32 lanes: no index division; the loads of eight rows are in flight before the first store -- taken one
+      // by one every element waited out its own trip to memory: 26 000 cycles per chain for 12 705 weights)
+      const float* src = th + A->woff[l];
+      const int kk = tid & 31;
+      for (int f0 = tid >> 5; f0 < dout; f0 += 16 * 8) {
+        for (int k = kk; k < ldw; k += 32) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int f = f0 + 16 * u;
+            v[u] = (k < din && f < dout) ? src[(f < dout ? f : 0) * din + (k < din ? k : 0)] : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int f = f0 + 16 * u;
+            if (f < dout) W[f * ldw + k] = v[u];
+          }
+        }
       }
       float* B = smem + A->b_at[l];
       const int bp = (dout + 31) & ~31;
@@ -236,6 +294,7 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accL[r] = 0.0f;
 
+    MT(0);  // staging
     for (int rd = 0; rd < rounds; ++rd) {
       A = MID_ARGS();
       const int row0 = 32 * (2 * rd + rt);
@@ -244,12 +303,16 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
       {
         const int d0 = A->dims[0], ldx = A->ldh[0];
         float* X = grp + A->h_at[0];
-        for (int e = gtid; e < 32 * ldx; e += 256) {
-          const int r = e / ldx, k = e - r * ldx;
-          X[e] = (k < d0 && row0 + r < A->N) ? A->x[(size_t)(row0 + r) * d0 + k] : 0.0f;
-        }
+        const int r = gtid >> 3;  // eight threads per row
+        const bool rv = row0 + r < A->N;
+        const float* xr = A->x + (size_t)(rv ? row0 + r : 0) * d0;
+        for (int k = gtid & 7; k < ldx; k += 8) X[r * ldx + k] = (k < d0 && rv) ? xr[k] : 0.0f;
       }
+      // this lane's row's label (CE) is fetched here, a whole round trip to memory ahead of the loss that uses it
+      int lab_pre = 0;
+      if (A->lik != EY_LIK_BCE_SUM && row0 + c < A->N) lab_pre = A->labels[row0 + c];
       __syncthreads();
+      MT(1);  // data tile
       // ---- forward through the hidden layers (mlp.py:45-50)
 #pragma unroll
       for (int l = 0; l < 2; ++l) {
@@ -274,6 +337,7 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
           __syncthreads();
         }
       }
+      MT(2);  // forward
       A = MID_ARGS();
       // ---- the output layer: partial logits over this wave's 32 features, on the vector ALUs
       const int lt = nl - 1;  // the output layer
@@ -284,20 +348,28 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
         const float* W = smem + A->w_at[lt];
         const int ldw = A->ldw[lt];
         float* PL = grp + A->pl_at + fb * A->dkp * 32;
-        for (int o = 0; o < dK; ++o) {
-          float s = 0.0f;
+        float sv[16];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (!mine) break;
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(W + o * ldw + 32 * fb + 8 * q + 4 * h);
+        for (int o = 0; o < 16; ++o) {
+          sv[o] = 0.0f;
+          if (o < dK && mine) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += wv[j] * Hl[4 * q + j];
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(W + o * ldw + 32 * fb + 8 * q + 4 * h);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sv[o] += wv[j] * Hl[4 * q + j];
+            }
           }
-          s += __shfl_xor(s, 32, 64);
-          PL[o * 32 + c] = s;  // (both halves hold the sum and store it)
         }
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+          if (o < dK) sv[o] += __shfl_xor(sv[o], 32, 64);  // (independent exchanges: in flight together)
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+          if (o < dK) PL[o * 32 + c] = sv[o];  // (both halves hold the sum and store it)
       }
       __syncthreads();
+      MT(3);  // partial logits
       A = MID_ARGS();
       // ---- loss and output delta (constants.py:15-18, loss.py:1-11), by the first wave of the group: the outputs pass
       // through the row's slots of delta's image (no register arrays: d_K is a run-time number)
@@ -308,40 +380,54 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
         const int n = row0 + c;
         const bool valid = n < A->N;
         const int code = A->act[lt];
-        float mx = -3.0e38f;
-        for (int o = 0; o < dK; ++o) {
-          float v = ((PL[(0 * A->dkp + o) * 32 + c] + PL[(1 * A->dkp + o) * 32 + c]) + PL[(2 * A->dkp + o) * 32 + c]) +
-                    PL[(3 * A->dkp + o) * 32 + c];
-          v = mid_act(code, v + bL[o]);
-          D3[o] = v;  // (both halves of the wave hold the row and store the same value)
-          mx = fmaxf(mx, v);
+        float out[16], mx = -3.0e38f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+          out[o] = 0.0f;
+          if (o < dK)
+            out[o] = (((PL[(0 * A->dkp + o) * 32 + c] + PL[(1 * A->dkp + o) * 32 + c]) + PL[(2 * A->dkp + o) * 32 + c]) +
+                      PL[(3 * A->dkp + o) * 32 + c]) + bL[o];
         }
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+          if (o < dK) {
+            out[o] = mid_act(code, out[o]);
+            mx = fmaxf(mx, out[o]);
+          }
         float row = 0.0f;
         if (A->lik == EY_LIK_BCE_SUM) {
-          for (int o = 0; o < dK; ++o) {
-            const float p = D3[o], yy = valid ? A->y[(size_t)n * dK + o] : 0.0f;
-            row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
-            D3[o] = valid ? (yy / p - (1.0f - yy) / (1.0f - p)) * mid_dact(code, p) : 0.0f;
-          }
+#pragma unroll
+          for (int o = 0; o < 16; ++o)
+            if (o < dK) {
+              const float p = out[o], yy = valid ? A->y[(size_t)n * dK + o] : 0.0f;
+              row += __logf(p) * yy + __logf(1.0f - p) * (1.0f - yy);  // naive logs (eeyore/stats/loss.py:2)
+              out[o] = valid ? (yy / p - (1.0f - yy) / (1.0f - p)) * mid_dact(code, p) : 0.0f;
+            }
         } else {
-          const int lab = valid ? A->labels[n] : 0;
-          float ssum = 0.0f, olab = 0.0f;
-          for (int o = 0; o < dK; ++o) {
-            const float v = D3[o];
-            ssum += __expf(v - mx);
-            olab = o == lab ? v : olab;
+          const int lab = lab_pre;
+          float ssum = 0.0f, olab = 0.0f, e[16];
+#pragma unroll
+          for (int o = 0; o < 16; ++o) {
+            e[o] = 0.0f;
+            if (o < dK) {
+              e[o] = __expf(out[o] - mx);
+              ssum += e[o];
+              olab = o == lab ? out[o] : olab;
+            }
           }
           row = olab - (mx + __logf(ssum));
           const float rs = 1.0f / ssum;
-          for (int o = 0; o < dK; ++o) {
-            const float v = D3[o];
-            D3[o] = valid ? ((o == lab ? 1.0f : 0.0f) - __expf(v - mx) * rs) * mid_dact(code, v) : 0.0f;
-          }
+#pragma unroll
+          for (int o = 0; o < 16; ++o)
+            if (o < dK) out[o] = valid ? ((o == lab ? 1.0f : 0.0f) - e[o] * rs) * mid_dact(code, out[o]) : 0.0f;
         }
-        for (int o = dK; o < 16; ++o) D3[o] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(D3 + 4 * q) = f32x4{out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
         lik += (valid && h == 0) ? row : 0.0f;
       }
       __syncthreads();
+      MT(4);  // loss
       A = MID_ARGS();
       // ---- backward through the output layer: dW_K-1 (block pair (0, fb)), then delta of the last hidden layer
       f32x16 dn;
@@ -372,6 +458,7 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
           *reinterpret_cast<f32x4*>(Ho + 8 * q) = f32x4{dn[4 * q], dn[4 * q + 1], dn[4 * q + 2], dn[4 * q + 3]};
       }
       __syncthreads();
+      MT(5);  // output layer backward
       A = MID_ARGS();
       // ---- backward through the second hidden layer's weights W_1 (three-layer models)
       if (nl == 3) {
@@ -405,6 +492,7 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
         }
         __syncthreads();
       }
+      MT(6);  // second hidden layer backward
       A = MID_ARGS();
       // ---- the first layer's weights: dW_0 = delta_1^T x
       {
@@ -421,6 +509,7 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
           }
         }
       }
+      MT(7);  // first layer's weights
     }  // row tiles
 
     A = MID_ARGS();
@@ -428,20 +517,45 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
     const float tsc = A->temp ? A->temp[chain] : 1.0f;
     float* gout = A->grad + (size_t)chain * A->P;
     float* red = smem + A->grp_at;  // both regions are free now: [4 waves][17][64 lanes]
-    auto combine = [&](f32x16& acc, float& dbv) {
+    // (as many accumulator blocks per pass as the two regions hold, A->red_per: two barriers per pass, not per block)
+    constexpr int NS = S0 + 5;  // slots: the first layer's, the second layer's four, the output layer's
+    auto slot_on = [&](int i) { return i < S0 || i == NS - 1 || nl == 3; };
+    auto red_put = [&](int pos, const f32x16& acc, float dbv) {
+      float* r = red + pos * (4 * 17 * 64) + fb * 17 * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) r[k * 64] = acc[k];
+      r[16 * 64] = dbv;
+    };
+    auto red_get = [&](int pos, f32x16& acc, float& dbv) {
+      const float* r = red + pos * (4 * 17 * 64) + fb * 17 * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] += r[k * 64];
+      dbv += r[16 * 64];
+    };
+    const int per = A->red_per;
+    for (int lo = 0; lo < NS; lo += per) {
       __syncthreads();
       if (rt == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(fb * 17 + r) * 64 + lane] = acc[r];
-        red[(fb * 17 + 16) * 64 + lane] = dbv;
+        for (int i = 0; i < NS; ++i)
+          if (i >= lo && i < lo + per && slot_on(i)) {
+            if (i < S0) red_put(i - lo, acc0[i < S0 ? i : 0], db0[i < S0 ? i : 0]);
+            else if (i < S0 + 4) red_put(i - lo, acc1[(i - S0) & 3], db1[(i - S0) & 3]);
+            else red_put(i - lo, accL, dbL);
+          }
       }
       __syncthreads();
       if (rt == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += red[(fb * 17 + r) * 64 + lane];
-        dbv += red[(fb * 17 + 16) * 64 + lane];
+        for (int i = 0; i < NS; ++i)
+          if (i >= lo && i < lo + per && slot_on(i)) {
+            if (i < S0) red_get(i - lo, acc0[i < S0 ? i : 0], db0[i < S0 ? i : 0]);
+            else if (i < S0 + 4) red_get(i - lo, acc1[(i - S0) & 3], db1[(i - S0) & 3]);
+            else red_get(i - lo, accL, dbL);
+          }
       }
-    };
+    }
+    A = MID_ARGS();
     auto emit = [&](int l, int mm, int nn, const f32x16& acc, float dbv) {
       const int din = A->dims[l], dout = A->dims[l + 1];
       const float* W = smem + A->w_at[l];
@@ -469,7 +583,6 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
       const int mb = (A->dims[1] + 31) >> 5, nb = (A->dims[0] + 31) >> 5;
 #pragma unroll
       for (int s = 0; s < S0; ++s) {
-        combine(acc0[s], db0[s]);
         const int p = fb + 4 * s;
         if (rt == 0 && p < mb * nb) emit(0, p / nb, p % nb, acc0[s], db0[s]);
       }
@@ -478,13 +591,11 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
       const int mb = (A->dims[2] + 31) >> 5, nb = (A->dims[1] + 31) >> 5;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        combine(acc1[s], db1[s]);
         const int p = fb + 4 * s;
         if (rt == 0 && p < mb * nb) emit(1, p / nb, p % nb, acc1[s], db1[s]);
       }
     }
     {
-      combine(accL, dbL);
       const int nb = (A->dims[nl - 1] + 31) >> 5;
       if (rt == 0 && fb < nb) {
         // the output layer's block: rows of the accumulator are outputs (f < dK), its bias sums sit in lanes c < dK
@@ -520,7 +631,15 @@ __global__ void __launch_bounds__(512, 2) k_mid(MidArgs A_) {
     }
     __syncthreads();
     if (tid == 0) A->lik_o[chain] = red[0] + red[1];
+    MT(8);  // combine + write-out
+#if MID_TIMING
+    if (mt_on && lane == 0) atomicAdd(&g_mid_phase[31], 1ull);
+#endif
   }
+#if MID_TIMING
+  if (mt_on && lane == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_mid_phase[i], mt_acc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------- host side
@@ -567,10 +686,11 @@ static bool mid_plan(const EyModel& m, MidArgs& a) {
   a.dkp = (dK + 3) & ~3;
   a.pl_at = g;
   g += 4 * a.dkp * 32;
-  g = std::max(g, 4 * 17 * 64 / 2 + 64);  // the end-of-chain reduction scratch spans both regions
+  g = std::max(g, 4 * 17 * 64 / 2 + 64);  // the end-of-chain reduction scratch spans both regions: at least one block per pass
   g = (g + 3) & ~3;
   a.grp_floats = g;
   a.total_floats = at + 2 * g;
+  a.red_per = std::max(1, (2 * g - 8) / (4 * 17 * 64));
   return (size_t)a.total_floats * sizeof(float) <= 160 * 1024;
 }
 

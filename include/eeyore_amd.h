@@ -253,8 +253,11 @@ int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* ta
  * through the register-resident evaluation of the generic kernels; 10 (ey_debug_set_variant only): new plans, and
  * ey_debug_bgemm, start with EY_PRODUCTS_EXACT; 11: the layerwise path's bf16x3 products split the data matrix in every
  * workgroup instead of taking it pre-split; 12: the layerwise path's epilogues that read per element (prior gradient, fused
- * leapfrog update, act'(H)) element by element instead of in batches of loads.  Results agree to rounding across them (bit
- * for bit across bits 11 and 12). */
+ * leapfrog update, act'(H)) element by element instead of in batches of loads; 3: the fused f32 trajectory kernel's HMC draw with
+ * the pipelined tile loop at one wave per SIMD (same bits, slower: DESIGN.md 4.1.3); 13: value + gradient of mid-size models
+ * (hidden widths 33 .. 128, at most two hidden layers, d_K <= 16, f32) by the fused workgroup-per-chain kernel instead of one
+ * product launch per layer and direction.  Results agree to rounding across them (bit for bit across bits 3,
+ * 11 and 12). */
 int ey_plan_set_variant(ey_plan* plan, int variant);
 int ey_debug_set_variant(int variant);
 

@@ -2684,3 +2684,63 @@ def test_model_surface_ten_classes_and_layers_without_bias():
     assert ch.get_samples().shape == (10, 6, P)
     assert 0.05 < ch.acceptance_rate().mean().item() <= 1.0
     assert torch.isfinite(ch.get_target_vals()).all()
+
+
+@pytest.mark.parametrize("dims,acts,bias,lik,N", [
+    ([20, 100, 100, 5], [1, 1, 0], [1, 1, 1], 1, 70),     # the mid-size model of DESIGN.md 9, ragged rows
+    ([10, 100, 10], [1, 0], [1, 1], 1, 64),               # one hidden layer, ten classes
+    ([40, 70, 33, 2], [1, 2, 1], [1, 1, 1], 0, 130),      # more than 32 inputs, widths off the block grid, BCE on sigmoid outputs
+    ([7, 20, 64, 3], [1, 3, 0], [1, 1, 0], 1, 33),        # relu, a narrow first hidden layer, output layer without bias
+    ([8, 36, 1], [3, 1], [1, 1], 0, 40),                  # one output
+    ([64, 128, 16], [2, 0], [0, 1], 1, 96),               # 128 hidden units, 16 outputs (the limits), 64 inputs; no first bias
+    ([5, 50, 90, 4], [2, 2, 0], [1, 0, 1], 1, 200),       # tanh, second layer without bias, seven row tiles
+])
+def test_fused_midsize_kernel_vs_oracle_and_layerwise(dims, acts, bias, lik, N):
+    """Variant bit 13: value + gradient of mid-size models by the fused workgroup-per-chain kernel (ey_mid.hip: weights resident
+    in LDS, weight-gradient accumulators in registers, one launch) instead of one product launch per layer and direction.
+    Against the f64 oracle on the same f32 inputs and against the layerwise path, with a temperature and an elementwise prior;
+    an HMC draw through it makes the same decisions as through the layerwise path."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(sum(dims) + N)
+    x = rng.standard_normal((N, dims[0])).astype(np.float32)
+    if lik == 1:
+        y = np.eye(dims[-1], dtype=np.float32)[rng.integers(0, dims[-1], N)]
+    else:
+        y = (rng.random((N, dims[-1])) < 0.5).astype(np.float32)
+    P = sum((dims[i] + (1 if bias[i] else 0)) * dims[i + 1] for i in range(len(dims) - 1))
+    mu = (0.1 * rng.standard_normal(P)).astype(np.float32)
+    sg = (1.0 + rng.random(P)).astype(np.float32)
+    C = 9
+    L.lib().ey_debug_set_variant(16)  # these shapes through the layerwise family whatever their size
+    try:
+        pl = Plan(dims, bias, acts, lik, torch.float32, DEV)
+    finally:
+        L.lib().ey_debug_set_variant(0)
+    pl.set_data(_t(x, torch.float32), _t(y, torch.float32))
+    pl.set_prior(torch.tensor(mu), torch.tensor(sg))
+    assert pl.kernel == "bgemm" and pl.P == P
+    co = COracle(dims, acts, lik, x.astype(np.float64), y, mu.astype(np.float64), sg.astype(np.float64), dtype=np.float64, nthreads=8,
+                 bias=bias)
+    th = (0.4 * pl.philox_normal(C, seed=5, it=0)).contiguous()
+    temp = torch.linspace(0.3, 1.0, C, device=DEV)
+    res = {}
+    for v in (16, 16 + 8192):
+        pl.set_variant(v)
+        t, g = pl.log_target_grad(th, temp=temp)
+        a = [th.clone(), t.clone(), g.clone()]
+        out = pl.hmc_step(a[0], a[1], a[2], 0.004, 5, temp=temp, seed=3, it=1)
+        res[v] = (t.cpu().numpy(), g.cpu().numpy(), a[0].cpu().numpy(), out["accepted"].cpu().numpy(), out["h_prop"].cpu().numpy())
+    pl.set_variant(16)
+    for c in range(C):
+        co.temp = float(temp[c].item())
+        to, go, _, _ = co.log_target_grad(th[c].cpu().numpy().astype(np.float64))
+        for v in res:
+            np.testing.assert_allclose(res[v][0][c], to, rtol=2e-5, atol=2e-3)
+            np.testing.assert_allclose(res[v][1][c], go, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(go).max()))
+    a, b = res[16], res[16 + 8192]
+    assert not np.array_equal(a[1], b[1])  # two different kernels (not the same launch twice)
+    np.testing.assert_allclose(b[4], a[4], rtol=1e-4, atol=2e-2)
+    assert (a[3] == b[3]).all()  # the same in-kernel random streams, Hamiltonians equal to rounding: the same decisions
+    same = a[3] == b[3]
+    np.testing.assert_allclose(b[2][same], a[2][same], rtol=2e-3, atol=2e-4)

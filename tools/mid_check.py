@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The fused mid-size kernel (ey_mid.hip) against the layerwise path (variant bit 13) and the f64 oracle: value and gradient by
+"""The fused mid-size kernel (ey_mid.hip) (variant bit 13) against the layerwise path and the f64 oracle: value and gradient by
 parameter block.   usage: python tools/mid_check.py d0,h1[,h2],dK [rows] [lik 0|1] [acts e.g. 1,1,0] [bias e.g. 1,1,1]"""
 import os
 import sys
@@ -45,8 +45,8 @@ for l in range(nl):
 print(f"kernel {pl.kernel}  dims {dims} rows {N} P {pl.P}")
 for c in range(C):
     tt, gg, _, _ = co.log_target_grad(th[c].cpu().numpy().astype(np.float64))
-    line = f"chain {c}: target oracle {tt:.4f} layerwise {res[8192][0][c]:.4f} mid {res[0][0][c]:.4f} |"
+    line = f"chain {c}: target oracle {tt:.4f} layerwise {res[0][0][c]:.4f} mid {res[8192][0][c]:.4f} |"
     for n, a, b in blocks:
         sc = max(1e-6, np.abs(gg[a:b]).max())
-        line += f" {n}: {np.abs(res[8192][1][c][a:b] - gg[a:b]).max() / sc:.1e}/{np.abs(res[0][1][c][a:b] - gg[a:b]).max() / sc:.1e}"
+        line += f" {n}: {np.abs(res[0][1][c][a:b] - gg[a:b]).max() / sc:.1e}/{np.abs(res[8192][1][c][a:b] - gg[a:b]).max() / sc:.1e}"
     print(line)

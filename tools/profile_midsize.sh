@@ -23,6 +23,7 @@ K = len(dims) - 1
 pl = Plan(dims, [1] * K, [1] * (K - 1) + [0], 1, tdt, dev)
 pl.set_data(torch.tensor(x, device=dev), torch.tensor(y, device=dev))
 pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
+pl.set_variant(int('${VARIANT:-0}'))
 th = 0.1 * pl.philox_normal(C, seed=0, it=0)
 t, g = pl.log_target_grad(th)
 for i in range(6):
