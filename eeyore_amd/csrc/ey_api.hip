@@ -27,8 +27,8 @@ __global__ void k_labels(const T* __restrict__ y, int* __restrict__ labels, int6
 
 thread_local int t_ey_variant = 0, t_ey_products = EY_PRODUCTS_BF16X3;
 // what a new plan starts with: EY_VARIANT / EY_F32_PRODUCTS in the environment, or ey_debug_set_variant
-static std::atomic<int> g_ey_default_variant{[] { const char* e = getenv("EY_VARIANT"); return e ? atoi(e) & 16383 : 0; }()};
-int ey_default_variant() { return g_ey_default_variant.load() & (16383 & ~1024); }
+static std::atomic<int> g_ey_default_variant{[] { const char* e = getenv("EY_VARIANT"); return e ? atoi(e) & 32767 : 0; }()};
+int ey_default_variant() { return g_ey_default_variant.load() & (32767 & ~1024); }
 int ey_default_products() {
   if (g_ey_default_variant.load() & 1024) return EY_PRODUCTS_EXACT;
   const char* e = getenv("EY_F32_PRODUCTS");
@@ -95,7 +95,7 @@ int ey_plan_create(ey_plan** out, int n_layers, const int* dims, const int* bias
   hipDeviceProp_t prop;
   EY_HIP(hipGetDeviceProperties(&prop, device_id));
   pl->n_cu = prop.multiProcessorCount;
-  pl->variant = g_ey_default_variant.load() & (16383 & ~1024);
+  pl->variant = g_ey_default_variant.load() & (32767 & ~1024);
   pl->products = (g_ey_default_variant.load() & 1024) ? EY_PRODUCTS_EXACT : ey_default_products();
   {
     const char* e = getenv("EY_ROW_WAVES");
@@ -133,11 +133,11 @@ int ey_plan_num_params(const ey_plan* pl, int64_t* P) {
 // Diagnostic switches for A/B runs and tests (not part of the reference-facing surface).  They belong to the plan:
 // ey_plan_set_variant changes one plan, ey_debug_set_variant the value plans created afterwards start with (and what
 // ey_debug_bgemm, which has no plan, runs under).  Both return the previous value.
-extern "C" int ey_debug_set_variant(int v) { return g_ey_default_variant.exchange(v & 16383); }
+extern "C" int ey_debug_set_variant(int v) { return g_ey_default_variant.exchange(v & 32767); }
 extern "C" int ey_plan_set_variant(ey_plan* pl, int v) {
   if (!pl) return -1;
   const int old = pl->variant;
-  pl->variant = v & (16383 & ~1024);
+  pl->variant = v & (32767 & ~1024);
   return old;
 }
 extern "C" int ey_plan_set_option(ey_plan* pl, int option, int value) {

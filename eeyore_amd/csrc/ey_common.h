@@ -155,6 +155,9 @@ int ey_stats_update_run(const void* samples, const void* accepted_rec, int n_it,
 // fused value + gradient of mid-size MLPs, f32 (ey_mid.hip)
 bool ey_mid_supports(const ey_plan* pl);
 int ey_mid_eval(ey_plan* pl, const float* theta, const float* temp, int C, float* lik_o, float* grad, hipStream_t s);
+bool ey_mid32_supports(const ey_plan* pl);  // narrow deeper models: every hidden width <= 32, up to three hidden layers, d_0 <= 64
+int ey_mid32_eval(ey_plan* pl, const float* theta, const float* temp, int C, float* lik_o, float* grad, void* scratch,
+                  hipStream_t s);
 
 // generic kernels (ey_generic.hip)
 int ey_generic_log_target(ey_plan* pl, const void* theta, const void* temp, int64_t C, void* lik, void* prior,

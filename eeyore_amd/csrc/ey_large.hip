@@ -2173,6 +2173,10 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
     if (grad && !rows_o && !lf && EY_VBIT(13) && ey_mid_supports(pl)) {
       if ((rc = ey_mid_eval(pl, (const float*)theta, (const float*)temp, C, (float*)lik_tmp, (float*)grad, s))) return rc;
       mid = true;
+    } else if (grad && !rows_o && !lf && !EY_VBIT(14) && ey_mid32_supports(pl)) {
+      // narrow deeper models (every hidden width <= 32): one wave per row tile, no barrier inside a chain's rounds
+      if ((rc = ey_mid32_eval(pl, (const float*)theta, (const float*)temp, C, (float*)lik_tmp, (float*)grad, (void*)ws, s))) return rc;
+      mid = true;
     }
   }
   if (!mid) {
@@ -2307,7 +2311,7 @@ static int large_hmc(ey_plan* pl, void* theta, void* target, void* grad, const v
   // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
   const bool tail = sizeof(T) == 4 && tail_ok(m) && !EY_VBIT(6);
   // (the fused mid-size kernel produces the whole gradient in one launch: the leapfrog update then stays k_leap's)
-  const bool fuse = sizeof(T) == 4 && !EY_VBIT(7) && !(EY_VBIT(13) && ey_mid_supports(pl));
+  const bool fuse = sizeof(T) == 4 && !EY_VBIT(7) && !(EY_VBIT(13) && ey_mid_supports(pl)) && !(!EY_VBIT(14) && ey_mid32_supports(pl));
   const int nslots = fuse ? leap_fuse_slots(m, tail) : 0;
   const int nq = nblk > nslots ? nblk : nslots;
   const size_t ws_floats = 2 * (size_t)cc * af + (size_t)cc + 3 * (size_t)cc * P + 2 * (size_t)cc + 2 * (size_t)cc * nq;

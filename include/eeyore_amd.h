@@ -256,8 +256,9 @@ int ey_plan_attach_da(ey_plan* plan, void* state, void* step_vec, const void* ta
  * leapfrog update, act'(H)) element by element instead of in batches of loads; 3: the fused f32 trajectory kernel's HMC draw with
  * the pipelined tile loop at one wave per SIMD (same bits, slower: DESIGN.md 4.1.3); 13: value + gradient of mid-size models
  * (hidden widths 33 .. 128, at most two hidden layers, d_K <= 16, f32) by the fused workgroup-per-chain kernel instead of one
- * product launch per layer and direction.  Results agree to rounding across them (bit for bit across bits 3,
- * 11 and 12). */
+ * product launch per layer and direction; 14: narrow deeper models (every hidden width <= 32, up to three
+ * hidden layers, up to 64 inputs, f32) through those product launches instead of the fused kernel k_mid32 that serves them
+ * by default.  Results agree to rounding across them (bit for bit across bits 3, 11 and 12). */
 int ey_plan_set_variant(ey_plan* plan, int variant);
 int ey_debug_set_variant(int variant);
 

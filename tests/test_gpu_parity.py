@@ -2744,3 +2744,62 @@ def test_fused_midsize_kernel_vs_oracle_and_layerwise(dims, acts, bias, lik, N):
     assert (a[3] == b[3]).all()  # the same in-kernel random streams, Hamiltonians equal to rounding: the same decisions
     same = a[3] == b[3]
     np.testing.assert_allclose(b[2][same], a[2][same], rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("dims,acts,bias,lik,N", [
+    ([16, 32, 32, 32, 3], [1, 1, 1, 0], [1, 1, 1, 1], 1, 150),   # three hidden layers, five row tiles
+    ([64, 32, 32, 10], [1, 1, 0], [1, 1, 1], 1, 150),            # 64 inputs: two input blocks, ten classes
+    ([16, 32, 32, 32, 3], [1, 1, 1, 0], [1, 1, 1, 1], 1, 700),   # 22 row tiles: three rounds, a data tile per wave (no batch image)
+    ([33, 20, 7, 2], [2, 3, 1], [1, 1, 1], 0, 45),               # widths off the grid, tanh / relu, BCE on two sigmoid outputs
+    ([5, 32, 1], [2, 1], [1, 1], 0, 31),                         # one hidden layer, one output, a single ragged tile
+    ([24, 9, 32, 30, 16], [1, 2, 3, 0], [1, 0, 1, 1], 1, 257),   # sixteen outputs, a layer without bias, nine tiles (two rounds)
+])
+def test_fused_narrow_deep_kernel_vs_oracle_and_layerwise(dims, acts, bias, lik, N):
+    """Models whose hidden widths are all <= 32 with up to three hidden layers and up to 64 inputs -- the shapes the
+    one-wave-per-chain families do not take -- run value + gradient on k_mid32 (ey_mid.hip: a workgroup per chain, one wave
+    per row tile, weights in LDS, no barrier inside a chain's rounds) unless variant bit 14 sends them through the layerwise
+    launches.  Against the f64 oracle on the same f32 inputs and against the layerwise path, with a per-chain temperature
+    and an elementwise prior; HMC draws through both make the same decisions."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.plan import Plan
+    rng = np.random.default_rng(sum(dims) + N)
+    x = rng.standard_normal((N, dims[0])).astype(np.float32)
+    if lik == 1:
+        y = np.eye(dims[-1], dtype=np.float32)[rng.integers(0, dims[-1], N)]
+    else:
+        y = (rng.random((N, dims[-1])) < 0.5).astype(np.float32)
+    P = sum((dims[i] + (1 if bias[i] else 0)) * dims[i + 1] for i in range(len(dims) - 1))
+    mu = (0.1 * rng.standard_normal(P)).astype(np.float32)
+    sg = (1.0 + rng.random(P)).astype(np.float32)
+    C = 11
+    L.lib().ey_debug_set_variant(16)  # the layerwise family whatever the model's size
+    try:
+        pl = Plan(dims, bias, acts, lik, torch.float32, DEV)
+    finally:
+        L.lib().ey_debug_set_variant(0)
+    pl.set_data(_t(x, torch.float32), _t(y, torch.float32))
+    pl.set_prior(torch.tensor(mu), torch.tensor(sg))
+    assert pl.kernel == "bgemm" and pl.P == P
+    co = COracle(dims, acts, lik, x.astype(np.float64), y, mu.astype(np.float64), sg.astype(np.float64), dtype=np.float64, nthreads=8,
+                 bias=bias)
+    th = (0.4 * pl.philox_normal(C, seed=5, it=0)).contiguous()
+    temp = torch.linspace(0.3, 1.0, C, device=DEV)
+    res = {}
+    for v in (16 + 16384, 16):
+        pl.set_variant(v)
+        t, g = pl.log_target_grad(th, temp=temp)
+        a = [th.clone(), t.clone(), g.clone()]
+        out = pl.hmc_step(a[0], a[1], a[2], 0.004, 5, temp=temp, seed=3, it=1)
+        res[v] = (t.cpu().numpy(), g.cpu().numpy(), a[0].cpu().numpy(), out["accepted"].cpu().numpy(), out["h_prop"].cpu().numpy())
+    pl.set_variant(16)
+    for c in range(C):
+        co.temp = float(temp[c].item())
+        to, go, _, _ = co.log_target_grad(th[c].cpu().numpy().astype(np.float64))
+        for v in res:
+            np.testing.assert_allclose(res[v][0][c], to, rtol=2e-5, atol=2e-3)
+            np.testing.assert_allclose(res[v][1][c], go, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(go).max()))
+    a, b = res[16 + 16384], res[16]
+    assert not np.array_equal(a[1], b[1])  # two different kernels
+    np.testing.assert_allclose(b[4], a[4], rtol=1e-4, atol=2e-2)
+    assert (a[3] == b[3]).all()
+    np.testing.assert_allclose(b[2], a[2], rtol=2e-3, atol=2e-4)

@@ -24,19 +24,23 @@ if lik == 1:
     y = np.eye(dims[-1], dtype=np.float32)[rng.integers(0, dims[-1], N)]
 else:
     y = (rng.random((N, dims[-1])) < 0.5).astype(np.float32)
+from eeyore_amd import _lib as L
+L.lib().ey_debug_set_variant(16)
 pl = Plan(dims, bias, acts, lik, torch.float32, dev)
+L.lib().ey_debug_set_variant(0)
 pl.set_data(torch.tensor(x, device=dev), torch.tensor(y, device=dev))
 pl.set_prior(torch.zeros(pl.P), torch.full((pl.P,), 2.0))
 co = COracle(dims, acts, lik, x.astype(np.float64), y, 0.0, 2.0, dtype=np.float64, nthreads=4, bias=bias) if "bias" in COracle.__init__.__code__.co_varnames else COracle(dims, acts, lik, x.astype(np.float64), y, 0.0, 2.0, dtype=np.float64, nthreads=4)
 C = 6
 th = (0.3 * pl.philox_normal(C, seed=3, it=0)).contiguous()
 res = {}
-for v in (8192, 0):
-    pl.set_variant(v)
+REF, FUSED = int(os.environ.get('MID_REF', '0')), int(os.environ.get('MID_FUSED', '8192'))
+for v in (REF, FUSED):
+    pl.set_variant(16 | v)
     t, g = pl.log_target_grad(th)
     torch.cuda.synchronize()
     res[v] = (t.cpu().numpy(), g.cpu().numpy())
-pl.set_variant(0)
+pl.set_variant(16)
 blocks, at = [], 0
 for l in range(nl):
     blocks.append((f"W{l}", at, at + dims[l] * dims[l + 1])); at += dims[l] * dims[l + 1]
@@ -45,8 +49,8 @@ for l in range(nl):
 print(f"kernel {pl.kernel}  dims {dims} rows {N} P {pl.P}")
 for c in range(C):
     tt, gg, _, _ = co.log_target_grad(th[c].cpu().numpy().astype(np.float64))
-    line = f"chain {c}: target oracle {tt:.4f} layerwise {res[0][0][c]:.4f} mid {res[8192][0][c]:.4f} |"
+    line = f"chain {c}: target oracle {tt:.4f} layerwise {res[REF][0][c]:.4f} mid {res[FUSED][0][c]:.4f} |"
     for n, a, b in blocks:
         sc = max(1e-6, np.abs(gg[a:b]).max())
-        line += f" {n}: {np.abs(res[0][1][c][a:b] - gg[a:b]).max() / sc:.1e}/{np.abs(res[8192][1][c][a:b] - gg[a:b]).max() / sc:.1e}"
+        line += f" {n}: {np.abs(res[REF][1][c][a:b] - gg[a:b]).max() / sc:.1e}/{np.abs(res[FUSED][1][c][a:b] - gg[a:b]).max() / sc:.1e}"
     print(line)

@@ -23,7 +23,7 @@ K = len(dims) - 1
 pl = Plan(dims, [1] * K, [1] * (K - 1) + [0], 1, torch.float32, dev)
 pl.set_data(torch.tensor(x, device=dev), torch.tensor(y, device=dev))
 pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
-pl.set_variant(8192)
+pl.set_variant(int(os.environ.get('MID_VARIANT', '8192')))
 th = 0.1 * pl.philox_normal(C, seed=0, it=0)
 lib = ct.CDLL(os.environ["EEYORE_AMD_LIB"])
 buf = (ct.c_ulonglong * 32)()
