@@ -510,12 +510,17 @@ def main():
 
     # dominant kernel, timed per launch with HIP events on the launch stream (torch's current stream)
     def launch_ms(n_ev=10):
+        """One launch of ipl iterations of the dominant kernel ALONE: with the moments detached a recording launch does the
+        same work (the moments of a recorded launch are not in the kernel: they come from ey_stats_update_run behind it,
+        which the timed region above includes and this bracket must not)."""
         nonlocal it
+        plan.detach_moments()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
         for a, b in evs:
             a.record(); steps(it, ipl); b.record(); it += ipl
         torch.cuda.synchronize()
-        return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # one launch of ipl iterations
+        stats.attach(plan)
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     kern_ms = launch_ms()
     # the same launches with the other form of the kernel's 32x32x32 products (EY_OPT_F32_PRODUCTS), for the record
