@@ -860,6 +860,7 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
           mid_wave_fence();
         }
       }
+      MT(3);  // data tile, forward through the hidden layers
       A = MID_ARGS();
       // ---- output layer, loss and delta (constants.py:15-18, loss.py:1-11): every lane holds its row's outputs
       const int lt = nl - 1;
@@ -943,6 +944,7 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
         m32_store(Hl, dn, din, c, h);
         mid_wave_fence();
       }
+      MT(4);  // output layer backward
 #pragma unroll
       for (int l = 2; l >= 1; --l) {
         if (l < nl - 1) {  // hidden-to-hidden weights W_l: delta_{l+1} lies in H_{l+1}'s buffer, H_l in its own
@@ -957,6 +959,7 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
           mid_wave_fence();
         }
       }
+      MT(5);  // hidden layers backward
       {
         const float* D = wr_ + A->h_at[1];
 #pragma unroll
@@ -966,8 +969,9 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
         }
       }
       mid_wave_fence();
+      MT(6);  // first layer's dW
     }  // row tiles of this wave
-    MT(1);  // this wave's row tiles
+    MT(1);  // (waves without a tile)
 
     // ---- the eight waves' sums meet: slot by slot through LDS, wave (slot mod 8) adds the copies in wave order and writes
     // that slot's part of the gradient (prior gradient and temperature applied, bayesian_model.py:46-50, :33-34)

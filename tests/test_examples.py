@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("script", ["iris_mala_single_chain.py", "iris_hmc_multichain.py",
-                                    "iris_diagnostics_and_prediction.py"])
+                                    "iris_diagnostics_and_prediction.py", "deep_narrow_hmc.py"])
 def test_example_runs(script):
     env = dict(os.environ, EEYORE_EXAMPLE_EPOCHS="33", EEYORE_EXAMPLE_CHAINS="96", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)], env=env,

@@ -41,6 +41,9 @@ lib.ey_debug_mid_phase_read(buf, 1)
 chains = buf[31]
 names = ["staging", "data tile", "forward hidden", "partial logits", "loss", "output layer backward", "2nd hidden backward",
          "first layer dW", "combine + write-out"]
+if os.environ.get("MID_VARIANT", "8192") == "0":  # k_mid32's stamps
+    names = ["staging", "(waves without a tile)", "output layer + loss", "data tile + forward", "output layer backward", "hidden layers backward",
+             "first layer dW", "-", "waves' sums + write-out"]
 rounds = ((N + 31) // 32 + 1) // 2
 print(f"{dims} N={N} C={C}: {a.elapsed_time(b) / 10 * 1e3:.1f} us per evaluation (whole, with the timing stamps); {chains} chains timed, "
       f"{rounds} rounds per chain; ticks per chain:")
