@@ -2803,3 +2803,41 @@ def test_fused_narrow_deep_kernel_vs_oracle_and_layerwise(dims, acts, bias, lik,
     np.testing.assert_allclose(b[4], a[4], rtol=1e-4, atol=2e-2)
     assert (a[3] == b[3]).all()
     np.testing.assert_allclose(b[2], a[2], rtol=2e-3, atol=2e-4)
+
+
+def test_fused_narrow_deep_kernel_many_chains_and_mala():
+    """More chains than k_mid32's grid has workgroups (each workgroup walks its chains), and the MALA step and the recorded HMC
+    block of a narrow deeper model: the same decisions and states as through the layerwise launches (variant bit 14)."""
+    from eeyore_amd import _lib as L
+    from eeyore_amd.plan import Plan
+    dims, acts, bias, N, C = [16, 32, 32, 32, 3], [1, 1, 1, 0], [1, 1, 1, 1], 150, 1500
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((N, dims[0])).astype(np.float32)
+    y = np.eye(3, dtype=np.float32)[rng.integers(0, 3, N)]
+    pl = Plan(dims, bias, acts, 1, torch.float32, DEV)
+    pl.set_data(_t(x, torch.float32), _t(y, torch.float32))
+    P = pl.P
+    pl.set_prior(torch.zeros(P), torch.full((P,), 3.0).sqrt())
+    assert pl.kernel == "bgemm"
+    th0 = (0.3 * pl.philox_normal(C, seed=9, it=0)).contiguous()
+    res = {}
+    for v in (16384, 0):
+        pl.set_variant(v)
+        t, g = pl.log_target_grad(th0)
+        a = [th0.clone(), t.clone(), g.clone()]
+        o1 = pl.mala_step(a[0], a[1], a[2], 0.002, seed=4, it=1)
+        smp = torch.empty(3, C, P, device=DEV)
+        o2 = pl.hmc_run(a[0], a[1], a[2], 0.01, 6, 3, seed=4, it=2, samples=smp)
+        res[v] = (t.cpu().numpy(), o1["accepted"].cpu().numpy(), o1["log_rate"].cpu().numpy(), o2["accepted"].cpu().numpy(),
+                  a[0].cpu().numpy(), smp.cpu().numpy())
+    pl.set_variant(0)
+    a, b = res[16384], res[0]
+    assert not np.array_equal(a[0], b[0])  # two different kernels
+    np.testing.assert_allclose(b[0], a[0], rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-3, atol=2e-2)
+    assert 0.05 < b[1].mean() < 0.999 and 0.05 < b[3].mean() < 0.999
+    # a Hamiltonian within rounding of log u may fall either way in a chain or two of 1500; everything else agrees
+    same = (a[1] == b[1]) & (a[3] == b[3])
+    assert same.mean() > 0.995
+    np.testing.assert_allclose(b[4][same], a[4][same], rtol=5e-3, atol=5e-4)
+    np.testing.assert_allclose(b[5][:1, same], a[5][:1, same], rtol=5e-3, atol=5e-4)
