@@ -55,12 +55,14 @@ struct BGT {
   // (k_bf3_presplit), pre_rows rows
   const void* pre;
   int pre_rows;
+  const void* preB;  // the same for a B operand the whole batch shares (x in the first layer's weight gradient), preB_rows rows
+  int preB_rows;
   // every parameter has the same prior (mu0, 1 / sigma0^2) (ey_plan_set_prior detects it): the fused update then reads no prior arrays
   int pr_uniform;
   T pr_mu0, pr_iv0;
   int epi_nobatch;  // ey_debug_set_variant bit 12: the element-by-element form of the fused update (A/B runs, tests)
 };
-#define EY_DEV_NOBATCH(g) ((g).epi_nobatch != 0)
+#define EY_DEV_NOBATCH(g) (((g).epi_nobatch & 1) != 0)
 using BG = BGT<float>;
 
 __device__ __forceinline__ float l_act(int code, float g) {
@@ -501,6 +503,25 @@ __device__ __forceinline__ BlockId xcd_block() {
   r.z = t / gy;
   return r;
 }
+// The same with the block COLUMNS divided between the two XCDs of a pair (XCD 2q takes the left half of the columns of the
+// q-th quarter of the batch, XCD 2q + 1 the right half): for a product whose B operand the whole batch shares and whose pre-split
+// image (4.8 MB for config 5's x) does not fit one XCD's 4 MB L2 beside the streams -- half of it does.  The per-batch operand
+// is then fetched by two XCDs instead of one.  Needs an even number of block columns and a batch that divides by four; else the
+// mapping above.  Config 5's first-layer weight gradient: 22.3 -> 19.9 GB of fabric traffic per dispatch, 4.51 -> 4.47 ms
+// (profiles/r05_cfg5_steps.txt; that workgroup id % 8 IS the XCD: tools/xcd_probe.hip, profiles/r05_xcd_probe.txt).
+__device__ __forceinline__ BlockId xcd_block_cols() {
+  const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+  const unsigned nb = gy * gz;
+  if ((gx & 1u) || (nb & 3u)) return xcd_block();
+  const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const unsigned xcd = id & 7u, i = id >> 3, hx = gx >> 1;
+  const unsigned bq = (xcd >> 1) * (nb >> 2) + i / hx;
+  BlockId r;
+  r.x = (xcd & 1u) * hx + i % hx;
+  r.y = bq % gy;
+  r.z = bq / gy;
+  return r;
+}
 
 // C[b] = epilogue(A[b] B[b]).  Block tile BMT x BNT x 16 with two LDS buffers; the 4 waves form a WGM x WGN grid and
 // each owns TM x TN MFMA tiles of 32x32 (v_mfma_f32_32x32x2_f32), so one operand register feeds TN (or TM) MFMAs.
@@ -774,6 +795,25 @@ __global__ void __launch_bounds__(256, 3) k_bgemm_dma(BG g) {
 #define EY_BF3_MINB 3  // workgroups per CU the bf16x3 product is compiled for (three: 168 registers per lane and ~280 bytes of
                        // scratch; two, without the spills, measured 2-5 % slower on config 5: 4.99 / 4.22 against 4.89 / 4.00 ms)
 #endif
+// EY_BF3_TIMING (diagnostic builds, tools/bf3_phase.py): s_memtime sums per phase of the chunk loop, wave 0 of every 16th workgroup
+#ifndef EY_BF3_TIMING
+#define EY_BF3_TIMING 0
+#endif
+#if EY_BF3_TIMING
+__device__ unsigned long long g_bf3_phase[16];
+#define BT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                   __builtin_amdgcn_sched_barrier(0); bt_acc[i] += n_ - bt_t; bt_t = n_; } while (0)
+extern "C" int ey_debug_bf3_phase_read(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bf3_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bf3_phase), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define BT(i) do { } while (0)
+#endif
 #ifndef EY_BF3_SWZ_MASK
 #define EY_BF3_SWZ_MASK 0x0C
 #endif
@@ -834,6 +874,37 @@ __device__ __forceinline__ void bf3_fetch(const float* rowp, long sK, int K, int
     for (int j = 0; j < 8; ++j) v[j] = rowp[(long)min(k0 + j, K - 1) * sK];
   }
 }
+// The same elements addressed as (wave-uniform pointer) + (32-bit lane offset), so that the loads take their base from scalar
+// registers (`global_load v, voffset, s[base]`) and a chunk's address arithmetic is scalar adds: with per-lane 64-bit pointers
+// every chunk cost each wave 24 vector instructions of 64-bit address arithmetic -- v_mad_u64_u32, v_mul_lo_u32, fourteen
+// v_lshl_add_u64 -- in front of its sixteen loads, 1 200 cycles of a 4 400-cycle chunk (tools/bf3_phase.py).
+// base: the operand of this batch item (uniform); lane_off: row * row stride (+ 8 tg when k is contiguous), in elements;
+// ktg: 8 tg when the rows are contiguous (uniform per wave then), else 0.  KTAIL = 0 only.
+// lane_off[j] (rows contiguous): row * row stride + j * sK, kept in eight registers (opaque: folded back into one lane pointer
+// plus scalar offsets the compiler gives every load its own v_lshl_add_u64 again); k contiguous: one offset, row * stride + 8 tg.
+template <bool KF>
+__device__ __forceinline__ void bf3_fetch_u(const float* base, const unsigned (&lane_off)[8], long sK, int kt, int ktg, float (&v)[8]) {
+  if constexpr (KF) {
+    const float* ub = base + (long)kt * BK3;
+    const char* ubc = reinterpret_cast<const char*>(ub);  // (byte offsets: base + zext(offset) is the pattern the scalar-base form needs)
+    // opaque HERE, on a copy: a zero-extension hoisted out of the loop arrives as a 64-bit lane value and the loads fall back to
+    // per-lane pointers.  (Made opaque in place -- no v_mov -- the sixteen offsets become loop-carried through sixteen ordered
+    // statements and the schedule falls apart: config 5's weight gradient 5.96 ms against 4.68.)
+    unsigned o = lane_off[0];
+    asm volatile("" : "+v"(o));
+    const f32x4_u lo = *reinterpret_cast<const f32x4_u*>(ubc + o), hi = *reinterpret_cast<const f32x4_u*>(ubc + o + 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+  } else {
+    const char* ubc = reinterpret_cast<const char*>(base + (long)(kt * BK3 + ktg) * sK);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned o = lane_off[j];
+      asm volatile("" : "+v"(o));
+      v[j] = *reinterpret_cast<const float*>(ubc + o);
+    }
+  }
+}
 template <int KTAIL>
 __device__ __forceinline__ void bf3_zero_tail(int K, int kt, int tg, float (&v)[8]) {
   if constexpr (KTAIL) {
@@ -868,7 +939,12 @@ __global__ void __launch_bounds__(256) k_bf3_presplit(const float* __restrict__ 
 // loads and the split, which every workgroup of every chain otherwise repeats on the same data: config 5's forward
 // product 4.54 -> 4.24 ms.  (The same for x as the B operand of the first layer's weight gradient measured 5 % SLOWER,
 // 6.97 -> 7.35 ms: 48 bytes per task instead of 32 through an L2 that product already saturates.  Not kept.)
-template <bool AK, bool BK_, bool PRE = false, int KTAIL = 0>
+// PREB: the same for a shared B operand (x in the first layer's weight gradient; round 5: 4.68 -> 4.48 ms once the fetches
+// took their base from scalar registers, see bf3_fetch_u -- the L2 that "saturated" in round 3 was the wave waiting to issue).
+// Measured on these two kernels in round 5 and not kept: the pre-split operand's fragments loaded straight from
+// the image into the operand registers (no LDS: neutral / 6 % slower), three chunks of fetches in flight (neutral), issue
+// priorities by wave slot (3 % slower), sched_group_barrier pipelines of the split behind the products (neutral, then spills).
+template <bool AK, bool BK_, int PRE = 0, int KTAIL = 0, int PREB = 0>
 __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
   __shared__ __attribute__((aligned(16))) u32x4_t As[2][3 * 128 * 2];
   __shared__ __attribute__((aligned(16))) u32x4_t Bs[2][3 * 128 * 2];
@@ -877,7 +953,7 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const BlockId bid = xcd_block();
+  const BlockId bid = PREB ? xcd_block_cols() : xcd_block();
   const int m0 = bid.y * 128, n0 = bid.x * 128;
   const long b = bid.z;
   const float* A = g.A + b * g.bA;
@@ -890,7 +966,7 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int ktiles = (g.K + BK3 - 1) / BK3;
-  const bool want_rowsum = !PRE && g.rowsum != nullptr && bid.x == 0;  // (a pre-split A is never a delta: no row sums)
+  const bool want_rowsum = PRE == 0 && g.rowsum != nullptr && bid.x == 0;  // (a pre-split A is never a delta: no row sums)
   float rsum = 0.0f;
   // staging tasks: k contiguous -> consecutive lanes take the two granules of a row; rows contiguous -> consecutive lanes
   // take consecutive rows
@@ -903,6 +979,15 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
   const int fb[2] = {rb * 2 + (h ^ BF3_SWZ(rb)), (rb + 32) * 2 + (h ^ BF3_SWZ(rb + 32))};
   const float* arow = A + (long)min(m0 + ar, g.M - 1) * g.sAm;
   const float* brow = B + (long)min(n0 + br, g.N - 1) * g.sBn;
+  // (uniform base) + (lane offset) addressing of the K-whole instantiations, see bf3_fetch_u
+  unsigned a_off[8], b_off[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a_off[j] = 4u * ((unsigned)(min(m0 + ar, g.M - 1) * g.sAm) + (AK ? 8u * ag : (unsigned)(j * g.sAk)));  // bytes
+    b_off[j] = 4u * ((unsigned)(min(n0 + br, g.N - 1) * g.sBn) + (BK_ ? 8u * bg : (unsigned)(j * g.sBk)));
+  }
+  const int a_ktg = AK ? 0 : 8 * __builtin_amdgcn_readfirstlane(ag);
+  const int b_ktg = BK_ ? 0 : 8 * __builtin_amdgcn_readfirstlane(bg);
   // Two chunks of fetches are in flight: chunk kt + 2 is requested at the top of iteration kt, chunk kt + 1 (requested an
   // iteration earlier) is split and staged at its end.  With one chunk ahead every iteration waited for the fetch it had just
   // issued (s_waitcnt vmcnt(0) behind 24 MFMAs = 0.3 us of cover for a 1 - 2 us round trip): the matrix pipe was busy 36 - 47 %
@@ -912,43 +997,74 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
   const int pr = tid >> 1, pg = tid & 1;
   const int p_slot = pr * 2 + (pg ^ BF3_SWZ(pr));
   const long pre_chunk = (long)g.pre_rows * 2;  // 16-byte units per (k-chunk, piece)
-  const u32x4_t* pre = !PRE ? nullptr : reinterpret_cast<const u32x4_t*>(g.pre) + (long)min(m0 + pr, g.M - 1) * 2 + pg;
+  const u32x4_t* pre_img = reinterpret_cast<const u32x4_t*>(g.pre);
+  const unsigned pre_off = PRE != 1 ? 0u : 16u * (unsigned)(min(m0 + pr, g.M - 1) * 2 + pg);
   u32x4_t vp[2][3];
+  const long preb_chunk = (long)g.preB_rows * 2;
+  const u32x4_t* preb_img = reinterpret_cast<const u32x4_t*>(g.preB);
+  const unsigned preb_off = PREB != 1 ? 0u : 16u * (unsigned)(min(n0 + pr, g.N - 1) * 2 + pg);
+  u32x4_t vpb[2][3];
   auto fetch = [&](int kt, auto set_tag) {
     constexpr int S = decltype(set_tag)::value;
-    if constexpr (PRE) {
+    if constexpr (PRE == 1) {
+      unsigned o = pre_off;  // (scalar base + lane offset, as bf3_fetch_u)
+      asm volatile("" : "+v"(o));
 #pragma unroll
-      for (int p = 0; p < 3; ++p) vp[S][p] = pre[(long)(kt * 3 + p) * pre_chunk];
-    } else {
-      bf3_fetch<AK, KTAIL>(arow, g.sAk, g.K, kt, ag, va[S]);
+      for (int p = 0; p < 3; ++p)
+        vp[S][p] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(pre_img + (long)(kt * 3 + p) * pre_chunk) + o);
+    } else if constexpr (PRE == 0) {
+      if constexpr (KTAIL == 0) bf3_fetch_u<AK>(A, a_off, g.sAk, kt, a_ktg, va[S]);
+      else bf3_fetch<AK, KTAIL>(arow, g.sAk, g.K, kt, ag, va[S]);
     }
-    bf3_fetch<BK_, KTAIL>(brow, g.sBk, g.K, kt, bg, vb[S]);
+    if constexpr (PREB == 1) {
+      unsigned o = preb_off;
+      asm volatile("" : "+v"(o));
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        vpb[S][p] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(preb_img + (long)(kt * 3 + p) * preb_chunk) + o);
+    } else if constexpr (PREB == 0) {
+      if constexpr (KTAIL == 0) bf3_fetch_u<BK_>(B, b_off, g.sBk, kt, b_ktg, vb[S]);
+      else bf3_fetch<BK_, KTAIL>(brow, g.sBk, g.K, kt, bg, vb[S]);
+    }
   };
   auto stage = [&](int st, int kt, auto set_tag) {  // chunk kt from register set S into LDS stage st
     constexpr int S = decltype(set_tag)::value;
     u32x4_t hi, mid, lo;
     if constexpr (!PRE) bf3_zero_tail<KTAIL>(g.K, kt, ag, va[S]);
-    bf3_zero_tail<KTAIL>(g.K, kt, bg, vb[S]);
-    if constexpr (PRE) {
+    if constexpr (!PREB) bf3_zero_tail<KTAIL>(g.K, kt, bg, vb[S]);
+    if constexpr (PRE == 1) {
       As[st][0 * 256 + p_slot] = vp[S][0]; As[st][1 * 256 + p_slot] = vp[S][1]; As[st][2 * 256 + p_slot] = vp[S][2];
-    } else {
-      if (want_rowsum && kt < ktiles)  // (the iteration behind the last chunk stages that chunk once more: not summed twice)
-        rsum += ((va[S][0] + va[S][1]) + (va[S][2] + va[S][3])) + ((va[S][4] + va[S][5]) + (va[S][6] + va[S][7]));
+    } else if constexpr (PRE == 0) {
+      // (the iteration behind the last chunk stages that chunk once more: not summed twice.  A select, not a branch: a branch
+      // here ends the basic block of the chunk's products, and the split below can then never be scheduled among them)
+      const float rs8 = ((va[S][0] + va[S][1]) + (va[S][2] + va[S][3])) + ((va[S][4] + va[S][5]) + (va[S][6] + va[S][7]));
+      rsum = __builtin_fmaf(rs8, (want_rowsum && kt < ktiles) ? 1.0f : 0.0f, rsum);  // (x 1 and + 0 are exact: the same sums)
       l_split8(va[S], hi, mid, lo);
       As[st][0 * 256 + a_slot] = hi; As[st][1 * 256 + a_slot] = mid; As[st][2 * 256 + a_slot] = lo;
     }
-    l_split8(vb[S], hi, mid, lo);
-    Bs[st][0 * 256 + b_slot] = hi; Bs[st][1 * 256 + b_slot] = mid; Bs[st][2 * 256 + b_slot] = lo;
+    if constexpr (PREB == 1) {
+      Bs[st][0 * 256 + p_slot] = vpb[S][0]; Bs[st][1 * 256 + p_slot] = vpb[S][1]; Bs[st][2 * 256 + p_slot] = vpb[S][2];
+    } else if constexpr (PREB == 0) {
+      l_split8(vb[S], hi, mid, lo);
+      Bs[st][0 * 256 + b_slot] = hi; Bs[st][1 * 256 + b_slot] = mid; Bs[st][2 * 256 + b_slot] = lo;
+    }
   };
   typedef std::integral_constant<int, 0> Set0;
   typedef std::integral_constant<int, 1> Set1;
   // one iteration: chunk kt is multiplied out of LDS stage kt & 1; chunk kt + 2 goes into the register set chunk kt had,
   // chunk kt + 1 leaves the other one for LDS stage (kt + 1) & 1
+#if EY_BF3_TIMING
+  unsigned long long bt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long bt_t = __builtin_amdgcn_s_memtime();
+  const unsigned long long bt_begin = bt_t;
+#endif
   auto iteration = [&](int kt, auto mine, auto other) {
     const int cur = kt & 1;
+    BT(0);  // (what lies between the barrier and here: loop control)
     // (unconditional: behind a branch the compiler can no longer count how many younger loads may stay in flight when it
     // waits for chunk kt + 1 and waits for all of them; the last two iterations fetch the last chunk again, unused)
     fetch(min(kt + 2, ktiles - 1), mine);
+    BT(1);  // the fetches issued
     u32x4_t pa[2][3], pb[2][3];  // [tile][piece: hi, mid, lo]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -957,6 +1073,13 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
         pa[i][p] = As[cur][p * 256 + fa[i]];
         pb[i][p] = Bs[cur][p * 256 + fb[i]];
       }
+#if EY_BF3_TIMING
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) asm volatile("" : "+v"(pa[i][pp]), "+v"(pb[i][pp]));
+#endif
+    BT(2);  // the fragments read
     // (hi, lo), (lo, hi), (mid, mid), (hi, mid), (mid, hi), (hi, hi): smallest terms first
     constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -965,10 +1088,13 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = l_mfma_bf16(pa[i][TA[t]], pb[j][TB[t]], acc[i][j]);
+    BT(3);  // the products issued
     // (unconditional as well: the last iteration stages the re-fetched last chunk into the stage nobody reads any more;
     // behind a branch the loop header waited for every load, see fetch)
     stage(cur ^ 1, kt + 1, other);
+    BT(4);  // chunk kt + 1 split and staged
     __syncthreads();
+    BT(5);  // the barrier
   };
   fetch(0, Set0());
   stage(0, 0, Set0());
@@ -980,6 +1106,9 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
     iteration(kt + 1, Set1(), Set0());
   }
   if (kt < ktiles) iteration(kt, Set0(), Set1());
+#if EY_BF3_TIMING
+  const unsigned long long bt_loop_end = __builtin_amdgcn_s_memtime();
+#endif
   bool do_rowsum = false;
   if (want_rowsum) {  // the two granule columns of a row, in a fixed order
     rs_red[ag][ar] = rsum;
@@ -988,6 +1117,17 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
     if (do_rowsum) rsum = rs_red[0][tid] + rs_red[1][tid];
   }
   bg_epilogue<2, 2, 2, 2>(g, acc, m0, n0, wm, wn, c, h, b, rsum, do_rowsum, tid);
+#if EY_BF3_TIMING
+  if (tid == 0 && (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) % 16 == 0) {
+    const unsigned long long bt_end = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_bf3_phase[i], bt_acc[i]);
+    atomicAdd(&g_bf3_phase[8], bt_loop_end - bt_begin);  // the chunk loop
+    atomicAdd(&g_bf3_phase[9], bt_end - bt_loop_end);    // row sums + epilogue
+    atomicAdd(&g_bf3_phase[10], 1ull);
+    atomicAdd(&g_bf3_phase[11], (unsigned long long)ktiles);
+  }
+#endif
 }
 
 static bool dma_ok(const BG& g, bool& kfast) {
@@ -1239,6 +1379,7 @@ static int bgemm(const BG& g, int batch, hipStream_t s, int* cursor = nullptr, b
     const long off = (long)body.N * g.sCn;  // the tail's columns: B, C and everything indexed like C move along n
     tail.N = rem;
     tail.B = g.B + (long)body.N * g.sBn;
+    tail.preB = nullptr;
     tail.C = g.C + off;
     tail.rowsum = nullptr;  // the body's first block column has written the row sums
     if (g.pr_theta) { tail.pr_theta = g.pr_theta + off; tail.pr_mu = g.pr_mu + off; tail.pr_iv = g.pr_iv + off; }
@@ -1281,11 +1422,14 @@ static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry) {
     else if (ktail == 1) hipLaunchKernelGGL((k_bgemm_bf3<A_, B_, P_, 1>), grid, dim3(256), 0, s, g);   \
     else hipLaunchKernelGGL((k_bgemm_bf3<A_, B_, P_, 0>), grid, dim3(256), 0, s, g);                   \
   } while (0)
-      if (g.pre && a_k && b_k && !g.rowsum) EY_BF3_LAUNCH(true, true, true);
-      else if (a_k && b_k) EY_BF3_LAUNCH(true, true, false);
-      else if (a_k) EY_BF3_LAUNCH(true, false, false);
-      else if (b_k) EY_BF3_LAUNCH(false, true, false);
-      else EY_BF3_LAUNCH(false, false, false);
+      if (g.preB && !a_k && !b_k) {  // (rows contiguous on both sides: K's tail is 0 or 1)
+        if (ktail == 1) hipLaunchKernelGGL((k_bgemm_bf3<false, false, 0, 1, 1>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_bgemm_bf3<false, false, 0, 0, 1>), grid, dim3(256), 0, s, g);
+      } else if (g.pre && a_k && b_k && !g.rowsum) EY_BF3_LAUNCH(true, true, 1);
+      else if (a_k && b_k) EY_BF3_LAUNCH(true, true, 0);
+      else if (a_k) EY_BF3_LAUNCH(true, false, 0);
+      else if (b_k) EY_BF3_LAUNCH(false, true, 0);
+      else EY_BF3_LAUNCH(false, false, 0);
 #undef EY_BF3_LAUNCH
     } else if (g_bgemm_dma && dma_ok(g, kfast)) {
       if (kfast) hipLaunchKernelGGL(k_bgemm_dma<true>, grid, dim3(256), 0, s, g);
@@ -2064,11 +2208,15 @@ void ey_large_free(ey_plan* pl) {
 // The data matrix x [N, d0] as the first layer's forward product takes it in the bf16x3 form (its A operand: rows n, k =
 // input), split once per batch (ey_plan_set_data counts the batches) on the caller's stream: 4.8 MB for config 5's
 // 1024 x 784; every workgroup of every chain then copies its pieces instead of splitting the same numbers again.
-static int ensure_xpre(ey_plan* pl, hipStream_t s, const void** out) {
+// Round 5: beside it the same matrix as the first layer's weight gradient takes it (its B operand: rows = inputs, k = n) when
+// that product is a 128-wide one (more than 32 inputs): *out_b, else null.
+static bool xpre_wants_b(const EyModel& m) { return m.dims[0] > 32; }
+static int ensure_xpre(ey_plan* pl, hipStream_t s, const void** out, const void** out_b) {
   const EyModel& m = pl->m;
   const int N = m.N, d0 = m.dims[0];
-  const int ktiles = (d0 + BK3 - 1) / BK3;
-  const size_t bytes = (size_t)16 * ktiles * 3 * N * 2;
+  const int ktiles = (d0 + BK3 - 1) / BK3, ktiles_b = (N + BK3 - 1) / BK3;
+  const size_t bytes_a = (size_t)16 * ktiles * 3 * N * 2;
+  const size_t bytes = bytes_a + (xpre_wants_b(m) ? (size_t)16 * ktiles_b * 3 * d0 * 2 : 0);
   if (pl->xpre_bytes < bytes) {
     EY_HIP(hipDeviceSynchronize());
     (void)hipFree(pl->d_xpre);
@@ -2082,6 +2230,11 @@ static int ensure_xpre(ey_plan* pl, hipStream_t s, const void** out) {
     const long tasks = (long)ktiles * N * 2;
     hipLaunchKernelGGL(k_bf3_presplit, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, (const float*)m.x, (long)d0, 1L, N,
                        d0, (u32x4_t*)pl->d_xpre);
+    if (xpre_wants_b(m)) {
+      const long tasks_b = (long)ktiles_b * d0 * 2;
+      hipLaunchKernelGGL(k_bf3_presplit, dim3((unsigned)((tasks_b + 255) / 256)), dim3(256), 0, s, (const float*)m.x, 1L, (long)d0,
+                         d0, N, (u32x4_t*)((char*)pl->d_xpre + bytes_a));
+    }
     EY_HIP(hipGetLastError());
     if (!pl->xpre_event) EY_HIP(hipEventCreateWithFlags(&pl->xpre_event, hipEventDisableTiming));
     EY_HIP(hipEventRecord(pl->xpre_event, s));
@@ -2092,6 +2245,7 @@ static int ensure_xpre(ey_plan* pl, hipStream_t s, const void** out) {
     EY_HIP(hipStreamWaitEvent(s, pl->xpre_event, 0));
   }
   *out = pl->d_xpre;
+  *out_b = xpre_wants_b(m) ? (const void*)((const char*)pl->d_xpre + bytes_a) : nullptr;
   return EY_OK;
 }
 
@@ -2158,9 +2312,10 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
   int rc, cursor = 0;
   // bf16x3 form, first layer wide enough for the 128-wide product: x comes pre-split (variant bit 11 switches it off)
   const void* xpre = nullptr;
+  const void* xpreT = nullptr;  // ... and as the B operand of the first layer's weight gradient
   if constexpr (sizeof(T) == 4) {
     if (t_ey_products == EY_PRODUCTS_BF16X3 && N > 32 && m.dims[1] > 32 && m.dims[0] >= 16 && !EY_VBIT(11))
-      if ((rc = ensure_xpre(pl, s, &xpre))) return rc;
+      if ((rc = ensure_xpre(pl, s, &xpre, &xpreT))) return rc;
   }
   // f32 only: in f64 the fused kernel measured SLOWER than the separate launches (every lane of a row repeats the
   // row's loss with the library exp / log, and eight-byte accumulators spill) -- 1.0 ms against 0.6 ms on MLP(10-100-10)
@@ -2233,6 +2388,9 @@ static int eval_chunk(ey_plan* pl, const T* theta, const T* temp, int C, T* lik_
       g.B = l == 0 ? (const T*)m.x : H[l]; g.sBk = m.dims[l]; g.sBn = 1; g.bB = l == 0 ? 0 : (long)N * m.dims[l];
       g.C = grad + m.woff[l]; g.sCm = m.dims[l]; g.sCn = 1; g.bC = P;
       g.M = m.dims[l + 1]; g.N = m.dims[l]; g.K = N; g.act = EY_ACT_NONE;
+      if constexpr (sizeof(T) == 4) {
+        if (l == 0 && xpreT) { g.preB = xpreT; g.preB_rows = m.dims[0]; }
+      }
       if (m.boff[l] >= 0) { g.rowsum = grad + m.boff[l]; g.bRow = P; }
       g.pr_theta = theta + m.woff[l]; g.pr_mu = (const T*)m.mu + m.woff[l]; g.pr_iv = (const T*)m.inv_var + m.woff[l];
       if (m.boff[l] >= 0) {
