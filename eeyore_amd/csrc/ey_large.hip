@@ -878,30 +878,50 @@ __device__ __forceinline__ void bf3_fetch(const float* rowp, long sK, int K, int
 // registers (`global_load v, voffset, s[base]`) and a chunk's address arithmetic is scalar adds: with per-lane 64-bit pointers
 // every chunk cost each wave 24 vector instructions of 64-bit address arithmetic -- v_mad_u64_u32, v_mul_lo_u32, fourteen
 // v_lshl_add_u64 -- in front of its sixteen loads, 1 200 cycles of a 4 400-cycle chunk (tools/bf3_phase.py).
-// base: the operand of this batch item (uniform); lane_off: row * row stride (+ 8 tg when k is contiguous), in elements;
-// ktg: 8 tg when the rows are contiguous (uniform per wave then), else 0.  KTAIL = 0 only.
-// lane_off[j] (rows contiguous): row * row stride + j * sK, kept in eight registers (opaque: folded back into one lane pointer
-// plus scalar offsets the compiler gives every load its own v_lshl_add_u64 again); k contiguous: one offset, row * stride + 8 tg.
-template <bool KF>
-__device__ __forceinline__ void bf3_fetch_u(const float* base, const unsigned (&lane_off)[8], long sK, int kt, int ktg, float (&v)[8]) {
+// base: the operand of this batch item (uniform).  KTAIL as bf3_fetch (which stays for reference: the same elements).
+template <bool KF, int KTAIL>
+__device__ __forceinline__ void bf3_fetch_u(const float* base, unsigned row_b, const unsigned (&row_jb)[8], long sK, int K, int kt, int tg,
+                                            int ktg, float (&v)[8]) {
+  // row_b: this lane's row * row stride, in bytes; tg: the lane's k-half (k contiguous); ktg: 8 * the WAVE's k-half (rows contiguous).
+  // Every offset is made opaque HERE, on a copy: a zero-extension hoisted out of the loop arrives as a 64-bit lane value and the
+  // loads fall back to per-lane pointers.  (Opaque in place -- no v_mov -- the offsets become loop-carried through ordered
+  // statements and the schedule falls apart: config 5's weight gradient 5.96 ms against 4.68.)
+  const char* bc = reinterpret_cast<const char*>(base);  // (byte offsets: base + zext(offset) is the pattern the scalar-base form needs)
   if constexpr (KF) {
-    const float* ub = base + (long)kt * BK3;
-    const char* ubc = reinterpret_cast<const char*>(ub);  // (byte offsets: base + zext(offset) is the pattern the scalar-base form needs)
-    // opaque HERE, on a copy: a zero-extension hoisted out of the loop arrives as a 64-bit lane value and the loads fall back to
-    // per-lane pointers.  (Made opaque in place -- no v_mov -- the sixteen offsets become loop-carried through sixteen ordered
-    // statements and the schedule falls apart: config 5's weight gradient 5.96 ms against 4.68.)
-    unsigned o = lane_off[0];
-    asm volatile("" : "+v"(o));
-    const f32x4_u lo = *reinterpret_cast<const f32x4_u*>(ubc + o), hi = *reinterpret_cast<const f32x4_u*>(ubc + o + 16);
+    const int k0 = kt * BK3 + 8 * tg;
+    if constexpr (KTAIL == 1) {  // K not a multiple of 4: dword loads, k clamped
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
-  } else {
-    const char* ubc = reinterpret_cast<const char*>(base + (long)(kt * BK3 + ktg) * sK);
+      for (int j = 0; j < 8; ++j) {
+        unsigned o = row_b + 4u * (unsigned)min(k0 + j, K - 1);
+        asm volatile("" : "+v"(o));
+        v[j] = *reinterpret_cast<const float*>(bc + o);
+      }
+    } else {
+      unsigned o1 = row_b + 4u * (unsigned)(KTAIL ? min(k0, K - 4) : k0);
+      unsigned o2 = row_b + 4u * (unsigned)(KTAIL ? min(k0 + 4, K - 4) : k0 + 4);
+      asm volatile("" : "+v"(o1));
+      asm volatile("" : "+v"(o2));
+      const f32x4_u lo = *reinterpret_cast<const f32x4_u*>(bc + o1), hi = *reinterpret_cast<const f32x4_u*>(bc + o2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+    }
+  } else if constexpr (KTAIL == 0) {  // rows contiguous, the k index is the wave's: ONE scalar base per chunk and the lane's eight
+                                      // offsets row_jb[j] = row_b + 4 j sK kept in registers (eight scalar bases and one lane
+                                      // offset measured slower: 4.60 against 4.47 ms on config 5's weight gradient)
+    const char* ubc = bc + (long)(kt * BK3 + ktg) * sK * 4;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      unsigned o = lane_off[j];
+      unsigned o = row_jb[j];
       asm volatile("" : "+v"(o));
       v[j] = *reinterpret_cast<const float*>(ubc + o);
+    }
+  } else {  // ... with a clamped k: a scalar base per load
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = min(kt * BK3 + ktg + j, K - 1);
+      unsigned o = row_b;
+      asm volatile("" : "+v"(o));
+      v[j] = *reinterpret_cast<const float*>(bc + (long)k * sK * 4 + o);
     }
   }
 }
@@ -977,14 +997,13 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
   const int ra = wm * 64 + c, rb = wn * 64 + c;
   const int fa[2] = {ra * 2 + (h ^ BF3_SWZ(ra)), (ra + 32) * 2 + (h ^ BF3_SWZ(ra + 32))};
   const int fb[2] = {rb * 2 + (h ^ BF3_SWZ(rb)), (rb + 32) * 2 + (h ^ BF3_SWZ(rb + 32))};
-  const float* arow = A + (long)min(m0 + ar, g.M - 1) * g.sAm;
-  const float* brow = B + (long)min(n0 + br, g.N - 1) * g.sBn;
   // (uniform base) + (lane offset) addressing of the K-whole instantiations, see bf3_fetch_u
-  unsigned a_off[8], b_off[8];
+  const unsigned a_rowb = 4u * (unsigned)(min(m0 + ar, g.M - 1) * g.sAm), b_rowb = 4u * (unsigned)(min(n0 + br, g.N - 1) * g.sBn);
+  unsigned a_rowjb[8], b_rowjb[8];  // (only the rows-contiguous K-whole instantiations keep them)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    a_off[j] = 4u * ((unsigned)(min(m0 + ar, g.M - 1) * g.sAm) + (AK ? 8u * ag : (unsigned)(j * g.sAk)));  // bytes
-    b_off[j] = 4u * ((unsigned)(min(n0 + br, g.N - 1) * g.sBn) + (BK_ ? 8u * bg : (unsigned)(j * g.sBk)));
+    a_rowjb[j] = a_rowb + 4u * (unsigned)(j * g.sAk);
+    b_rowjb[j] = b_rowb + 4u * (unsigned)(j * g.sBk);
   }
   const int a_ktg = AK ? 0 : 8 * __builtin_amdgcn_readfirstlane(ag);
   const int b_ktg = BK_ ? 0 : 8 * __builtin_amdgcn_readfirstlane(bg);
@@ -1013,8 +1032,7 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
       for (int p = 0; p < 3; ++p)
         vp[S][p] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(pre_img + (long)(kt * 3 + p) * pre_chunk) + o);
     } else if constexpr (PRE == 0) {
-      if constexpr (KTAIL == 0) bf3_fetch_u<AK>(A, a_off, g.sAk, kt, a_ktg, va[S]);
-      else bf3_fetch<AK, KTAIL>(arow, g.sAk, g.K, kt, ag, va[S]);
+      bf3_fetch_u<AK, KTAIL>(A, a_rowb, a_rowjb, g.sAk, g.K, kt, ag, a_ktg, va[S]);
     }
     if constexpr (PREB == 1) {
       unsigned o = preb_off;
@@ -1023,8 +1041,7 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
       for (int p = 0; p < 3; ++p)
         vpb[S][p] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(preb_img + (long)(kt * 3 + p) * preb_chunk) + o);
     } else if constexpr (PREB == 0) {
-      if constexpr (KTAIL == 0) bf3_fetch_u<BK_>(B, b_off, g.sBk, kt, b_ktg, vb[S]);
-      else bf3_fetch<BK_, KTAIL>(brow, g.sBk, g.K, kt, bg, vb[S]);
+      bf3_fetch_u<BK_, KTAIL>(B, b_rowb, b_rowjb, g.sBk, g.K, kt, bg, b_ktg, vb[S]);
     }
   };
   auto stage = [&](int st, int kt, auto set_tag) {  // chunk kt from register set S into LDS stage st
