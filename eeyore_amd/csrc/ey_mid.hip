@@ -819,6 +819,9 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
     }
     __syncthreads();
     MT(0);  // staging
+#if MID_TIMING
+    const unsigned long long mt_w0 = __builtin_amdgcn_s_memtime();  // every wave of a timed workgroup: its tiles' duration
+#endif
     f32x16 accF[NB0], accH[2], accL;
     float dbF = 0.0f, dbH[2] = {0.0f, 0.0f}, dbL = 0.0f, lik = 0.0f;
 #pragma unroll
@@ -972,6 +975,9 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
       MT(6);  // first layer's dW
     }  // row tiles of this wave
     MT(1);  // (waves without a tile)
+#if MID_TIMING
+    if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd(&g_mid_phase[16 + wave], __builtin_amdgcn_s_memtime() - mt_w0);
+#endif
 
     // ---- the eight waves' sums meet: slot by slot through LDS, wave (slot mod 8) adds the copies in wave order and writes
     // that slot's part of the gradient (prior gradient and temperature applied, bayesian_model.py:46-50, :33-34)
@@ -1020,8 +1026,10 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
       }
     };
     const int per = A->red_per;
+    MT(8);  // (temperature, pointers)
     for (int lo = 0; lo < NS; lo += per) {
       __syncthreads();
+      MT(9);  // the barrier in front of a pass (the first one: waiting for the slowest wave's tiles)
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_)
         if (s_ >= lo && s_ < lo + per && slot_on(s_)) {
@@ -1030,10 +1038,13 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
           else if (s_ == NB0 + 1) put(s_ - lo, accH[1], dbH[1]);
           else put(s_ - lo, accL, dbL);
         }
+      MT(10);  // accumulators to LDS
       __syncthreads();
+      MT(11);  // the barrier behind them
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_)
         if (s_ >= lo && s_ < lo + per && slot_on(s_)) emit(s_ - lo, slot_layer(s_), s_ < NB0 ? s_ : 0);
+      MT(12);  // sums, prior gradient, stores
     }
     // ---- the log-likelihood, in wave order
     __syncthreads();
@@ -1045,7 +1056,7 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
     }
     __syncthreads();
     if (tid == 0) A->lik_o[chain] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-    MT(8);  // the waves' sums, write-out
+    MT(13);  // the log-likelihood
 #if MID_TIMING
     if (mt_on && lane == 0) atomicAdd(&g_mid_phase[31], 1ull);
 #endif

@@ -43,12 +43,15 @@ names = ["staging", "data tile", "forward hidden", "partial logits", "loss", "ou
          "first layer dW", "combine + write-out"]
 if os.environ.get("MID_VARIANT", "8192") == "0":  # k_mid32's stamps
     names = ["staging", "(waves without a tile)", "output layer + loss", "data tile + forward", "output layer backward", "hidden layers backward",
-             "first layer dW", "-", "waves' sums + write-out"]
+             "first layer dW", "-", "end: temperature, pointers", "end: barrier in front of a pass", "end: accumulators to LDS",
+             "end: barrier behind them", "end: sums, prior gradient, stores", "end: log-likelihood"]
 rounds = ((N + 31) // 32 + 1) // 2
 print(f"{dims} N={N} C={C}: {a.elapsed_time(b) / 10 * 1e3:.1f} us per evaluation (whole, with the timing stamps); {chains} chains timed, "
       f"{rounds} rounds per chain; ticks per chain:")
-tot = sum(buf[i] for i in range(9)) / max(1, chains)
+tot = sum(buf[i] for i in range(len(names))) / max(1, chains)
 for i, n in enumerate(names):
     v = buf[i] / max(1, chains)
     print(f"  {n:26s}{v:10.0f}  ({100 * v / tot:4.1f} %)" + (f"  = {v / rounds:8.0f} per round" if 1 <= i <= 7 else ""))
 print(f"  total {tot:.0f}")
+if any(buf[16 + w] for w in range(8)):
+    print("  the tiles of a chain by wave: " + " ".join(f"{buf[16 + w] / max(1, chains):.0f}" for w in range(8)))
