@@ -587,6 +587,9 @@ def main():
                 "kernel_ms": kern_ms, "leapfrog_steps_per_launch": C * L_STEPS * ipl,
                 "flops_per_leapfrog_step_per_chain": f_step,
                 "peak_measured": MEASURED_F32_MFMA_TFLOPS, "frac_of_measured": achieved_tflops / MEASURED_F32_MFMA_TFLOPS,
+                # what the matrix pipes sustain alone at the socket's power limit (tools/mfma_power_probe.hip, operands whose bits
+                # change; profiles/r05_mfma_power_probe.txt, r05_clock_power.txt: this kernel runs at 1 360 W and 2.36 GHz)
+                "sustained_at_power_limit": {"f32_mfma_tflops": 139.5, "bf16_mfma_tflops": [1731.7, 1814.6]},
             },
         }
         if ess is not None:
