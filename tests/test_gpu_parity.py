@@ -2610,22 +2610,22 @@ def test_batched_gemm_vs_torch_bmm(M, N, K, kfast, act, products):
     assert (C.double() - ref).abs().max().item() < tol
 
 
-@pytest.mark.parametrize("dims,N", [([784, 128, 10], 96), ([100, 64, 3], 200), ([45, 40, 40, 5], 77)])
-def test_bgemm_path_presplit_data_matrix_is_the_same_arithmetic(dims, N):
+@pytest.mark.parametrize("dims,N,C", [([784, 128, 10], 96, 8), ([100, 64, 3], 200, 5), ([45, 40, 40, 5], 77, 5), ([256, 256, 4], 80, 4)])
+def test_bgemm_path_presplit_data_matrix_is_the_same_arithmetic(dims, N, C):
     """bf16x3 form of the layerwise path: the first layer's forward product takes the data matrix already split into its
     bf16 pieces (made once per batch) instead of splitting it in every workgroup: bit-identical values and gradients
     (variant bit 11 switches the image off), also for K that is not a multiple of the 16-deep chunk (100, 45), and the
     image follows a new batch handed over with set_data (same size and a larger one).  Round 5: with more than 32 inputs the
     first layer's weight gradient takes x pre-split as well (its B operand: the image's second half), and with an even
     number of block columns and a chain count that divides by four its workgroups are dealt to the XCDs by column halves
-    (xcd_block_cols: eight chains on the 784-input model, six block columns)."""
+    (xcd_block_cols: eight chains on the 784-input model, six block columns; four chains, two block columns and two block
+    rows on the 256-256 one)."""
     from eeyore_amd.plan import Plan
     K = len(dims) - 1
     rng = np.random.default_rng(5)
     pl = Plan(dims, [1] * K, [1] * (K - 1) + [0], 1, torch.float32, DEV)
     assert pl.kernel == "bgemm" and pl.f32_products == "bf16x3"
     pl.set_prior(torch.zeros(pl.P), torch.ones(pl.P))
-    C = 8 if dims[0] == 784 else 5
     th = _t((0.05 * rng.standard_normal((C, pl.P))).astype(np.float32), torch.float32)
     prev = None
     for n_rows in (N, N, N + 64):
