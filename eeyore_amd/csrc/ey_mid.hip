@@ -799,23 +799,33 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
       for (int k = tid & 7; k < ldx; k += 8) XS[r * ldx + k] = (k < d0 && rv) ? xr[k] : 0.0f;
     }
   }
+  // a chain's parameters are fetched while the chain before it sums and writes its gradient (the end of a chain is barriers
+  // and LDS round trips: the fetch's trip to memory costs nothing there and 2 500 cycles in front of the tiles)
+  float vnx[MID32_SPT];
+  auto fetch_theta = [&](int ch) {
+    const float* thn = MID_ARGS()->theta + (size_t)ch * MID_ARGS()->P;
+    const int P = MID_ARGS()->P;
+#pragma unroll
+    for (int t = 0; t < MID32_SPT; ++t) {
+      const int e = tid + 512 * t;
+      vnx[t] = e < P ? thn[e] : 0.0f;
+    }
+  };
+  if ((int)blockIdx.x < A->C) fetch_theta(blockIdx.x);
   for (int chain = blockIdx.x; chain < A->C; chain += gridDim.x) {
     A = MID_ARGS();
-    const float* th = A->theta + (size_t)chain * A->P;
     __syncthreads();
     {
-      float v[MID32_SPT];
       int d[MID32_SPT];
       const int P = A->P;
 #pragma unroll
       for (int t = 0; t < MID32_SPT; ++t) {
         const int e = tid + 512 * t;
-        v[t] = e < P ? th[e] : 0.0f;
         d[t] = e < P ? A->tab[e] : -1;
       }
 #pragma unroll
       for (int t = 0; t < MID32_SPT; ++t)
-        if (d[t] >= 0) smem[d[t]] = v[t];
+        if (d[t] >= 0) smem[d[t]] = vnx[t];
     }
     __syncthreads();
     MT(0);  // staging
@@ -979,6 +989,7 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
     if ((blockIdx.x & 63) == 0 && lane == 0) atomicAdd(&g_mid_phase[16 + wave], __builtin_amdgcn_s_memtime() - mt_w0);
 #endif
 
+    if (chain + (int)gridDim.x < A->C) fetch_theta(chain + gridDim.x);  // (uniform)
     // ---- the eight waves' sums meet: slot by slot through LDS, wave (slot mod 8) adds the copies in wave order and writes
     // that slot's part of the gradient (prior gradient and temperature applied, bayesian_model.py:46-50, :33-34)
     A = MID_ARGS();
@@ -1014,7 +1025,7 @@ __global__ void __launch_bounds__(512, 2) k_mid32(MidArgs A_) {
           gout[idx] = (v - (W[f * A->ldw[l] + i] - m_) * i_) * tsc;
         }
       }
-      if (wave == 0 && nn == 0 && A->boff[l] >= 0) {
+      if (wave == (pos & 7) && nn == 0 && A->boff[l] >= 0) {  // (the slots' bias sums dealt over the waves, not all to wave 0)
         float dbv = 0.0f;
         for (int w = 0; w < 8; ++w) dbv += r0[(w * 17 + 16) * 64];
         const float tot = dbv + __shfl_xor(dbv, 32, 64);
