@@ -1697,25 +1697,45 @@ __global__ void __launch_bounds__(256) k_hmc_begin(const T* __restrict__ theta, 
   // plain pointers every element's copy waited for the store before it (5.6 ms for config 5's share, 1.2 TB/s)
   // (the same number of rounds in every thread, the kinetic energy summed outside the per-element branch: DESIGN.md 4.4)
   const int nb4 = (P + 3) / 4, rounds = (nb4 + (int)blockDim.x - 1) / (int)blockDim.x;
+  // (round 5: a block of four that lies inside P moves as one 16-byte piece per array -- a chain's arrays start at a multiple of
+  // P elements, so the pieces are only element-aligned, as any global access on this device may be; element by element every
+  // wave instruction touched a quarter of the bytes of the lines it opened: 3.1 ms for config 5's share, 2.7 TB/s)
+  typedef T vec4e __attribute__((ext_vector_type(4), aligned(sizeof(T))));
 #pragma unroll 4
   for (int r = 0; r < rounds; ++r) {
     const int b = (int)threadIdx.x + r * (int)blockDim.x;
     T o[4];
     if (!p0) ey_rng_normal4<T>(rn, (uint32_t)b, o);
+    const bool whole = 4 * b + 3 < P;
+    const long k0 = c * P + (whole ? 4 * b : 0);
+    T pz[4];
+    if (whole) {
+      vec4e pv4;
+      if (p0) pv4 = *reinterpret_cast<const vec4e*>(p0 + k0);
+      else pv4 = vec4e{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<vec4e*>(p + k0) = pv4;
+      *reinterpret_cast<vec4e*>(thp + k0) = *reinterpret_cast<const vec4e*>(theta + k0);
+      *reinterpret_cast<vec4e*>(gp + k0) = *reinterpret_cast<const vec4e*>(grad + k0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = 4 * b + j;
-      const bool on = i < P;
-      const long k = c * P + (on ? i : P - 1);
-      const T pv = p0 ? p0[k] : o[j];
-      const T pz = on ? pv : T(0.0);
-      kin += pz * pz;
-      if (on) {
-        p[k] = pv;
-        thp[k] = theta[k];
-        gp[k] = grad[k];
+      for (int j = 0; j < 4; ++j) pz[j] = pv4[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = 4 * b + j;
+        const bool on = i < P;
+        const long k = c * P + (on ? i : P - 1);
+        const T pv = p0 ? p0[k] : o[j];
+        pz[j] = on ? pv : T(0.0);
+        if (on) {
+          p[k] = pv;
+          thp[k] = theta[k];
+          gp[k] = grad[k];
+        }
       }
     }
+    // (summed outside the branches, element after element as before: the same bits)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kin += pz[j] * pz[j];
   }
   kin = block_sum(kin, red);
   if (threadIdx.x == 0) hcur[c] = -target[c] + T(0.5) * kin;  // hmc.py:91-98,137
