@@ -1244,6 +1244,9 @@ static int smallk_kind(const BGT<T>& g) {
 // gradient (the sum of delta over rows), prior gradient, temperature and, when asked, the leapfrog update with the
 // workgroup's partial prior sum in ONE slot.
 #define DWN_XROWS 64
+#ifndef DWN_FLIGHT
+#define DWN_FLIGHT 8  // rows of delta in flight per thread (16, and a 128-row x tile: 0.652 against 0.605 ms on config 5's sixteen remainder columns)
+#endif
 template <class T>
 __global__ void __launch_bounds__(256) k_dw_smalln(BGT<T> g) {
   __shared__ __attribute__((aligned(16))) T xs[DWN_XROWS * 16];
@@ -1269,12 +1272,12 @@ __global__ void __launch_bounds__(256) k_dw_smalln(BGT<T> g) {
     __syncthreads();
     if (live) {
       // eight rows' delta values are fetched before any is used: the loop is bound by the latency of these loads
-      for (int kk = grp; kk < kn; kk += 8 * G) {
-        T a[8];
+      for (int kk = grp; kk < kn; kk += DWN_FLIGHT * G) {
+        T a[DWN_FLIGHT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = kk + u * G < kn ? A[(long)(k0 + kk + u * G) * g.sAk + m] : T(0.0);
+        for (int u = 0; u < DWN_FLIGHT; ++u) a[u] = kk + u * G < kn ? A[(long)(k0 + kk + u * G) * g.sAk + m] : T(0.0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DWN_FLIGHT; ++u) {
           if (kk + u * G >= kn) break;
           rs += a[u];
           const Vec4<T>* xr = reinterpret_cast<const Vec4<T>*>(xs + (kk + u * G) * 16);
@@ -1401,6 +1404,11 @@ static int bgemm(const BG& g, int batch, hipStream_t s, int* cursor = nullptr, b
     tail.rowsum = nullptr;  // the body's first block column has written the row sums
     if (g.pr_theta) { tail.pr_theta = g.pr_theta + off; tail.pr_mu = g.pr_mu + off; tail.pr_iv = g.pr_iv + off; }
     if (g.lf_p) { tail.lf_p = g.lf_p + off; tail.lf_p_b = nullptr; }
+    {  // sixteen columns or fewer: the vector-ALU kernel that reads delta once per chain (k_dw_smalln) rather than a 32-wide f32 tile
+      bool handled;
+      rc = bgemm_narrow(tail, batch, s, cursor, dry, &handled);
+      if (handled) return rc;
+    }
     return bgemm_one(tail, batch, s, cursor, dry);
   }
   return bgemm_one(g, batch, s, cursor, dry);
