@@ -523,6 +523,20 @@ __device__ __forceinline__ BlockId xcd_block_cols() {
   return r;
 }
 
+// ... and the block ROWS, for a product whose A operand the whole batch shares (x in the first layer's forward product; one block
+// column): XCD 2q takes the upper half of the rows of the q-th quarter of the batch.  Config 5's forward product 3.80 -> 3.75 ms.
+__device__ __forceinline__ BlockId xcd_block_rows() {
+  const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+  if (gx != 1u || (gy & 1u) || (gz & 3u)) return xcd_block();
+  const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const unsigned xcd = id & 7u, i = id >> 3, hy = gy >> 1;
+  BlockId r;
+  r.x = 0;
+  r.y = (xcd & 1u) * hy + i % hy;
+  r.z = (xcd >> 1) * (gz >> 2) + i / hy;
+  return r;
+}
+
 // C[b] = epilogue(A[b] B[b]).  Block tile BMT x BNT x 16 with two LDS buffers; the 4 waves form a WGM x WGN grid and
 // each owns TM x TN MFMA tiles of 32x32 (v_mfma_f32_32x32x2_f32), so one operand register feeds TN (or TM) MFMAs.
 //   <2,2,2,2>: 128 x 128 (the big products)   <1,1,4,1>: 128 x 32 (narrow N)   <1,1,1,4>: 32 x 128 (narrow M)
@@ -973,7 +987,7 @@ __global__ void __launch_bounds__(256, EY_BF3_MINB) k_bgemm_bf3(BG g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const BlockId bid = PREB ? xcd_block_cols() : xcd_block();
+  const BlockId bid = PREB ? xcd_block_cols() : (PRE ? xcd_block_rows() : xcd_block());
   const int m0 = bid.y * 128, n0 = bid.x * 128;
   const long b = bid.z;
   const float* A = g.A + b * g.bA;
