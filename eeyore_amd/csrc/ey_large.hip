@@ -1452,7 +1452,10 @@ static int bgemm_one(BG g, int batch, hipStream_t s, int* cursor, bool dry) {
     dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
     bool kfast = false;
     const bool a_k = g.sAk == 1, b_k = g.sBk == 1;
-    if (t_ey_products == EY_PRODUCTS_BF16X3 && (a_k || g.sAm == 1) && (b_k || g.sBn == 1)) {
+    // (the bf16x3 kernel addresses an operand of one batch item with 32-bit byte offsets from a scalar base, bf3_fetch_u: an
+    // operand beyond 4 GB per item -- a million rows of a thousand features -- takes the f32 kernels and their 64-bit pointers)
+    const bool fits32 = (g.M - 1) * g.sAm + (g.K + BK3) * g.sAk < (1L << 30) && (g.N - 1) * g.sBn + (g.K + BK3) * g.sBk < (1L << 30);
+    if (t_ey_products == EY_PRODUCTS_BF16X3 && (a_k || g.sAm == 1) && (b_k || g.sBn == 1) && fits32) {
       // the tail of K (a pre-split operand is zero-padded to whole chunks: its own fetch has none)
       const int ktail = g.K % BK3 == 0 ? 0 : ((a_k || b_k) && g.K % 4 == 0 && g.K >= 4 ? 2 : 1);
 #define EY_BF3_LAUNCH(A_, B_, P_)                                                                      \
